@@ -1,0 +1,160 @@
+"""ctypes front-end of the CPU ORACLE (oracle/libte_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (traversability_estimation_amd) never does.  See oracle/te_oracle.h for what is restated.
+
+Layers are float32 numpy arrays in grid_map storage order: flat, column-major,
+value(i, j) = a[j * rows + i].  2-D views used here have shape (cols, rows) (C-contiguous), i.e.
+``a2d[j, i]``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Geom(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("res", C.c_double), ("len_x", C.c_double),
+                ("len_y", C.c_double), ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("normals_radius", C.c_double), ("normals_axis", C.c_int), ("slope_critical", C.c_double),
+                ("step_critical", C.c_double), ("step_radius1", C.c_double), ("step_radius2", C.c_double),
+                ("step_ncrit", C.c_int), ("rough_critical", C.c_double), ("rough_radius", C.c_double),
+                ("w_scale", C.c_float), ("w_slope", C.c_float), ("w_step", C.c_float), ("w_rough", C.c_float),
+                ("fp_radius", C.c_double), ("fp_offset", C.c_double), ("fp_default", C.c_double),
+                ("fp_max_gap", C.c_double), ("fp_critical_step", C.c_double), ("fp_check_roughness", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libte_oracle.so")
+    src = os.path.join(_HERE, "te_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libte_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libte_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        fp = C.POINTER(C.c_float)
+        gp, pp = C.POINTER(Geom), C.POINTER(Params)
+        L.teo_geom_init.argtypes = [gp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.teo_params_default.argtypes = [pp]
+        L.teo_set_threads.argtypes = [C.c_int]
+        L.teo_get_max_threads.restype = C.c_int
+        L.teo_normals.argtypes = [gp, fp, C.c_double, C.c_int, fp, fp, fp]
+        L.teo_slope.argtypes = [gp, fp, C.c_double, fp]
+        L.teo_step.argtypes = [gp, fp, C.c_double, C.c_double, C.c_double, C.c_int, fp, fp]
+        L.teo_roughness.argtypes = [gp, fp, fp, fp, fp, C.c_double, C.c_double, fp]
+        L.teo_combine.argtypes = [C.c_long, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+        L.teo_chain.argtypes = [gp, pp, fp, fp, fp, fp, fp, fp, fp, fp]
+        L.teo_footprint.argtypes = [gp, pp, fp, fp, fp, fp, fp, fp, fp, fp, fp]
+        L.teo_circle_count.argtypes = [gp, C.c_int, C.c_int, C.c_double]
+        ip = C.POINTER(C.c_int)
+        L.teo_spiral_offsets.argtypes = [gp, C.c_int, C.c_int, C.c_double, ip, ip, ip, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def geom(rows, cols, res, pos=(0.0, 0.0)):
+    g = Geom()
+    lib().teo_geom_init(C.byref(g), int(rows), int(cols), float(res), float(pos[0]), float(pos[1]))
+    return g
+
+
+def default_params(**over):
+    p = Params()
+    lib().teo_params_default(C.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def set_threads(n):
+    lib().teo_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().teo_get_max_threads())
+
+
+def _flat(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    assert a.size == n, (a.size, n)
+    return a
+
+
+def chain(g, p, elev, want_normals=False):
+    """Run normals->slope->step->roughness->combine.  Returns dict of flat float32 layers."""
+    n = g.rows * g.cols
+    e = _flat(elev, n)
+    out = {k: np.empty(n, np.float32) for k in ("traversability_slope", "traversability_step",
+                                                "traversability_roughness", "traversability")}
+    nrm = [np.empty(n, np.float32) for _ in range(3)] if want_normals else [None] * 3
+    rc = lib().teo_chain(C.byref(g), C.byref(p), _f(e), _f(out["traversability_slope"]),
+                         _f(out["traversability_step"]), _f(out["traversability_roughness"]),
+                         _f(out["traversability"]), _f(nrm[0]), _f(nrm[1]), _f(nrm[2]))
+    if rc:
+        raise RuntimeError(f"teo_chain failed: {rc}")
+    if want_normals:
+        out["surface_normal_x"], out["surface_normal_y"], out["surface_normal_z"] = nrm
+    return out
+
+
+def step(g, elev, crit, r1, r2, ncrit, want_step_height=False):
+    n = g.rows * g.cols
+    e = _flat(elev, n)
+    out = np.empty(n, np.float32)
+    sh = np.empty(n, np.float32) if want_step_height else None
+    rc = lib().teo_step(C.byref(g), _f(e), crit, r1, r2, int(ncrit), _f(out), _f(sh))
+    if rc:
+        raise RuntimeError(f"teo_step failed: {rc}")
+    return (out, sh) if want_step_height else out
+
+
+def footprint(g, p, elev, layers, want_memo=False):
+    n = g.rows * g.cols
+    e = _flat(elev, n)
+    sl = _flat(layers["traversability_slope"], n)
+    st = _flat(layers["traversability_step"], n)
+    ro = _flat(layers["traversability_roughness"], n)
+    tr = _flat(layers["traversability"], n)
+    fp = np.empty(n, np.float32)
+    memo = [np.empty(n, np.float32) for _ in range(3)] if want_memo else [None] * 3
+    rc = lib().teo_footprint(C.byref(g), C.byref(p), _f(e), _f(sl), _f(st), _f(ro), _f(tr), _f(fp), _f(memo[0]),
+                             _f(memo[1]), _f(memo[2]))
+    if rc:
+        raise RuntimeError(f"teo_footprint failed: {rc}")
+    if want_memo:
+        return fp, dict(slope_footprint=memo[0], step_footprint=memo[1], roughness_footprint=memo[2])
+    return fp
+
+
+def circle_count(g, i, j, radius):
+    return int(lib().teo_circle_count(C.byref(g), int(i), int(j), float(radius)))
+
+
+def spiral_offsets(g, ci, cj, radius, cap=4096):
+    di = (C.c_int * cap)()
+    dj = (C.c_int * cap)()
+    rg = (C.c_int * cap)()
+    n = lib().teo_spiral_offsets(C.byref(g), int(ci), int(cj), float(radius), di, dj, rg, cap)
+    if n < 0 or n > cap:
+        raise RuntimeError(f"teo_spiral_offsets: {n}")
+    return np.array(di[:n]), np.array(dj[:n]), np.array(rg[:n])

@@ -1,0 +1,104 @@
+/*
+ * te_oracle.h -- CPU ORACLE for the traversability filter chain.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's CPU algorithm for the hot path
+ * (surface normals -> slope -> step -> roughness -> weighted combine -> circular footprint).
+ * It exists to CHECK the HIP path and to be TIMED as the CPU baseline; it is never the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (libtravgpu.so) neither links nor calls anything in this directory.
+ *
+ * Reference files restated (paths relative to /root/reference):
+ *   traversability_estimation_filters/src/SlopeFilter.cpp:59-88
+ *   traversability_estimation_filters/src/StepFilter.cpp:102-182
+ *   traversability_estimation_filters/src/RoughnessFilter.cpp:73-132
+ *   traversability_estimation/src/TraversabilityMap.cpp:307-318,654-746,774-921
+ *   traversability_estimation/config/robot_filter_parameter.yaml:1-37 (chain order and defaults)
+ * Un-vendored dependencies restated from their published algorithm (no version pinned by the
+ * reference; de-facto ros-noetic-grid-map 1.6.x / Eigen 3.3.7 -- SURVEY.md 8c):
+ *   grid_map_core : GridMap geometry (getPositionFromIndex / getIndexFromPosition / isInside /
+ *                   getSubmap), GridMapIterator, CircleIterator, SpiralIterator, LineIterator
+ *   grid_map_filters : NormalVectorsFilter (area method), MathExpressionFilter (fixed weighted
+ *                   sum form), DeletionFilter
+ *
+ * Parity pin: the reference's own fixture traversability_estimation/maps/elevation_map.bag holds
+ * golden outputs of the default chain; tests/test_oracle_kat.py checks this oracle against it
+ * (bit-exact on step and combine, bit-exact on slope/roughness except the two exactly-planar
+ * border cells documented in SURVEY.md F6).  The circular-footprint pass has NO golden vector in
+ * the reference ("parity unpinned" for te_oracle_footprint).
+ *
+ * Data contract: layers are float32, COLUMN-major like grid_map::Matrix (Eigen::MatrixXf):
+ * element (row i, col j) at data[j * rows + i].  Invalid cell == non-finite value.
+ * All per-cell arithmetic is double, as in the reference; only layer storage is float.
+ */
+#ifndef TE_ORACLE_H
+#define TE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct teo_geom {
+  int rows, cols;      /* grid_map size(0), size(1) */
+  double res;          /* resolution [m] */
+  double len_x, len_y; /* rows*res, cols*res (GridMap::setGeometry) */
+  double pos_x, pos_y; /* map centre position */
+} teo_geom;
+
+typedef struct teo_params {
+  /* NormalVectorsFilter (robot_filter_parameter.yaml:3-9) */
+  double normals_radius;
+  int normals_axis; /* 0:x 1:y 2:z  (normal_vector_positive_axis) */
+  /* SlopeFilter (:10-14) */
+  double slope_critical;
+  /* StepFilter (:15-22) */
+  double step_critical, step_radius1, step_radius2;
+  int step_ncrit;
+  /* RoughnessFilter (:23-28) */
+  double rough_critical, rough_radius;
+  /* MathExpressionFilter fixed form (:29-33): out = w_scale * ((w_slope*s + w_step*t) + w_rough*r) in float32 */
+  float w_scale, w_slope, w_step, w_rough;
+  /* circular footprint (TraversabilityMap.cpp:307-318, robot_footprint_parameter.yaml, robot.yaml) */
+  double fp_radius, fp_offset;   /* radiusMin = fp_radius, radiusMax = fp_radius + fp_offset */
+  double fp_default;             /* traversability_default for NaN traversability */
+  double fp_max_gap;             /* max_gap_width */
+  double fp_critical_step;       /* criticalStepHeight_ (= stepFilter.critical_value, TraversabilityMap.cpp:117-126) */
+  int fp_check_roughness;        /* footprint/verify_roughness_footprint */
+} teo_params;
+
+void teo_geom_init(teo_geom* g, int rows, int cols, double res, double pos_x, double pos_y);
+void teo_params_default(teo_params* p); /* shipped YAML defaults */
+
+/* number of OpenMP threads used by the loops below (1 = the reference's single thread) */
+void teo_set_threads(int n);
+int teo_get_max_threads(void);
+
+/* a1: NormalVectorsFilter, area method. Outputs NaN where the centre elevation is invalid. */
+int teo_normals(const teo_geom* g, const float* elev, double radius, int axis, float* nx, float* ny, float* nz);
+/* a2: SlopeFilter::update */
+int teo_slope(const teo_geom* g, const float* nz, double crit, float* out);
+/* a4+a5: StepFilter::update. step_height_out may be NULL (temp layer is erased by the filter). */
+int teo_step(const teo_geom* g, const float* elev, double crit, double r1, double r2, int ncrit, float* out,
+             float* step_height_out);
+/* a7: RoughnessFilter::update */
+int teo_roughness(const teo_geom* g, const float* elev, const float* nx, const float* ny, const float* nz,
+                  double crit, double radius, float* out);
+/* a9: MathExpressionFilter, fixed weighted-sum form, float32 arithmetic */
+int teo_combine(long n, const float* slope, const float* step, const float* rough, float w_scale, float w_slope,
+                float w_step, float w_rough, float* out);
+/* a1..a10 in YAML order; normals may be NULL (DeletionFilter drops them) */
+int teo_chain(const teo_geom* g, const teo_params* p, const float* elev, float* slope, float* step, float* rough,
+              float* trav, float* nx, float* ny, float* nz);
+/* a13+a14: traversabilityFootprint(radius, offset) over the whole map, starting from all-NaN caches.
+ * slope_fp/step_fp/rough_fp (memo layers) may be NULL. */
+int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                  const float* rough, const float* trav, float* footprint, float* slope_fp, float* step_fp,
+                  float* rough_fp);
+
+/* helpers exposed for tests */
+int teo_circle_count(const teo_geom* g, int i, int j, double radius);
+int teo_spiral_offsets(const teo_geom* g, int ci, int cj, double radius, int* di, int* dj, int* ring, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
