@@ -1,0 +1,162 @@
+/*
+ * travgpu.h -- C-ABI of libtravgpu.so: the MI355X (gfx950) traversability filter chain.
+ *
+ * This is the drop-in boundary for ONE hot path of leggedrobotics/traversability_estimation: the
+ * filter chain that `filter_chain_.update(elevationMapCopy, traversabilityMapCopy)` runs
+ * (traversability_estimation/src/TraversabilityMap.cpp:214) plus the circular footprint pass
+ * (TraversabilityMap.cpp:307-318).  The shim owns the device-resident elevation and output layers
+ * and launches the HIP chain; plain pointers and sizes only, no C++/torch types.
+ *
+ * Which reference interface each entry point replaces (paths relative to the reference root):
+ *
+ *   te_set_params        <- FilterBase<T>::getParam() reads in
+ *                           traversability_estimation_filters/src/SlopeFilter.cpp:34-56,
+ *                           StepFilter.cpp:38-99, RoughnessFilter.cpp:36-70, the
+ *                           NormalVectorsFilter / MathExpressionFilter entries of
+ *                           traversability_estimation/config/robot_filter_parameter.yaml:3-9,29-33
+ *                           and the footprint parameters read in TraversabilityMap.cpp:108-126
+ *   te_set_geometry      <- grid_map::GridMap::setGeometry (length/resolution/position) as used by
+ *                           TraversabilityMap::setElevationMap, TraversabilityMap.cpp:135-154
+ *   te_upload_elevation  <- the "elevation" layer of mapIn handed to every plugin's
+ *                           update(const T& mapIn, T& mapOut) (SlopeFilter.cpp:59, StepFilter.cpp:102,
+ *                           RoughnessFilter.cpp:73)
+ *   te_run_chain         <- filters::FilterChain<GridMap>::update, TraversabilityMap.cpp:214
+ *                           (NormalVectorsFilter -> SlopeFilter::update -> StepFilter::update ->
+ *                           RoughnessFilter::update -> MathExpressionFilter -> DeletionFilter)
+ *   te_run_footprint     <- TraversabilityMap::traversabilityFootprint(radius, offset),
+ *                           TraversabilityMap.cpp:307-318 (isTraversable :654-746,
+ *                           isTraversableForFilters :774-792, checkFor{Slope,Step,Roughness} :794-921)
+ *   te_download_layer    <- mapOut.add(type_) / mapOut.at(type_, index) results of each plugin
+ *                           (SlopeFilter.cpp:63,77-80 etc.)
+ *
+ * Data contract (identical to grid_map::Matrix = Eigen::MatrixXf): float32, COLUMN-major,
+ * element (row i, col j) of map m at ptr[m*rows*cols + j*rows + i]; invalid cell = non-finite.
+ * Circular-buffer start index must be (0,0) (GridMap::convertToDefaultStartIndex() on the host).
+ *
+ * All functions return TE_OK (0) or a negative te_status; te_last_error() gives the message of the
+ * calling thread's last failure.  A context is internally serialised (one mutex, one HIP stream);
+ * different contexts may be used concurrently from different threads.
+ */
+#ifndef TRAVGPU_H
+#define TRAVGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TE_ABI_VERSION 1
+
+typedef enum te_status {
+  TE_OK = 0,
+  TE_ERR_INVALID_ARG = -1, /* NULL pointer, bad enum, bad size */
+  TE_ERR_BAD_PARAM = -2,   /* a filter parameter outside the range the reference's configure() accepts */
+  TE_ERR_NOT_READY = -3,   /* geometry/params/elevation missing, or chain not run before footprint */
+  TE_ERR_HIP = -4,         /* HIP runtime error (message has hipGetErrorString) */
+  TE_ERR_NO_DEVICE = -5,   /* no usable gfx950 device: the library never falls back to the CPU */
+  TE_ERR_UNSUPPORTED = -6  /* e.g. radius too large for the on-chip tile */
+} te_status;
+
+/* Layers owned by a context (device-resident, [batch][cols][rows] float32). */
+typedef enum te_layer {
+  TE_LAYER_ELEVATION = 0,
+  TE_LAYER_SLOPE = 1,       /* traversability_slope      (SlopeFilter map_type)     */
+  TE_LAYER_STEP = 2,        /* traversability_step       (StepFilter map_type)      */
+  TE_LAYER_ROUGHNESS = 3,   /* traversability_roughness  (RoughnessFilter map_type) */
+  TE_LAYER_TRAVERSABILITY = 4,
+  TE_LAYER_FOOTPRINT = 5,   /* traversability_footprint  */
+  TE_LAYER_NORMAL_X = 6,    /* surface_normal_{x,y,z}: only kept with TE_RUN_KEEP_NORMALS */
+  TE_LAYER_NORMAL_Y = 7,
+  TE_LAYER_NORMAL_Z = 8,
+  TE_LAYER_SLOPE_FOOTPRINT = 9,   /* memo layers of checkForSlope/Step/Roughness (0/1/NaN) */
+  TE_LAYER_STEP_FOOTPRINT = 10,
+  TE_LAYER_ROUGHNESS_FOOTPRINT = 11,
+  TE_LAYER_COUNT = 12
+} te_layer;
+
+/* te_run_chain flags */
+#define TE_RUN_KEEP_NORMALS 0x1u /* also write surface_normal_{x,y,z} (i.e. no DeletionFilter) */
+#define TE_RUN_FOOTPRINT    0x2u /* run the circular footprint pass right after the chain */
+
+/* Filter parameters: same keys, defaults and validity ranges as the reference's configure()s.
+ * POD; `size` must be sizeof(te_params) (ABI check).  This is the blob that is broadcast to the
+ * other ranks (RCCL) when the batch is sharded over several GPUs. */
+typedef struct te_params {
+  uint32_t size;
+  uint32_t abi_version;
+  /* gridMapFilters/NormalVectorsFilter: radius, normal_vector_positive_axis */
+  double normals_radius;
+  int32_t normals_axis; /* 0:x 1:y 2:z */
+  int32_t _pad0;
+  /* traversabilityFilters/SlopeFilter: critical_value in [0, pi/2] */
+  double slope_critical;
+  /* traversabilityFilters/StepFilter: critical_value>=0, first/second_window_radius>=0, critical_cell_number>0 */
+  double step_critical;
+  double step_radius1;
+  double step_radius2;
+  int32_t step_ncrit;
+  int32_t _pad1;
+  /* traversabilityFilters/RoughnessFilter: critical_value>=0, estimation_radius>=0 */
+  double rough_critical;
+  double rough_radius;
+  /* gridMapFilters/MathExpressionFilter, fixed form, float32:
+   *   traversability = w_scale * ((w_slope*slope + w_step*step) + w_rough*roughness)
+   * default (1.0f/3.0f) and 1,1,1 == the shipped expression bit for bit */
+  float w_scale, w_slope, w_step, w_rough;
+  /* circular footprint: radiusMin = fp_radius, radiusMax = fp_radius + fp_offset */
+  double fp_radius;
+  double fp_offset;
+  double fp_default;       /* footprint/traversability_default */
+  double fp_max_gap;       /* max_gap_width */
+  double fp_critical_step; /* criticalStepHeight_ = stepFilter.critical_value */
+  int32_t fp_check_roughness;
+  int32_t _pad2;
+} te_params;
+
+typedef struct te_ctx te_ctx;
+
+/* Fill `p` with the shipped defaults (robot_filter_parameter.yaml, robot_footprint_parameter.yaml, robot.yaml). */
+int te_params_default(te_params* p);
+/* Range checks of the reference's configure()s; TE_ERR_BAD_PARAM + message on violation. */
+int te_params_validate(const te_params* p);
+
+int te_device_count(int* count);
+int te_create(int device, te_ctx** out);
+int te_destroy(te_ctx* ctx);
+
+int te_set_params(te_ctx* ctx, const te_params* p);
+int te_get_params(te_ctx* ctx, te_params* p);
+/* rows = size(0), cols = size(1) of every map of the batch; (pos_x,pos_y) = map centre. */
+int te_set_geometry(te_ctx* ctx, int rows, int cols, int batch, double resolution, double pos_x, double pos_y);
+
+/* Host -> device copy of `nmaps` maps starting at batch slot `map0` (column-major float32). */
+int te_upload_elevation(te_ctx* ctx, const float* host, int map0, int nmaps);
+/* Overwrite the h x w sub-rectangle with top-left cell (row0, col0) of map `map` from a packed
+ * column-major h x w host tile (dirty-region update). */
+int te_upload_tile(te_ctx* ctx, const float* host_tile, int map, int row0, int col0, int h, int w);
+/* Device pointer of a layer ([batch][cols][rows] float32) for zero-copy producers/consumers
+ * (e.g. a torch tensor filled on the same device); valid until te_set_geometry/te_destroy. */
+int te_device_ptr(te_ctx* ctx, int layer, void** dptr, size_t* bytes);
+
+int te_run_chain(te_ctx* ctx, unsigned flags);
+/* Re-filter only the cells whose outputs can change when the h x w rectangle at (row0,col0) of map
+ * `map` changed (the rectangle dilated by the chain's reach). */
+int te_run_chain_region(te_ctx* ctx, unsigned flags, int map, int row0, int col0, int h, int w);
+int te_run_footprint(te_ctx* ctx);
+int te_sync(te_ctx* ctx);
+
+int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);
+
+/* Time `iters` back-to-back te_run_chain(flags) launches with HIP events on the context's stream
+ * (after `warmup` untimed ones); inputs and outputs stay resident in HBM. */
+int te_time_chain(te_ctx* ctx, unsigned flags, int warmup, int iters, float* ms_per_iter);
+
+const char* te_last_error(void);
+const char* te_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAVGPU_H */

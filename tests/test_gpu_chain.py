@@ -1,0 +1,180 @@
+"""Parity of the HIP chain (through the C-ABI) against the CPU oracle and the bag golden vector."""
+import numpy as np
+import pytest
+
+from tests.helpers import OUT_LAYERS, assert_layers_match, compare_layer, to_te_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no MI355X visible"
+    return capi
+
+
+def run_gpu(capi, elev, rows, cols, res, p, pos=(0.0, 0.0), flags=0, layers=OUT_LAYERS, batch=1):
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(rows, cols, batch, res, pos)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(flags)
+        ctx.sync()
+        return {k: ctx.download(k) for k in layers}
+
+
+def both(capi, oracle, elev, rows, cols, res, pos=(0.0, 0.0), **over):
+    op = oracle.default_params(**over)
+    g = oracle.geom(rows, cols, res, pos)
+    want = oracle.chain(g, op, elev, want_normals=True)
+    got = run_gpu(capi, elev, rows, cols, res, to_te_params(capi, op), pos, flags=capi.RUN_KEEP_NORMALS,
+                  layers=OUT_LAYERS + ("surface_normal_x", "surface_normal_y", "surface_normal_z"))
+    return got, want
+
+
+def test_bag_golden_vector(capi, bag):
+    """The reference's own golden outputs (default YAML) straight against the GPU."""
+    rows, cols = int(bag["rows"]), int(bag["cols"])
+    got = run_gpu(capi, bag["elevation"], rows, cols, float(bag["resolution"]), capi.default_params(),
+                  tuple(bag["position"]))
+    known = np.zeros(rows * cols, bool)
+    for (i, j) in ((99, 117), (99, 118)):  # exactly planar border patches, golden used UnitZ
+        known[j * rows + i] = True
+    for k in OUT_LAYERS:
+        n_bad, mx, _ = compare_layer(k, got[k][~known], bag[k][~known])
+        assert n_bad == 0, (k, n_bad, mx)
+    # the step filter is pure compare/select arithmetic: bit-exact
+    assert (got["traversability_step"].view(np.uint32) == bag["traversability_step"].view(np.uint32)).all()
+
+
+def test_bag_vs_oracle(capi, oracle, bag):
+    got, want = both(capi, oracle, bag["elevation"], int(bag["rows"]), int(bag["cols"]), float(bag["resolution"]),
+                     tuple(bag["position"]))
+    assert_layers_match(got, want, ctx="bag, default YAML")
+
+
+@pytest.mark.parametrize("cells", [1.4, 3, 5, 9])
+def test_perlin_radius_sweep(capi, oracle, cells):
+    from traversability_estimation_amd import synth
+    rows, cols, res = 200, 160, 0.05
+    elev = synth.perlin_elevation(rows, cols, seed=100 + int(cells * 10))
+    r = synth.benchmark_radius(cells, res)
+    got, want = both(capi, oracle, elev, rows, cols, res, normals_radius=r, rough_radius=r, step_radius1=r,
+                     step_radius2=r)
+    assert_layers_match(got, want, ctx=f"perlin r={cells} cells")
+
+
+def test_different_radii_per_filter(capi, oracle):
+    from traversability_estimation_amd import synth
+    rows, cols, res = 150, 170, 0.04
+    elev = synth.with_steps(synth.perlin_elevation(rows, cols, seed=7), 12, seed=8)
+    got, want = both(capi, oracle, elev, rows, cols, res, pos=(12.5, -3.25), normals_radius=0.1, rough_radius=0.17,
+                     step_radius1=0.09, step_radius2=0.13, slope_critical=0.7, step_critical=0.2, step_ncrit=3,
+                     rough_critical=0.08)
+    assert_layers_match(got, want, ctx="different radii")
+
+
+def test_holes_and_steps(capi, oracle):
+    from traversability_estimation_amd import synth
+    rows, cols, res = 180, 140, 0.05
+    elev = synth.with_holes(synth.with_steps(synth.perlin_elevation(rows, cols, seed=21), 10, seed=22), 0.05, seed=23)
+    elev[10:40, 20:60] = np.nan  # a big unobserved region
+    elev[100, 100] = np.inf      # non-finite == invalid
+    r = synth.benchmark_radius(4, res)
+    got, want = both(capi, oracle, elev, rows, cols, res, normals_radius=r, rough_radius=r, step_radius1=r,
+                     step_radius2=r)
+    assert_layers_match(got, want, ctx="holes+steps")
+    assert np.isnan(got["traversability_slope"]).sum() == np.isnan(elev).sum() + 1
+
+
+def test_degenerate_inputs(capi, oracle):
+    """Flat map, tilted exact plane, single valid cell, all-NaN map, 1-row map, radius below res/2."""
+    res = 0.05
+    cases = {}
+    cases["flat"] = np.full((40, 70), 0.25, np.float32)
+    jj, ii = np.meshgrid(np.arange(40), np.arange(70), indexing="ij")
+    cases["plane"] = (0.125 * ii + 0.0625 * jj).astype(np.float32) * np.float32(res)
+    lone = np.full((40, 70), np.nan, np.float32)
+    lone[20, 30] = 1.0
+    lone[5, 5:8] = 0.5   # three collinear cells
+    lone[30:32, 50:52] = [[0.1, 0.2], [0.3, 0.7]]
+    cases["sparse"] = lone
+    cases["allnan"] = np.full((40, 70), np.nan, np.float32)
+    for name, elev in cases.items():
+        for cells in (0.3, 1.0 + 1e-6, 2.5):
+            r = cells * res
+            got, want = both(capi, oracle, elev, 70, 40, res, normals_radius=r, rough_radius=r, step_radius1=r,
+                             step_radius2=r)
+            assert_layers_match(got, want, ctx=f"{name} r={cells}")
+    strip = np.linspace(0, 1, 300, dtype=np.float32).reshape(1, 300) ** 2
+    got, want = both(capi, oracle, strip, 300, 1, res)
+    assert_layers_match(got, want, ctx="1-column map")
+    got, want = both(capi, oracle, strip.reshape(300, 1), 1, 300, res)
+    assert_layers_match(got, want, ctx="1-row map")
+
+
+def test_tie_radii_follow_the_reference_rounding(capi, oracle):
+    """Radii that are exact multiples of the resolution: membership of the cells ON the
+    circle depends on the double rounding of the positions and must be decided per cell like the reference."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 199, 131, 0.05
+    elev = synth.with_steps(synth.perlin_elevation(rows, cols, seed=31), 8, seed=32)
+    for r in (0.05, 0.25, 0.1):
+        got, want = both(capi, oracle, elev, rows, cols, res, pos=(0.37, -1.21), normals_radius=r, rough_radius=r,
+                         step_radius1=r, step_radius2=r)
+        assert_layers_match(got, want, ctx=f"tie radius {r}")
+
+
+def test_batch_of_maps(capi, oracle):
+    from traversability_estimation_amd import synth
+    rows, cols, res, B = 96, 80, 0.05, 5
+    elevs = np.stack([synth.perlin_elevation(rows, cols, seed=2000 + b) for b in range(B)])
+    r = synth.benchmark_radius(5, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r)
+    got = run_gpu(capi, elevs, rows, cols, res, to_te_params(capi, op), batch=B)
+    g = oracle.geom(rows, cols, res)
+    n = rows * cols
+    for b in range(B):
+        want = oracle.chain(g, op, elevs[b])
+        assert_layers_match({k: got[k][b * n:(b + 1) * n] for k in OUT_LAYERS}, want, ctx=f"map {b}")
+
+
+def test_dirty_region_refilter(capi, oracle):
+    from traversability_estimation_amd import synth
+    rows, cols, res = 256, 192, 0.05
+    elev = synth.perlin_elevation(rows, cols, seed=77)
+    r = synth.benchmark_radius(5, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r)
+    new = elev.copy()
+    row0, col0, h, w = 100, 60, 48, 40
+    new[col0:col0 + w, row0:row0 + h] += synth.perlin_elevation(h, w, seed=78) * 0.5
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(elev)
+        ctx.run_chain()
+        ctx.upload_tile(new[col0:col0 + w, row0:row0 + h], 0, row0, col0)
+        ctx.run_chain_region(0, row0, col0, h, w)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+    want = oracle.chain(oracle.geom(rows, cols, res), op, new)
+    assert_layers_match(got, want, ctx="dirty tile")
+
+
+def test_error_paths(capi):
+    with capi.Context(0) as ctx:
+        with pytest.raises(capi.TeError) as e:
+            ctx.run_chain()
+        assert e.value.code == capi.TE_ERR_NOT_READY
+        ctx.set_geometry(64, 64, 1, 0.05)
+        with pytest.raises(capi.TeError) as e:
+            ctx.run_chain()
+        assert e.value.code == capi.TE_ERR_NOT_READY  # no elevation
+        with pytest.raises(capi.TeError) as e:
+            ctx.set_params(capi.default_params(normals_radius=5.0))  # 100 cells
+        assert e.value.code == capi.TE_ERR_UNSUPPORTED
+        with pytest.raises(capi.TeError) as e:
+            ctx.set_params(capi.default_params(slope_critical=3.0))
+        assert e.value.code == capi.TE_ERR_BAD_PARAM

@@ -1,0 +1,196 @@
+"""ctypes binding of the C-ABI in include/travgpu.h (libtravgpu.so).
+
+This is the only way Python (tests, bench.py) reaches the HIP chain.  There is no fallback: if the
+shared library is missing this module raises, and without a gfx950 device te_create() fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtravgpu.so")
+
+TE_OK = 0
+TE_ERR_INVALID_ARG, TE_ERR_BAD_PARAM, TE_ERR_NOT_READY, TE_ERR_HIP, TE_ERR_NO_DEVICE, TE_ERR_UNSUPPORTED = \
+    -1, -2, -3, -4, -5, -6
+
+LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traversability_roughness=3,
+              traversability=4, traversability_footprint=5, surface_normal_x=6, surface_normal_y=7,
+              surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11)
+RUN_KEEP_NORMALS = 0x1
+RUN_FOOTPRINT = 0x2
+
+# every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
+SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
+           "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
+           "te_device_ptr", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_sync",
+           "te_download_layer", "te_time_chain", "te_last_error", "te_version"]
+
+
+class TeParams(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("abi_version", C.c_uint32),
+                ("normals_radius", C.c_double), ("normals_axis", C.c_int32), ("_pad0", C.c_int32),
+                ("slope_critical", C.c_double),
+                ("step_critical", C.c_double), ("step_radius1", C.c_double), ("step_radius2", C.c_double),
+                ("step_ncrit", C.c_int32), ("_pad1", C.c_int32),
+                ("rough_critical", C.c_double), ("rough_radius", C.c_double),
+                ("w_scale", C.c_float), ("w_slope", C.c_float), ("w_step", C.c_float), ("w_rough", C.c_float),
+                ("fp_radius", C.c_double), ("fp_offset", C.c_double), ("fp_default", C.c_double),
+                ("fp_max_gap", C.c_double), ("fp_critical_step", C.c_double),
+                ("fp_check_roughness", C.c_int32), ("_pad2", C.c_int32)]
+
+
+class TeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"travgpu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libtravgpu.so.  Raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m traversability_estimation_amd.build` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, pp = C.c_void_p, C.POINTER(TeParams)
+        fp = C.POINTER(C.c_float)
+        L.te_params_default.argtypes = [pp]
+        L.te_params_validate.argtypes = [pp]
+        L.te_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.te_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.te_destroy.argtypes = [vp]
+        L.te_set_params.argtypes = [vp, pp]
+        L.te_get_params.argtypes = [vp, pp]
+        L.te_set_geometry.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.te_upload_elevation.argtypes = [vp, fp, C.c_int, C.c_int]
+        L.te_upload_tile.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.te_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.te_run_chain.argtypes = [vp, C.c_uint]
+        L.te_run_chain_region.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.te_run_footprint.argtypes = [vp]
+        L.te_sync.argtypes = [vp]
+        L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
+        L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.te_last_error.restype = C.c_char_p
+        L.te_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != TE_OK:
+        raise TeError(rc, load().te_last_error().decode())
+
+
+def default_params(**over):
+    p = TeParams()
+    _check(load().te_params_default(C.byref(p)))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def params_to_bytes(p):
+    return bytes(p)
+
+
+def params_from_bytes(b):
+    p = TeParams()
+    assert len(b) == C.sizeof(p)
+    C.memmove(C.byref(p), b, len(b))
+    return p
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().te_device_count(C.byref(n))
+    return n.value if rc == TE_OK else 0
+
+
+class Context:
+    """One device context: owns the device-resident layers of a batch of maps (thin OO view of te_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(load().te_create(int(device), C.byref(self._h)))
+        self.rows = self.cols = self.batch = 0
+
+    def close(self):
+        if self._h:
+            load().te_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_params(self, p):
+        _check(load().te_set_params(self._h, C.byref(p)))
+
+    def get_params(self):
+        p = TeParams()
+        _check(load().te_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_geometry(self, rows, cols, batch, res, pos=(0.0, 0.0)):
+        _check(load().te_set_geometry(self._h, int(rows), int(cols), int(batch), float(res), float(pos[0]), float(pos[1])))
+        self.rows, self.cols, self.batch = int(rows), int(cols), int(batch)
+
+    def upload_elevation(self, elev, map0=0):
+        a = np.ascontiguousarray(elev, dtype=np.float32).reshape(-1)
+        per = self.rows * self.cols
+        assert a.size % per == 0, (a.size, per)
+        _check(load().te_upload_elevation(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), int(map0), a.size // per))
+
+    def upload_tile(self, tile, map_index, row0, col0):
+        """tile: array of shape (w, h) == [col][row] (column-major h x w tile)."""
+        t = np.ascontiguousarray(tile, dtype=np.float32)
+        w, h = t.shape
+        _check(load().te_upload_tile(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), int(map_index), int(row0),
+                                     int(col0), int(h), int(w)))
+
+    def device_ptr(self, layer):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(load().te_device_ptr(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), C.byref(p),
+                                    C.byref(n)))
+        return p.value, n.value
+
+    def run_chain(self, flags=0):
+        _check(load().te_run_chain(self._h, int(flags)))
+
+    def run_chain_region(self, map_index, row0, col0, h, w, flags=0):
+        _check(load().te_run_chain_region(self._h, int(flags), int(map_index), int(row0), int(col0), int(h), int(w)))
+
+    def run_footprint(self):
+        _check(load().te_run_footprint(self._h))
+
+    def sync(self):
+        _check(load().te_sync(self._h))
+
+    def download(self, layer, map0=0, nmaps=None):
+        nmaps = self.batch - map0 if nmaps is None else nmaps
+        out = np.empty(nmaps * self.rows * self.cols, np.float32)
+        _check(load().te_download_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)), int(map0), int(nmaps)))
+        return out
+
+    def time_chain(self, flags=0, warmup=3, iters=10):
+        ms = C.c_float()
+        _check(load().te_time_chain(self._h, int(flags), int(warmup), int(iters), C.byref(ms)))
+        return ms.value

@@ -1,0 +1,84 @@
+// te_internal.h -- shared between the C-ABI shim (te_shim.hip) and the gfx950 kernels (te_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "travgpu.h"
+
+namespace te {
+
+constexpr int kMaxRadiusCells = 32;  // largest stencil radius (in cells) a launch supports
+constexpr int kMaxTies = 32;         // offsets lying exactly on the circle (tie radii)
+constexpr int kMaxSpiral = 4096;     // ordered offsets of the footprint spiral
+
+// Map geometry as the kernels need it.  Device layout of every layer: [batch][cols][rows] float32,
+// i.e. grid_map's column-major matrix; the FAST axis is the grid_map row index i ("x" below).
+struct Geo {
+  int rows, cols, batch;
+  double res;
+  double ax, ay;  // position of cell 0: pos + (0.5*len - 0.5*res); x(i) = ax + res*(-i)
+  double len_x, len_y, pos_x, pos_y;
+};
+
+// A disc {(di,dj): di^2+dj^2 <= (radius/res)^2} as row runs: for column offset dj (|dj|<=R) the cells
+// di in [-hw[|dj|], hw[|dj|]].  Offsets whose squared norm equals (radius/res)^2 up to rounding are
+// NOT in the runs: whether CircleIterator keeps them depends on the double rounding of the cell
+// positions, so they are listed in `tie_*` and tested per cell with the reference's own formula.
+struct Disc {
+  int R;                         // largest |offset| in the runs (-1: empty disc)
+  int hw[kMaxRadiusCells + 1];   // -1 where the run is empty
+  int n_ties;
+  int8_t tie_di[kMaxTies], tie_dj[kMaxTies];
+  double r2;                     // radius*radius (double, as CircleIterator computes it)
+  int reach;                     // max(R, max |tie offset|)
+  int npoints;                   // number of cells in the runs (full disc, away from borders)
+};
+
+struct ChainParams {
+  Disc normals, rough, step1, step2;
+  int same_rough_disc;  // roughness radius selects the same cells as the normals radius
+  int axis;             // normal_vector_positive_axis
+  double slope_crit, step_crit, rough_crit;
+  int step_ncrit;
+  float w_scale, w_slope, w_step, w_rough;
+};
+
+struct Region {  // half-open cell rectangle of one map (or all maps when map < 0)
+  int map, i0, j0, i1, j1;
+};
+
+struct FootprintParams {
+  Disc slope_disc;   // circle(3*res) of checkForSlope / checkForRoughness
+  Disc step_disc;    // circle(2.5*res) of checkForStep
+  double rmin, rmax, def, max_gap, crit_step;
+  int check_rough;
+  int n_spiral;      // entries of the ordered spiral table
+  int n_spiral_tested_from;  // first entry that belongs to the two outer rings (isInside-tested)
+};
+
+struct Layers {
+  float* elev;
+  float* slope;
+  float* step;
+  float* rough;
+  float* trav;
+  float* footprint;
+  float* nx;
+  float* ny;
+  float* nz;
+  float* slope_fp;
+  float* step_fp;
+  float* rough_fp;
+  float* step_height;  // temp layer of StepFilter (never leaves the device)
+  uint8_t* untrav;     // !isTraversableForFilters per cell
+};
+
+// launch wrappers (te_kernels.hip); all asynchronous on `stream`
+hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags,
+                        hipStream_t stream);
+hipError_t launch_footprint(const Geo& g, const ChainParams& cp, const FootprintParams& p, const Layers& L,
+                            const int16_t* spiral_di, const int16_t* spiral_dj, const int16_t* spiral_ring,
+                            hipStream_t stream);
+int chain_max_reach(const ChainParams& p);
+
+}  // namespace te

@@ -1,0 +1,491 @@
+// te_shim.hip -- C-ABI of libtravgpu.so (declared in include/travgpu.h).
+//
+// Owns the device-resident elevation/output layers of a batch of maps and launches the HIP chain.
+// No CPU fallback of any kind: without a gfx950 device te_create() fails with TE_ERR_NO_DEVICE.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "te_internal.h"
+
+using namespace te;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));    \
+  } while (0)
+
+// Build the row-run table of the disc {di^2+dj^2 <= (radius/res)^2}.  Offsets whose squared norm
+// equals (radius/res)^2 to within 1e-9 relative are "ties": the reference decides them per cell
+// from rounded double positions, so the kernels test them with the same formula.
+int build_disc(double radius, double res, Disc* d, const char* what) {
+  memset(d, 0, sizeof(*d));
+  d->r2 = radius * radius;
+  const double q = (radius / res) * (radius / res);
+  const double tol = 1e-9 * (q > 1.0 ? q : 1.0);
+  const double rmax = sqrt(q + tol);
+  if (!(rmax < (double)kMaxRadiusCells + 0.5))
+    return fail(TE_ERR_UNSUPPORTED, "%s radius %.6g m is %.2f cells; this build supports up to %d", what, radius,
+                radius / res, kMaxRadiusCells);
+  const int lim = (int)floor(rmax) + 1;
+  d->R = -1;
+  d->reach = 0;
+  d->npoints = 0;
+  for (int b = 0; b <= kMaxRadiusCells; ++b) d->hw[b] = -1;
+  for (int b = 0; b <= lim && b <= kMaxRadiusCells; ++b) {
+    int hw = -1;
+    for (int a = 0; a <= lim; ++a) {
+      const double m = (double)(a * a + b * b);
+      if (fabs(m - q) <= tol) {
+        // tie: all sign combinations, each listed once
+        for (int sa = -1; sa <= 1; sa += 2)
+          for (int sb = -1; sb <= 1; sb += 2) {
+            if ((a == 0 && sa < 0) || (b == 0 && sb < 0)) continue;
+            if (d->n_ties >= kMaxTies) return fail(TE_ERR_UNSUPPORTED, "%s radius: too many tie offsets", what);
+            d->tie_di[d->n_ties] = (int8_t)(sa * a);
+            d->tie_dj[d->n_ties] = (int8_t)(sb * b);
+            d->n_ties++;
+            const int mx = a > b ? a : b;
+            if (mx > d->reach) d->reach = mx;
+          }
+      } else if (m < q) {
+        hw = a;
+      }
+    }
+    d->hw[b] = hw;
+    if (hw >= 0) {
+      d->R = b;
+      d->npoints += (b == 0 ? 1 : 2) * (2 * hw + 1);
+    }
+  }
+  // rows are nested (hw non-increasing) and a tie at (a,b) always sits right after the run end, so
+  // runs never skip an interior cell.
+  if (d->R > d->reach) d->reach = d->R;
+  if (d->hw[0] > d->reach) d->reach = d->hw[0];
+  return TE_OK;
+}
+
+bool same_disc(const Disc& a, const Disc& b) {
+  if (a.R != b.R || a.n_ties != b.n_ties) return false;
+  for (int k = 0; k <= kMaxRadiusCells; ++k)
+    if (a.hw[k] != b.hw[k]) return false;
+  if (a.n_ties && a.r2 != b.r2) return false;
+  return true;
+}
+
+}  // namespace
+
+struct te_ctx {
+  std::mutex mu;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  te_params params;
+  bool have_params = false, have_geo = false, have_elev = false, chain_done = false;
+  Geo geo;
+  ChainParams cp;
+  FootprintParams fp;
+  Layers L;
+  size_t layer_elems = 0;
+  void* slab = nullptr;
+  int16_t* d_spiral = nullptr;
+  bool tables_ready = false;
+};
+
+namespace {
+
+int rebuild_tables(te_ctx* c) {
+  c->tables_ready = false;
+  if (!c->have_params || !c->have_geo) return TE_OK;
+  const te_params& p = c->params;
+  const double res = c->geo.res;
+  int rc;
+  if ((rc = build_disc(p.normals_radius, res, &c->cp.normals, "normals"))) return rc;
+  if ((rc = build_disc(p.rough_radius, res, &c->cp.rough, "roughness estimation"))) return rc;
+  if ((rc = build_disc(p.step_radius1, res, &c->cp.step1, "step first window"))) return rc;
+  if ((rc = build_disc(p.step_radius2, res, &c->cp.step2, "step second window"))) return rc;
+  c->cp.same_rough_disc = same_disc(c->cp.normals, c->cp.rough) ? 1 : 0;
+  c->cp.axis = p.normals_axis;
+  c->cp.slope_crit = p.slope_critical;
+  c->cp.step_crit = p.step_critical;
+  c->cp.rough_crit = p.rough_critical;
+  c->cp.step_ncrit = p.step_ncrit;
+  c->cp.w_scale = p.w_scale;
+  c->cp.w_slope = p.w_slope;
+  c->cp.w_step = p.w_step;
+  c->cp.w_rough = p.w_rough;
+  c->tables_ready = true;
+  return TE_OK;
+}
+
+void free_layers(te_ctx* c) {
+  if (c->slab) (void)hipFree(c->slab);
+  c->slab = nullptr;
+  memset(&c->L, 0, sizeof(c->L));
+  c->layer_elems = 0;
+  c->have_elev = false;
+  c->chain_done = false;
+}
+
+float* layer_ptr(te_ctx* c, int layer) {
+  switch (layer) {
+    case TE_LAYER_ELEVATION: return c->L.elev;
+    case TE_LAYER_SLOPE: return c->L.slope;
+    case TE_LAYER_STEP: return c->L.step;
+    case TE_LAYER_ROUGHNESS: return c->L.rough;
+    case TE_LAYER_TRAVERSABILITY: return c->L.trav;
+    case TE_LAYER_FOOTPRINT: return c->L.footprint;
+    case TE_LAYER_NORMAL_X: return c->L.nx;
+    case TE_LAYER_NORMAL_Y: return c->L.ny;
+    case TE_LAYER_NORMAL_Z: return c->L.nz;
+    case TE_LAYER_SLOPE_FOOTPRINT: return c->L.slope_fp;
+    case TE_LAYER_STEP_FOOTPRINT: return c->L.step_fp;
+    case TE_LAYER_ROUGHNESS_FOOTPRINT: return c->L.rough_fp;
+    default: return nullptr;
+  }
+}
+
+int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
+  if (!c->have_params || !c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain: set params and geometry first");
+  if (!c->tables_ready) {
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+  }
+  if (!c->have_elev) return fail(TE_ERR_NOT_READY, "te_run_chain: no elevation uploaded");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
+  c->chain_done = true;
+  return TE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* te_last_error(void) { return g_err; }
+const char* te_version(void) { return "travgpu 0.1 (gfx950)"; }
+
+int te_params_default(te_params* p) {
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_params_default: NULL");
+  memset(p, 0, sizeof(*p));
+  p->size = (uint32_t)sizeof(te_params);
+  p->abi_version = TE_ABI_VERSION;
+  // traversability_estimation/config/robot_filter_parameter.yaml:3-33
+  p->normals_radius = 0.05;
+  p->normals_axis = 2;
+  p->slope_critical = 1.0;
+  p->step_critical = 0.12;
+  p->step_radius1 = 0.04;
+  p->step_radius2 = 0.04;
+  p->step_ncrit = 4;
+  p->rough_critical = 0.05;
+  p->rough_radius = 0.05;
+  p->w_scale = 1.0f / 3.0f;
+  p->w_slope = p->w_step = p->w_rough = 1.0f;
+  // robot_footprint_parameter.yaml:4-8, robot.yaml:10, TraversabilityMap.cpp:117-126
+  p->fp_radius = 0.30;
+  p->fp_offset = 0.15;
+  p->fp_default = 0.3;
+  p->fp_max_gap = 0.3;
+  p->fp_critical_step = 0.12;
+  p->fp_check_roughness = 0;
+  return TE_OK;
+}
+
+int te_params_validate(const te_params* p) {
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_params: NULL");
+  if (p->size != sizeof(te_params) || p->abi_version != TE_ABI_VERSION)
+    return fail(TE_ERR_INVALID_ARG, "te_params: size/abi mismatch (got %u/%u, want %zu/%d)", p->size, p->abi_version,
+                sizeof(te_params), TE_ABI_VERSION);
+  // same messages as the reference's configure()s
+  if (!(p->slope_critical <= M_PI_2 && p->slope_critical >= 0.0))  // SlopeFilter.cpp:41
+    return fail(TE_ERR_BAD_PARAM, "Critical slope must be in the interval [0, PI/2]");
+  if (!(p->step_critical >= 0.0))  // StepFilter.cpp:45
+    return fail(TE_ERR_BAD_PARAM, "Critical step height must be greater than zero.");
+  if (!(p->step_radius1 >= 0.0))  // :58
+    return fail(TE_ERR_BAD_PARAM, "'first_window_radius' must be greater than zero.");
+  if (!(p->step_radius2 >= 0.0))  // :71
+    return fail(TE_ERR_BAD_PARAM, "'second_window_radius' must be greater than zero.");
+  if (p->step_ncrit <= 0)  // :84
+    return fail(TE_ERR_BAD_PARAM, "'critical_cell_number' must be greater than zero.");
+  if (!(p->rough_critical >= 0.0))  // RoughnessFilter.cpp:43
+    return fail(TE_ERR_BAD_PARAM, "Critical roughness must be greater than zero");
+  if (!(p->rough_radius >= 0.0))  // :55
+    return fail(TE_ERR_BAD_PARAM, "Roughness estimation radius must be greater than zero");
+  if (!(p->normals_radius >= 0.0)) return fail(TE_ERR_BAD_PARAM, "normals radius must not be negative");
+  if (p->normals_axis < 0 || p->normals_axis > 2)
+    return fail(TE_ERR_BAD_PARAM, "normal_vector_positive_axis must be x, y or z");
+  if (!(p->fp_radius >= 0.0) || !(p->fp_offset >= 0.0))
+    return fail(TE_ERR_BAD_PARAM, "footprint radius/offset must not be negative");
+  if (!(p->fp_max_gap >= 0.0)) return fail(TE_ERR_BAD_PARAM, "max_gap_width must not be negative");
+  return TE_OK;
+}
+
+int te_device_count(int* count) {
+  if (!count) return fail(TE_ERR_INVALID_ARG, "te_device_count: NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(TE_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return TE_OK;
+}
+
+int te_create(int device, te_ctx** out) {
+  if (!out) return fail(TE_ERR_INVALID_ARG, "te_create: NULL out");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(TE_ERR_NO_DEVICE, "te_create: no HIP device visible (libtravgpu has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(TE_ERR_INVALID_ARG, "te_create: device %d of %d", device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(TE_ERR_NO_DEVICE, "te_create: device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+  te_ctx* c = new (std::nothrow) te_ctx();
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_create: out of host memory");
+  c->device = device;
+  memset(&c->L, 0, sizeof(c->L));
+  memset(&c->geo, 0, sizeof(c->geo));
+  memset(&c->cp, 0, sizeof(c->cp));
+  memset(&c->fp, 0, sizeof(c->fp));
+  te_params_default(&c->params);
+  c->have_params = true;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(TE_ERR_HIP, "te_create: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return TE_OK;
+}
+
+int te_destroy(te_ctx* c) {
+  if (!c) return TE_OK;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_layers(c);
+    if (c->d_spiral) (void)hipFree(c->d_spiral);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+  return TE_OK;
+}
+
+int te_set_params(te_ctx* c, const te_params* p) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_params: NULL ctx");
+  int rc = te_params_validate(p);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(c->mu);
+  te_params old = c->params;
+  c->params = *p;
+  c->have_params = true;
+  rc = rebuild_tables(c);
+  if (rc) {
+    c->params = old;
+    (void)rebuild_tables(c);
+    return rc;
+  }
+  c->chain_done = false;
+  return TE_OK;
+}
+
+int te_get_params(te_ctx* c, te_params* p) {
+  if (!c || !p) return fail(TE_ERR_INVALID_ARG, "te_get_params: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  *p = c->params;
+  return TE_OK;
+}
+
+int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double pos_x, double pos_y) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_geometry: NULL ctx");
+  if (rows <= 0 || cols <= 0 || batch <= 0 || !(res > 0.0) || !isfinite(res) || !isfinite(pos_x) || !isfinite(pos_y))
+    return fail(TE_ERR_INVALID_ARG, "te_set_geometry: rows=%d cols=%d batch=%d res=%g", rows, cols, batch, res);
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t elems = (size_t)rows * cols * batch;
+  if (elems != c->layer_elems) {
+    free_layers(c);
+    // one slab: 13 float layers + 1 byte layer, each 256-byte aligned
+    const size_t lb = (elems * sizeof(float) + 255) & ~(size_t)255;
+    const size_t ub = (elems + 255) & ~(size_t)255;
+    void* slab = nullptr;
+    hipError_t e = hipMalloc(&slab, 13 * lb + ub);
+    if (e != hipSuccess)
+      return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", 13 * lb + ub, hipGetErrorString(e));
+    c->slab = slab;
+    char* b = (char*)slab;
+    float** ptrs[13] = {&c->L.elev, &c->L.slope, &c->L.step,     &c->L.rough,   &c->L.trav,     &c->L.footprint, &c->L.nx,
+                        &c->L.ny,   &c->L.nz,    &c->L.slope_fp, &c->L.step_fp, &c->L.rough_fp, &c->L.step_height};
+    for (int k = 0; k < 13; ++k) *ptrs[k] = (float*)(b + (size_t)k * lb);
+    c->L.untrav = (uint8_t*)(b + 13 * lb);
+    c->layer_elems = elems;
+    // outputs read as NaN until computed, like GridMap::add()
+    HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub, c->stream));
+  }
+  c->geo.rows = rows;
+  c->geo.cols = cols;
+  c->geo.batch = batch;
+  c->geo.res = res;
+  c->geo.len_x = (double)rows * res;  // GridMap::setGeometry: length = size * resolution
+  c->geo.len_y = (double)cols * res;
+  c->geo.pos_x = pos_x;
+  c->geo.pos_y = pos_y;
+  c->geo.ax = pos_x + (0.5 * c->geo.len_x - 0.5 * res);
+  c->geo.ay = pos_y + (0.5 * c->geo.len_y - 0.5 * res);
+  c->have_geo = true;
+  c->chain_done = false;
+  return rebuild_tables(c);
+}
+
+int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
+  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_elevation: geometry not set");
+  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
+    return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  HIP_TRY(hipMemcpyAsync(c->L.elev + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer may be reused as soon as we return
+  c->have_elev = true;
+  c->chain_done = false;
+  return TE_OK;
+}
+
+int te_upload_tile(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
+  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_tile: geometry not set");
+  if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
+      col0 + w > c->geo.cols)
+    return fail(TE_ERR_INVALID_ARG, "te_upload_tile: tile (%d,%d)+(%d,%d) outside %dx%d", row0, col0, h, w,
+                c->geo.rows, c->geo.cols);
+  HIP_TRY(hipSetDevice(c->device));
+  float* dst = c->L.elev + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
+  // column-major: w columns of h contiguous rows each
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->geo.rows * sizeof(float), host_tile, (size_t)h * sizeof(float),
+                           (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_elev = true;
+  return TE_OK;
+}
+
+int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
+  if (!c || !dptr) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_device_ptr: geometry not set");
+  float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
+  *dptr = p;
+  if (bytes) *bytes = c->layer_elems * sizeof(float);
+  if (layer == TE_LAYER_ELEVATION) {  // caller fills the elevation in place (zero-copy producer)
+    c->have_elev = true;
+    c->chain_done = false;
+  }
+  return TE_OK;
+}
+
+int te_run_chain(te_ctx* c, unsigned flags) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain: geometry not set");
+  const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
+  int rc = run_chain_locked(c, flags, r);
+  if (rc) return rc;
+  if (flags & TE_RUN_FOOTPRINT) return fail(TE_ERR_UNSUPPORTED, "footprint pass not built yet");
+  return TE_OK;
+}
+
+int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, int h, int w) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain_region: geometry not set");
+  if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
+      col0 + w > c->geo.cols)
+    return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: rectangle outside the map");
+  if (!c->chain_done) return fail(TE_ERR_NOT_READY, "te_run_chain_region: run the full chain once first");
+  const Region r = {map, row0, col0, row0 + h, col0 + w};
+  return run_chain_locked(c, flags & ~TE_RUN_FOOTPRINT, r);
+}
+
+int te_run_footprint(te_ctx* c) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_footprint: NULL ctx");
+  return fail(TE_ERR_UNSUPPORTED, "footprint pass not built yet");
+}
+
+int te_sync(te_ctx* c) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TE_OK;
+}
+
+int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
+  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer: geometry not set");
+  float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer: bad layer %d", layer);
+  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
+    return fail(TE_ERR_INVALID_ARG, "te_download_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  HIP_TRY(hipMemcpyAsync(host, p + per * map0, per * nmaps * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TE_OK;
+}
+
+int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_per_iter) {
+  if (!c || !ms_per_iter || iters <= 0 || warmup < 0) return fail(TE_ERR_INVALID_ARG, "te_time_chain: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_time_chain: geometry not set");
+  const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
+  for (int k = 0; k < warmup; ++k) {
+    int rc = run_chain_locked(c, flags, r);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int k = 0; k < iters; ++k) {
+    int rc = run_chain_locked(c, flags, r);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_iter = ms / (float)iters;
+  return TE_OK;
+}
+
+}  // extern "C"
