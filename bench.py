@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- map cells/s through the full traversability filter chain on MI355X.
+
+Workload (BASELINE.json configs[2], the HBM-roofline config): one 4096 x 4096 synthetic elevation map
+per GPU, res 0.05 m, all four filter radii 9 cells (tie-free, r = 9*res*(1+1e-6)), followed by the
+circular traversability_footprint pass (radius 0.30 m, offset 0.15 m).  A "step" is one pass of the
+whole chain over the resident batch; the elevation is already in HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the batch axis is sharded -- every rank
+filters its own map (weak scaling, no data-path collective); rank 0's filter parameters are broadcast
+once over RCCL before the timed region.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the whole chain launch
+sequence: algorithmic bytes (20 B/cell chain, 24 B/cell with the footprint pass) divided
+by the chain's average duration measured with HIP events on the stream the kernels run on.
+`cpu_baseline` times the CPU oracle (our restatement of the reference; kind "port") on one host thread
+over a bounded crop of the same map.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096, help="map is size x size cells")
+    ap.add_argument("--radius-cells", type=float, default=9.0)
+    ap.add_argument("--res", type=float, default=0.05)
+    ap.add_argument("--maps-per-gpu", type=int, default=1)
+    ap.add_argument("--no-footprint", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
+    return ap.parse_args()
+
+
+def make_params(capi, synth, args):
+    r = synth.benchmark_radius(args.radius_cells, args.res)
+    return capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                               fp_radius=synth.benchmark_radius(6.0, args.res),
+                               fp_offset=synth.benchmark_radius(3.0, args.res))
+
+
+def cpu_baseline(args, elev_full, p, with_footprint):
+    """Time the CPU oracle (single thread, like the reference) on a bounded crop of the same map."""
+    from oracle import oracle as O
+    from tests.helpers import OUT_LAYERS  # noqa: F401
+    op = O.default_params()
+    for f, _ in op._fields_:
+        setattr(op, f, getattr(p, f))
+    O.set_threads(1)
+    n = 128
+    g = O.geom(n, n, args.res)
+    crop = np.ascontiguousarray(elev_full[:n, :n])
+    t0 = time.perf_counter()
+    out = O.chain(g, op, crop)
+    if with_footprint:
+        O.footprint(g, op, crop, out)
+    dt = time.perf_counter() - t0
+    rate = n * n / dt
+    # scale the sample so that it takes about cpu_seconds, at most the whole map
+    n = int(min(args.size, max(128, (rate * args.cpu_seconds) ** 0.5)))
+    n -= n % 64
+    n = max(n, 128)
+    g = O.geom(n, n, args.res)
+    crop = np.ascontiguousarray(elev_full[:n, :n])
+    t0 = time.perf_counter()
+    out = O.chain(g, op, crop)
+    if with_footprint:
+        O.footprint(g, op, crop, out)
+    dt = time.perf_counter() - t0
+    return {"value": n * n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": f"{n}x{n} crop of the same map, full chain{'+footprint' if with_footprint else ''}, "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/te_oracle.c, -O3)"}
+
+
+def main():
+    args = parse()
+    import torch
+    from traversability_estimation_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    capi.load()
+
+    # filter parameters: rank 0 decides, everyone else receives the te_params blob over RCCL
+    p = make_params(capi, synth, args)
+    if world > 1:
+        blob = torch.frombuffer(bytearray(capi.params_to_bytes(p)), dtype=torch.uint8).cuda()
+        if rank != 0:
+            blob.zero_()
+        dist.broadcast(blob, src=0)
+        p = capi.params_from_bytes(bytes(blob.cpu().numpy().tobytes()))
+
+    with_fp = not args.no_footprint
+    flags = capi.RUN_FOOTPRINT if with_fp else 0
+    n = args.size
+    B = args.maps_per_gpu
+    # shard of the batch owned by this rank: maps rank*B .. rank*B+B-1 (seed = 1235 + global map index)
+    elevs = [synth.perlin_elevation(n, n, seed=1235 + rank * B + b) for b in range(B)]
+    ctx = capi.Context(local_rank)
+    ctx.set_params(p)
+    ctx.set_geometry(n, n, B, args.res)
+    ctx.upload_elevation(np.stack(elevs))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.run_chain(flags)
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.run_chain(flags)
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel-only duration of the chain: HIP events on the context's own stream
+    ms_chain = ctx.time_chain(flags, warmup=1, iters=max(5, min(args.steps, 50)))
+
+    check = None
+    if args.check and rank == 0:
+        from oracle import oracle as O
+        from tests.helpers import OUT_LAYERS, compare_layer
+        m = 192
+        with capi.Context(local_rank) as c2:
+            c2.set_params(p)
+            c2.set_geometry(m, m, 1, args.res)
+            crop = np.ascontiguousarray(elevs[0][:m, :m])
+            c2.upload_elevation(crop)
+            c2.run_chain(flags)
+            c2.sync()
+            op = O.default_params()
+            for f, _ in op._fields_:
+                setattr(op, f, getattr(p, f))
+            g = O.geom(m, m, args.res)
+            want = O.chain(g, op, crop)
+            names = list(OUT_LAYERS)
+            if with_fp:
+                want["traversability_footprint"] = O.footprint(g, op, crop, want)
+                names.append("traversability_footprint")
+            check = {k: compare_layer(k, c2.download(k), want[k])[:2] for k in names}
+
+    if rank == 0:
+        cells_per_step = world * B * n * n
+        bytes_per_cell = 24 if with_fp else 20
+        achieved = B * n * n * bytes_per_cell / (ms_chain * 1e-3) / 1e9
+        out = {
+            "metric": "map cells/s through full filter chain",
+            "value": cells_per_step * args.steps / dt,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 per-cell math on f32 layers",
+            "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)",
+            "config": {"workload": f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
+                                   f" (normals/roughness/step), slope+roughness+step+normals+combine"
+                                   f"{' + traversability_footprint pass' if with_fp else ''}",
+                       "maps_per_gpu": B, "map_cells": n * n, "radius_cells": args.radius_cells,
+                       "footprint": with_fp, "sharding": "batch axis, one map shard per rank, params broadcast over RCCL"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "chain launch sequence (all kernels of one te_run_chain)",
+                         "ms_per_launch": ms_chain, "algorithmic_bytes_per_cell": bytes_per_cell},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
+        if check is not None:
+            out["parity_check"] = {k: {"mismatches": v[0], "max_abs_err": v[1]} for k, v in check.items()}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

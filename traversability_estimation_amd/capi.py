@@ -20,6 +20,7 @@ LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traver
               surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11)
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
+RUN_GENERIC_KERNELS = 0x4
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",

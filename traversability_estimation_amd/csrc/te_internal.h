@@ -32,6 +32,7 @@ struct Disc {
   double r2;                     // radius*radius (double, as CircleIterator computes it)
   int reach;                     // max(R, max |tie offset|)
   int npoints;                   // number of cells in the runs (full disc, away from borders)
+  int Q;                         // tie-free discs: largest a^2+b^2 <= (radius/res)^2 (names the shape); -1 with ties
 };
 
 struct ChainParams {
@@ -71,6 +72,11 @@ struct Layers {
   float* rough_fp;
   float* step_height;  // temp layer of StepFilter (never leaves the device)
   uint8_t* untrav;     // !isTraversableForFilters per cell
+  int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
+};
+
+struct FastGrid {  // block grid of the last shape-specialised normals launch
+  int nbx, nby, nbz, out_rows;
 };
 
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
@@ -80,5 +86,17 @@ hipError_t launch_footprint(const Geo& g, const ChainParams& cp, const Footprint
                             const int16_t* spiral_di, const int16_t* spiral_dj, const int16_t* spiral_ring,
                             hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
+
+// shape-specialised kernels (te_fast_*.hip); return false when the shape Q is not instantiated
+namespace fast {
+bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s);
+bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
+                     hipStream_t s);
+// normals + slope + roughness (same disc for normals and roughness, positive axis z); with `combine`
+// the traversability layer is written too (the step layer must be complete).
+bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
+                  const Region& r, int* block_flags, FastGrid* fg, hipStream_t s);
+int normals_fast_max_blocks(const Geo& g);
+}  // namespace fast
 
 }  // namespace te

@@ -80,6 +80,17 @@ int build_disc(double radius, double res, Disc* d, const char* what) {
   // runs never skip an interior cell.
   if (d->R > d->reach) d->reach = d->R;
   if (d->hw[0] > d->reach) d->reach = d->hw[0];
+  // the shape is named by the largest sum of two squares not above q (only meaningful without ties)
+  d->Q = -1;
+  if (d->n_ties == 0) {
+    int best = -1;
+    for (int a = 0; a <= lim; ++a)
+      for (int b = 0; b <= lim; ++b) {
+        const int m = a * a + b * b;
+        if ((double)m < q && m > best) best = m;
+      }
+    d->Q = best;  // -1: radius below zero cells cannot happen (m = 0 < q unless q == 0, which is a tie)
+  }
   return TE_OK;
 }
 
@@ -339,18 +350,24 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     const size_t lb = (elems * sizeof(float) + 255) & ~(size_t)255;
     const size_t ub = (elems + 255) & ~(size_t)255;
     void* slab = nullptr;
-    hipError_t e = hipMalloc(&slab, 13 * lb + ub);
+    Geo gtmp;
+    gtmp.rows = rows;
+    gtmp.cols = cols;
+    gtmp.batch = batch;
+    const size_t fb = ((size_t)fast::normals_fast_max_blocks(gtmp) * sizeof(int) + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&slab, 13 * lb + ub + fb);
     if (e != hipSuccess)
-      return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", 13 * lb + ub, hipGetErrorString(e));
+      return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", 13 * lb + ub + fb, hipGetErrorString(e));
     c->slab = slab;
     char* b = (char*)slab;
     float** ptrs[13] = {&c->L.elev, &c->L.slope, &c->L.step,     &c->L.rough,   &c->L.trav,     &c->L.footprint, &c->L.nx,
                         &c->L.ny,   &c->L.nz,    &c->L.slope_fp, &c->L.step_fp, &c->L.rough_fp, &c->L.step_height};
     for (int k = 0; k < 13; ++k) *ptrs[k] = (float*)(b + (size_t)k * lb);
     c->L.untrav = (uint8_t*)(b + 13 * lb);
+    c->L.block_flags = (int*)(b + 13 * lb + ub);
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
-    HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub, c->stream));
+    HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub + fb, c->stream));
   }
   c->geo.rows = rows;
   c->geo.cols = cols;
