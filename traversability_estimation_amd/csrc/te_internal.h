@@ -73,10 +73,11 @@ struct Layers {
   float* step_height;  // temp layer of StepFilter (never leaves the device)
   uint8_t* untrav;     // !isTraversableForFilters per cell
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
+  int* clip_table;     // x/y moments of the normals disc clipped by the map border (build_clip_table)
 };
 
-struct FastGrid {  // block grid of the last shape-specialised normals launch
-  int nbx, nby, nbz, out_rows;
+struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
+  int ntx, nty, nbz;
 };
 
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
@@ -95,8 +96,9 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
 // normals + slope + roughness (same disc for normals and roughness, positive axis z); with `combine`
 // the traversability layer is written too (the step layer must be complete).
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
-                  const Region& r, int* block_flags, FastGrid* fg, hipStream_t s);
+                  const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
+void build_clip_table(const Disc& d, int* out);  // (2R+1)^2 * 6 ints
 }  // namespace fast
 
 }  // namespace te

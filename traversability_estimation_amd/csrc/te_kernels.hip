@@ -268,43 +268,42 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
   extern __shared__ float tile[];
   __shared__ unsigned short todo[TX * TY];
   __shared__ int ntodo;
+  // one workgroup per 64x16 tile of the region; only flagged tiles do anything
   const int mapz = rg.map >= 0 ? 0 : blockIdx.z;
+  if (!flags[((size_t)mapz * fg.nty + blockIdx.y) * fg.ntx + blockIdx.x]) return;  // uniform
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  const int i0 = rg.i0 + blockIdx.x * TX, j0 = rg.j0 + blockIdx.y * TY;
-  {
-    int jl = j0 + TY - 1;
-    if (jl > rg.j1 - 1) jl = rg.j1 - 1;
-    const int by0 = (j0 - rg.j0) / fg.out_rows, by1 = (jl - rg.j0) / fg.out_rows;
-    const size_t base = (size_t)mapz * fg.nby;
-    const int f = flags[(base + by0) * fg.nbx + blockIdx.x] | flags[(base + by1) * fg.nbx + blockIdx.x];
-    if (!f) return;  // uniform
-  }
+  const int i0 = rg.i0 + blockIdx.x * TX;
+  const int jb0 = rg.j0 + blockIdx.y * TY;
+  const int jb1 = jb0 + TY < rg.j1 ? jb0 + TY : rg.j1;
   const int K = a.dn.reach > a.dr.reach ? a.dn.reach : a.dr.reach;
   const int tw = TX + 2 * K;
   const int tid = threadIdx.y * TX + threadIdx.x;
-  if (tid == 0) ntodo = 0;
-  load_tile(tile, elev + mo, g, i0, j0, K);
-  __syncthreads();
-  for (int c = 0; c < CPT; ++c) {
-    const int lj = threadIdx.y + c * BY;
-    const int i = i0 + threadIdx.x, j = j0 + lj;
-    bool need = false;
-    if (i < rg.i1 && j < rg.j1) {
-      const float z0 = tile[(lj + K) * tw + (threadIdx.x + K)];
-      const float s = slope[mo + (size_t)j * g.rows + i];
-      need = (z0 == z0) && !(s == s);
+  for (int j0 = jb0; j0 < jb1; j0 += TY) {
+    __syncthreads();
+    if (tid == 0) ntodo = 0;
+    load_tile(tile, elev + mo, g, i0, j0, K);
+    __syncthreads();
+    for (int c = 0; c < CPT; ++c) {
+      const int lj = threadIdx.y + c * BY;
+      const int i = i0 + threadIdx.x, j = j0 + lj;
+      bool need = false;
+      if (i < rg.i1 && j < jb1) {
+        const float z0 = tile[(lj + K) * tw + (threadIdx.x + K)];
+        const float s = slope[mo + (size_t)j * g.rows + i];
+        need = (z0 == z0) && !(s == s);
+      }
+      if (need) todo[atomicAdd(&ntodo, 1)] = (unsigned short)(lj * TX + threadIdx.x);
     }
-    if (need) todo[atomicAdd(&ntodo, 1)] = (unsigned short)(lj * TX + threadIdx.x);
-  }
-  __syncthreads();
-  const int n = ntodo;
-  for (int k = tid; k < n; k += TX * BY) {
-    const int c = todo[k];
-    const int lj = c / TX, li = c - lj * TX;
-    const int i = i0 + li, j = j0 + lj;
-    normals_cell(g, a, tile + (lj + K) * tw + (li + K), tw, i, j, mo + (size_t)j * g.rows + i, step, slope, rough,
-                 trav, onx, ony, onz);
+    __syncthreads();
+    const int n = ntodo;
+    for (int k = tid; k < n; k += TX * BY) {
+      const int c = todo[k];
+      const int lj = c / TX, li = c - lj * TX;
+      const int i = i0 + li, j = j0 + lj;
+      normals_cell(g, a, tile + (lj + K) * tw + (li + K), tw, i, j, mo + (size_t)j * g.rows + i, step, slope, rough,
+                   trav, onx, ony, onz);
+    }
   }
 }
 
@@ -389,8 +388,8 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   const bool fused_combine = whole;
   FastGrid fg;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
-      fast::normals_fast(g, p, L, keep, whole, rn, L.block_flags, &fg, stream)) {
-    hipLaunchKernelGGL(k_normals_fixup, tile_grid(g, rn), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
+      fast::normals_fast(g, p, L, keep, whole, rn, L.block_flags, L.clip_table, &fg, stream)) {
+    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fg.ntx, (unsigned)fg.nty, (unsigned)fg.nbz), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {
     hipLaunchKernelGGL(k_normals, tile_grid(g, rn), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,

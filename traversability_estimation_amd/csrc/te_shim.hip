@@ -118,6 +118,7 @@ struct te_ctx {
   size_t layer_elems = 0;
   void* slab = nullptr;
   int16_t* d_spiral = nullptr;
+  int* clip_table = nullptr;
   bool tables_ready = false;
 };
 
@@ -143,6 +144,17 @@ int rebuild_tables(te_ctx* c) {
   c->cp.w_slope = p.w_slope;
   c->cp.w_step = p.w_step;
   c->cp.w_rough = p.w_rough;
+  // x/y moments of the normals disc clipped by the map border, for the sliding-disc kernel
+  if (c->cp.normals.n_ties == 0 && c->cp.normals.R >= 1) {
+    const int R = c->cp.normals.R;
+    std::vector<int> tab((size_t)(2 * R + 1) * (2 * R + 1) * 6);
+    fast::build_clip_table(c->cp.normals, tab.data());
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1)));
+    HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->L.clip_table = c->clip_table;
   c->tables_ready = true;
   return TE_OK;
 }
@@ -303,6 +315,7 @@ int te_destroy(te_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_layers(c);
     if (c->d_spiral) (void)hipFree(c->d_spiral);
+    if (c->clip_table) (void)hipFree(c->clip_table);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -39,10 +39,17 @@ struct SlideArgs {
   int h[kMaxRadiusCells + 1];  // half-height of disc column |di| (== half-width of row |dj|)
   int np;                      // cells in the disc
   int sii;                     // sum of di^2 over the disc
-  int out_rows;                // rows per strip
   double slope_crit, inv_slope_crit, rough_crit, inv_rough_crit;
   float w_scale, w_slope, w_step, w_rough;
   int combine;
+  const int* gtab;  // [(2R+1)^2][6] x/y moments {n, si, sj, sii, sij, sjj} of the disc clipped by the map border
+  int fi0, fj0, ntx, nty;  // fix-up flag grid: 64x16 tiles from (fi0, fj0), ntx x nty per map
+  // One launch covers up to five rectangles (top, bottom, left, right frame with short strips and the
+  // clipped-disc tail, then the interior): blocks [first, first+nbx*nby) belong to rectangle k.
+  struct Sub {
+    int i0, i1, j0, j1, out_rows, nbx, first, border;
+  } sub[5];
+  int nsub;
 };
 
 __device__ __forceinline__ float qnanf() { return __builtin_nanf(""); }
@@ -83,6 +90,97 @@ __device__ __forceinline__ double acos_poly(double x) {
   return x < 0.0 ? 3.141592653589793 - r : r;
 }
 
+// General tail for a disc clipped by the map border (or any validity pattern whose x/y moments are
+// known): population covariance from the moments, smallest eigenpair of the 3x3 via a Jacobi
+// rotation of the x/y block and a safeguarded Newton iteration on the secular equation of the
+// resulting arrow matrix.  Returns false for the (measure-zero) configurations it does not
+// resolve; the caller leaves those cells to the fix-up pass.  q_out = n^T C n with the float32 normal.
+__device__ __forceinline__ bool border_tail(double res, int n, int si, int sj, int sii, int sij, int sjj, double Sz,
+                                            double Siz, double Sjz, double Szz, float& nx, float& ny, float& nz,
+                                            double& q_out) {
+  if (n < 1) return false;
+  const double dn = (double)n;
+  const double inv_n2 = 1.0 / (dn * dn);
+  const double r2 = res * res;
+  const double cxx = r2 * (double)((long long)n * sii - (long long)si * si) * inv_n2;
+  const double cxy = r2 * (double)((long long)n * sij - (long long)si * sj) * inv_n2;
+  const double cyy = r2 * (double)((long long)n * sjj - (long long)sj * sj) * inv_n2;
+  const double cxz = -res * fma(dn, Siz, -(double)si * Sz) * inv_n2;
+  const double cyz = -res * fma(dn, Sjz, -(double)sj * Sz) * inv_n2;
+  const double czz = fma(dn, Szz, -Sz * Sz) * inv_n2;
+  double vx = 0.0, vy = 0.0, vz = 1.0;
+  if (n >= 3) {
+    double cs = 1.0, sn = 0.0, mu1 = cxx, mu2 = cyy;
+    if (cxy != 0.0) {
+      const double tau = (cyy - cxx) / (2.0 * cxy);
+      double t = 1.0 / (fabs(tau) + sqrt(fma(tau, tau, 1.0)));
+      t = tau < 0.0 ? -t : t;
+      cs = 1.0 / sqrt(fma(t, t, 1.0));
+      sn = t * cs;
+      mu1 = cxx - t * cxy;
+      mu2 = cyy + t * cxy;
+    }
+    const double ap = cs * cxz - sn * cyz, bp = sn * cxz + cs * cyz;
+    const double ra = ap * ap, rb = bp * bp;
+    double lam;
+    if (ra == 0.0 && rb == 0.0) {
+      if (!(czz <= mu1 && czz <= mu2)) return false;  // horizontal normal: leave to the general solver
+      lam = czz;
+    } else {
+      double hi = czz;
+      if (ra != 0.0 && mu1 < hi) hi = mu1;
+      if (rb != 0.0 && mu2 < hi) hi = mu2;
+      double lo = hi < 0.0 ? hi - fabs(hi) - 1e-300 : 0.0;
+      lo = lo < -fabs(hi) ? lo : -fabs(hi);  // f(lo) >= 0 for a PSD matrix up to rounding
+      lam = hi > 0.0 ? 0.0 : lo;
+      double hb = hi;
+      for (int it = 0; it < 40; ++it) {
+        const double r1 = ra != 0.0 ? rcp_nr(mu1 - lam) : 0.0;
+        const double r2_ = rb != 0.0 ? rcp_nr(mu2 - lam) : 0.0;
+        const double f = (czz - lam) - ra * r1 - rb * r2_;
+        const double fp = -1.0 - ra * r1 * r1 - rb * r2_ * r2_;
+        if (f > 0.0)
+          lo = lam;
+        else
+          hb = lam;
+        double ln = lam - f * rcp_nr(fp);
+        if (!(ln >= lo && ln <= hb)) ln = 0.5 * (lo + hb);
+        const bool conv = fabs(ln - lam) <= 1e-15 * fabs(ln) || f == 0.0;
+        lam = ln;
+        if (__all(conv)) break;
+      }
+      if (ra == 0.0 && mu1 < lam) return false;
+      if (rb == 0.0 && mu2 < lam) return false;
+    }
+    // middle eigenvalue from the invariants (NormalVectorsFilter keeps the eigenvector only if it is > 1e-8)
+    const double tr = mu1 + mu2 + czz;
+    const double c1 = mu1 * mu2 + (mu1 + mu2) * czz - ra - rb;
+    const double s12 = tr - lam;
+    const double p12 = c1 - lam * s12;
+    double dsc = fma(s12, s12, -4.0 * p12);
+    dsc = dsc > 0.0 ? dsc : 0.0;
+    const double bigr = 0.5 * (s12 + sqrt(dsc));
+    const double lam1 = bigr > 0.0 ? p12 / bigr : 0.0;
+    if (lam1 > 1e-8) {
+      const double v1 = ra != 0.0 ? ap / (lam - mu1) : 0.0;
+      const double v2 = rb != 0.0 ? bp / (lam - mu2) : 0.0;
+      const double wx = cs * v1 + sn * v2, wy = -sn * v1 + cs * v2;
+      const double inv = 1.0 / sqrt(fma(wx, wx, fma(wy, wy, 1.0)));
+      if (!(inv > 0.0)) return false;
+      vx = wx * inv;
+      vy = wy * inv;
+      vz = inv;
+    }
+  }
+  nx = (float)vx;
+  ny = (float)vy;
+  nz = (float)vz;
+  const double x = (double)nx, y = (double)ny, z = (double)nz;
+  double q = fma(cxx * x, x, fma(2.0 * cxy * x, y, fma(cyy * y, y, fma(2.0 * z, fma(cxz, x, cyz * y), czz * z * z))));
+  q_out = q > 0.0 ? q : 0.0;
+  return true;
+}
+
 constexpr int ring_rows(int R) {
   int n = 4;
   while (n < 2 * R + 2) n *= 2;
@@ -94,21 +192,29 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
                                                           float* __restrict__ onx, float* __restrict__ ony,
-                                                          float* __restrict__ onz, int* __restrict__ block_flags,
+                                                          float* __restrict__ onz, int* __restrict__ tile_flags,
                                                           Region rg) {
   constexpr int W = kLanes + 2 * R;
-  constexpr int NR = ring_rows(R);
+  constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R are live while the disc moves from j to j+1
   constexpr int NX = (W + kLanes - 1) / kLanes;
   __shared__ double ring[NR * W];
   const int lane = threadIdx.x;
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  const int i0 = rg.i0 + blockIdx.x * kLanes;
-  const int js = rg.j0 + blockIdx.y * a.out_rows;
-  const int jend = (js + a.out_rows < rg.j1) ? js + a.out_rows : rg.j1;
+  int k = 0;  // which rectangle this block works on (uniform)
+#pragma unroll
+  for (int t = 1; t < 5; ++t)
+    if (t < a.nsub && (int)blockIdx.x >= a.sub[t].first) k = t;
+  const int lb = (int)blockIdx.x - a.sub[k].first;
+  const int sub_i1 = a.sub[k].i1, sub_j1 = a.sub[k].j1, out_rows = a.sub[k].out_rows;
+  const bool BORDER = a.sub[k].border != 0;
+  const int i0 = a.sub[k].i0 + (lb % a.sub[k].nbx) * kLanes;
+  const int js = a.sub[k].j0 + (lb / a.sub[k].nbx) * out_rows;
+  const int jend = (js + out_rows < sub_j1) ? js + out_rows : sub_j1;
   const int i = i0 + lane;
   const float* __restrict__ em = elev + mo;
-  const bool border_lane = (i - R < 0) || (i + R >= g.rows);
+  // clip of my disc by the left/right map border (0: none; k>0: columns di < -R+k missing; k<0: di > R+k missing)
+  const int kx = (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
   const int c = lane + R;  // my column inside a staged row
 
   // ---- stage one row into the ring; returns whether it contains an invalid in-map cell ----------
@@ -119,91 +225,103 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
     for (int x = 0; x < NX; ++x) {
       const int cc = lane + x * kLanes;
       const int ci = i0 - R + cc;
-      float t = 0.0f;  // out-of-map columns: never read by a non-border lane
-      if (cc < W && ci >= 0 && ci < g.rows) t = (r >= 0 && r < g.cols) ? em[(size_t)r * g.rows + ci] : qnanf();
+      float t = 0.0f;  // cells outside the map contribute nothing to the z-sums (their x/y moments: gtab)
+      if (cc < W && ci >= 0 && ci < g.rows && r >= 0 && r < g.cols) t = em[(size_t)r * g.rows + ci];
       pf[x] = t;
     }
   };
-  auto store_row = [&](int r, const float (&pf)[NX]) {
+  auto store_row = [&](int r, int slot, const float (&pf)[NX]) {
     bool bad = false;
-    double* dst = ring + (r & (NR - 1)) * W;
+    double* dst = ring + slot * W;
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
       const int cc = lane + x * kLanes;
+      const int ci = i0 - R + cc;
+      const bool inmap = cc < W && ci >= 0 && ci < g.rows && r >= 0 && r < g.cols;
       const float t = pf[x];
-      const bool ok = __builtin_isfinite(t);
-      bad |= !ok;
-      if (cc < W) dst[cc] = ok ? (double)t - zref : 0.0;
+      const bool ok = inmap && __builtin_isfinite(t);
+      bad |= inmap && !ok;
+      if (cc < W) dst[cc] = ok ? (double)t - zref : 0.0;  // invalid / outside the map: contributes nothing
     }
     if (__any(bad)) dirty_until = r + R > dirty_until ? r + R : dirty_until;
   };
 
-  // ---- prologue: rows js-R .. js+R, reference height, direct sum for the first output row --------
+  // ---- prologue: empty ring, reference height -------------------------------------------------------
+  // The march starts 2R+1 rows above the strip with an EMPTY disc (rows above js-R count as zeros and
+  // are never staged), so the first real output needs no separate 253-point sum: 2R+1 ordinary steps.
+  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
   {
-    float pf[NX];
-    load_row(js - R, pf);
-    // reference = first finite value of the first rows (uniform); 0 if there is none yet
+    float pf0[NX];
     bool found = false;
-    for (int r = js - R; r <= js + R; ++r) {
-      if (r > js - R) load_row(r, pf);
-      if (!found) {
+    for (int r = js - R; r <= js + R && !found; ++r) {  // uniform loop; normally one iteration
+      load_row(r, pf0);
 #pragma unroll
-        for (int x = 0; x < NX; ++x) {
-          const unsigned long long msk = __ballot(__builtin_isfinite(pf[x]) && pf[x] != 0.0f);
-          if (!found && msk) {
-            zref = (double)__shfl(pf[x], __ffsll((long long)msk) - 1);
-            found = true;
-          }
+      for (int x = 0; x < NX; ++x) {
+        const unsigned long long msk = __ballot(__builtin_isfinite(pf0[x]) && pf0[x] != 0.0f);
+        if (!found && msk) {
+          zref = (double)__shfl(pf0[x], __ffsll((long long)msk) - 1);
+          found = true;
         }
       }
-      store_row(r, pf);
-    }
-  }
-  // rows staged before the reference was found used zref = 0: restage them if the reference changed
-  if (zref != 0.0) {
-    float pf[NX];
-    for (int r = js - R; r <= js + R; ++r) {
-      load_row(r, pf);
-      store_row(r, pf);
     }
   }
   __syncthreads();
-
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
-  for (int dj = -R; dj <= R; ++dj) {
-    const int hw = a.h[dj < 0 ? -dj : dj];
-    const double* row = ring + ((js + dj) & (NR - 1)) * W + c;
-    double rs = 0.0, ri = 0.0, rq = 0.0;
-    for (int di = -hw; di <= hw; ++di) {
-      const double z = row[di];
-      rs += z;
-      ri = fma((double)di, z, ri);
-      rq = fma(z, z, rq);
-    }
-    Sz += rs;
-    Siz += ri;
-    Sjz = fma((double)dj, rs, Sjz);
-    Szz += rq;
-  }
+  const int jstart = js - (2 * R + 1);
+  int slot_j = 0;  // ring slot of row j (slot(r) = (r - jstart) mod NR)
 
   const double inv_np = 1.0 / (double)a.np;
   const double cxx = g.res * g.res * ((double)a.sii * inv_np);
   const double nm1 = (double)a.np / (double)(a.np > 1 ? a.np - 1 : 1);
-  bool need_fixup = false;
+  // fix-up flags: one per 64x16 tile of the whole region the chain runs on (origin a.fi0, a.fj0)
+  int* const flag_col = tile_flags + (size_t)(rg.map >= 0 ? 0 : blockIdx.z) * a.ntx * a.nty + ((i0 - a.fi0) >> 6);
 
-  float pf[NX];
-  load_row(js + 1 + R, pf);
+  // rows (and the step values of the combine) are fetched kAhead steps before they are needed
+  constexpr int kAhead = 4;
+  float pfq[kAhead][NX];
+  float stq[kAhead];
+  auto load_step = [&](int jj) -> float {
+    float v = 0.0f;
+    if (a.combine && jj >= js && jj < jend && i < sub_i1) v = step[mo + (size_t)jj * g.rows + i];
+    return v;
+  };
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) {
+    load_row(jstart + 1 + R + d, pfq[d]);
+    stq[d] = load_step(jstart + d);
+  }
 
 #pragma unroll 1
-  for (int j = js; j < jend; ++j) {
+  for (int j0 = jstart; j0 < jend; j0 += kAhead) {
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) {
+    const int j = j0 + d;
+    if (j >= jend) break;
+    float (&pf)[NX] = pfq[d];
     // ---- emit row j ---------------------------------------------------------------------------
-    if (i < rg.i1) {
+    bool need_fixup = false;
+    if (j >= js && i < sub_i1) {
       const size_t o = mo + (size_t)j * g.rows + i;
-      float stepv = 0.0f;
-      if (a.combine) stepv = step[o];
+      const float stepv = stq[d];
       float nx = qnanf(), ny = qnanf(), nz = qnanf(), o_slope = qnanf(), o_rough = qnanf();
       bool done = false;
-      if (j > dirty_until && !border_lane) {
+      double qrough = 0.0;
+      const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
+      if (!BORDER && (kx != 0 || ky != 0)) {
+        // not launched on border cells (see normals_fast); if it ever happens the fix-up pass takes the cell
+      } else if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
+        // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
+        // the x/y moments of the clipped disc come from the host-built table
+        const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+        done = border_tail(g.res, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, nx, ny, nz, qrough);
+        if (done) {
+          const double sl = acos_poly((double)nz);
+          o_slope = sl < a.slope_crit ? (float)(1.0 - sl * a.inv_slope_crit) : 0.0f;
+          const int n = gt[0];
+          const double rgh = n > 1 ? sqrt_nr(qrough * ((double)n / (double)(n - 1))) : 1e300;
+          o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh * a.inv_rough_crit) : 0.0f;
+        }
+      } else if (j > dirty_until) {
         const double mz = Sz * inv_np;
         const double ca = -g.res * Siz * inv_np;  // cov(x,z), x = -res*di
         const double cb = -g.res * Sjz * inv_np;  // cov(y,z)
@@ -234,7 +352,7 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
           done = true;
         }
       }
-      need_fixup |= !done;
+      need_fixup = !done;
       slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
       rough[o] = o_rough;
       if (a.combine) {
@@ -249,17 +367,26 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
         onz[o] = nz;
       }
     }
+    if (__any(need_fixup) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
     if (j + 1 >= jend) break;
     // ---- bring in row j+1+R, start the load of the one after ------------------------------------
-    store_row(j + 1 + R, pf);
-    load_row(j + 2 + R, pf);
+    {
+      int sl = slot_j + 1 + R;
+      sl = sl >= NR ? sl - NR : sl;
+      store_row(j + 1 + R, sl, pf);
+    }
+    load_row(j + 1 + R + kAhead, pf);
+    stq[d] = load_step(j + kAhead);
     // ---- slide the disc from row j to row j+1 ---------------------------------------------------
     double sj = 0.0;
 #pragma unroll
     for (int di = -R; di <= R; ++di) {
       const int h = a.h[di < 0 ? -di : di];
-      const double zl = ring[((j + 1 + h) & (NR - 1)) * W + c + di];
-      const double zt = ring[((j - h) & (NR - 1)) * W + c + di];
+      int sl = slot_j + 1 + h, st = slot_j - h;
+      sl = sl >= NR ? sl - NR : sl;
+      st = st < 0 ? st + NR : st;
+      const double zl = ring[sl * W + c + di];
+      const double zt = ring[st * W + c + di];
       const double u = zl - zt, v = zl + zt;
       Sz += u;
       if (di != 0) Siz = fma((double)di, u, Siz);
@@ -267,32 +394,57 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
       sj += fma((double)h, v, zl);
     }
     Sjz = (Sjz + sj) - Sz;
+    slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
   }
-  if (__any(need_fixup) && lane == 0)
-    block_flags[((size_t)(rg.map >= 0 ? 0 : blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = 1;
+  }
 }
 
+constexpr int kStripRows = 128;       // interior strips
+constexpr int kBorderStripRows = 32;  // the clipped-disc tail is slower: shorter strips finish with the rest
+
+// Split the region into the frame (clipped discs; launched first, short strips) and the cells whose
+// disc lies inside the map; every rectangle keeps its 64-column blocks aligned to r.i0.
 template <int R>
-void launch_r(const Geo& g, const SlideArgs& a, const Layers& L, bool keep, const Region& r, int* flags, FastGrid* fg,
-              hipStream_t s) {
-  fg->nbx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
-  fg->nby = (r.j1 - r.j0 + a.out_rows - 1) / a.out_rows;
-  fg->nbz = r.map >= 0 ? 1 : g.batch;
-  fg->out_rows = a.out_rows;
-  dim3 grid((unsigned)fg->nbx, (unsigned)fg->nby, (unsigned)fg->nbz);
-  (void)hipMemsetAsync(flags, 0, sizeof(int) * (size_t)fg->nbx * fg->nby * fg->nbz, s);
-  hipLaunchKernelGGL(k_normals_slide<R>, grid, dim3(kLanes), 0, s, g, a, L.elev, L.step, L.slope, L.rough, L.trav,
-                     keep ? L.nx : nullptr, keep ? L.ny : nullptr, keep ? L.nz : nullptr, flags, r);
+void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Region& r, int* flags, hipStream_t s) {
+  const int ja = r.j0 > R ? r.j0 : (R < r.j1 ? R : r.j1);                      // first interior row
+  const int jb = r.j1 < g.cols - R ? r.j1 : (g.cols - R > ja ? g.cols - R : ja);  // one past the last
+  int bxa = 0;
+  const int nbx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
+  while (bxa < nbx && r.i0 + kLanes * bxa < R) ++bxa;
+  int bxb = nbx;
+  while (bxb > bxa && r.i0 + kLanes * bxb - 1 > g.rows - 1 - R) --bxb;  // last lane of block bxb-1
+  const int il = r.i0 + kLanes * bxa < r.i1 ? r.i0 + kLanes * bxa : r.i1;
+  const int ir = r.i0 + kLanes * bxb < r.i1 ? r.i0 + kLanes * bxb : r.i1;
+  const int rect[5][5] = {{r.i0, il, ja, jb, 1},        // left
+                          {ir, r.i1, ja, jb, 1},        // right
+                          {r.i0, r.i1, r.j0, ja, 1},    // top
+                          {r.i0, r.i1, jb, r.j1, 1},    // bottom
+                          {il, ir, ja, jb, 0}};         // interior
+  int n = 0, first = 0;
+  for (int t = 0; t < 5; ++t) {
+    if (rect[t][1] <= rect[t][0] || rect[t][3] <= rect[t][2]) continue;
+    SlideArgs::Sub& u = a.sub[n++];
+    u.i0 = rect[t][0]; u.i1 = rect[t][1]; u.j0 = rect[t][2]; u.j1 = rect[t][3];
+    u.border = rect[t][4];
+    u.out_rows = u.border ? kBorderStripRows : kStripRows;
+    u.nbx = (u.i1 - u.i0 + kLanes - 1) / kLanes;
+    u.first = first;
+    first += u.nbx * ((u.j1 - u.j0 + u.out_rows - 1) / u.out_rows);
+  }
+  a.nsub = n;
+  for (int t = n; t < 5; ++t) a.sub[t] = a.sub[n ? n - 1 : 0];
+  if (first == 0) return;
+  hipLaunchKernelGGL(k_normals_slide<R>, dim3((unsigned)first, 1, (unsigned)(r.map >= 0 ? 1 : g.batch)), dim3(kLanes),
+                     0, s, g, a, L.elev, L.step, L.slope, L.rough, L.trav, keep ? L.nx : nullptr,
+                     keep ? L.ny : nullptr, keep ? L.nz : nullptr, flags, r);
 }
 
 }  // namespace
 
-constexpr int kStripRows = 128;
-
 // Normals + slope + roughness for a tie-free disc (same disc for normals and roughness, positive axis
 // z, at least 3 cells).  Returns false if the shape is not supported by this kernel.
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
-                  const Region& r, int* flags, FastGrid* fg, hipStream_t s) {
+                  const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s) {
   const Disc& d = p.normals;
   if (d.n_ties != 0 || d.R < 1 || d.R > 16 || d.npoints < 3) return false;
   SlideArgs a;
@@ -304,7 +456,13 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   }
   a.np = d.npoints;
   a.sii = sii;
-  a.out_rows = kStripRows;
+  fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
+  fg->nty = (r.j1 - r.j0 + 15) / 16;
+  fg->nbz = r.map >= 0 ? 1 : g.batch;
+  a.fi0 = r.i0;
+  a.fj0 = r.j0;
+  a.ntx = fg->ntx;
+  a.nty = fg->nty;
   a.slope_crit = p.slope_crit;
   a.inv_slope_crit = 1.0 / p.slope_crit;
   a.rough_crit = p.rough_crit;
@@ -314,10 +472,13 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.w_step = p.w_step;
   a.w_rough = p.w_rough;
   a.combine = combine ? 1 : 0;
+  a.gtab = gtab;
+  if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
+  (void)hipMemsetAsync(flags, 0, sizeof(int) * (size_t)fg->ntx * fg->nty * fg->nbz, s);
   switch (d.R) {
 #define X(q) \
   case q:    \
-    launch_r<q>(g, a, L, keep_normals, r, flags, fg, s); \
+    launch_r<q>(g, a, L, keep_normals, r, flags, s); \
     return true;
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X
@@ -326,8 +487,34 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   }
 }
 
+// Host side: x/y moments of the disc clipped to di in [lo_i, hi_i], dj in [lo_j, hi_j] for every clip
+// code (kx, ky) in [-R, R]^2 (see k_normals_slide).  out must hold (2R+1)^2 * 6 ints.
+void build_clip_table(const Disc& d, int* out) {
+  const int R = d.R;
+  for (int ky = -R; ky <= R; ++ky)
+    for (int kx = -R; kx <= R; ++kx) {
+      const int lo_i = kx > 0 ? -R + kx : -R, hi_i = kx < 0 ? R + kx : R;
+      const int lo_j = ky > 0 ? -R + ky : -R, hi_j = ky < 0 ? R + ky : R;
+      int n = 0, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
+      for (int dj = lo_j; dj <= hi_j; ++dj) {
+        const int hw = d.hw[dj < 0 ? -dj : dj];
+        for (int di = -hw; di <= hw; ++di) {
+          if (di < lo_i || di > hi_i) continue;
+          ++n;
+          si += di;
+          sj += dj;
+          sii += di * di;
+          sij += di * dj;
+          sjj += dj * dj;
+        }
+      }
+      int* e = out + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+      e[0] = n; e[1] = si; e[2] = sj; e[3] = sii; e[4] = sij; e[5] = sjj;
+    }
+}
+
 int normals_fast_max_blocks(const Geo& g) {
-  return ((g.rows + kLanes - 1) / kLanes) * ((g.cols + kStripRows - 1) / kStripRows + 1) * g.batch;
+  return ((g.rows + kLanes - 1) / kLanes) * ((g.cols + 15) / 16) * g.batch;  // one flag per 64x16 tile
 }
 
 }  // namespace fast
