@@ -79,6 +79,7 @@ typedef enum te_layer {
 /* te_run_chain flags */
 #define TE_RUN_KEEP_NORMALS 0x1u /* also write surface_normal_{x,y,z} (i.e. no DeletionFilter) */
 #define TE_RUN_FOOTPRINT    0x2u /* run the circular footprint pass right after the chain */
+#define TE_RUN_FOOTPRINT_MEMO 0x8u /* with the footprint pass: also write slope_/step_/roughness_footprint (0/1/NaN) */
 #define TE_RUN_GENERIC_KERNELS 0x4u /* use only the shape-generic kernels (also the path for tie radii); for A/B tests */
 
 /* Filter parameters: same keys, defaults and validity ranges as the reference's configure()s.

@@ -21,6 +21,7 @@ LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traver
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
 RUN_GENERIC_KERNELS = 0x4
+RUN_FOOTPRINT_MEMO = 0x8
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",

@@ -1,0 +1,405 @@
+// te_footprint.hip -- the circular footprint pass on gfx950.
+//
+//   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
+//     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
+//     -> isTraversableForFilters / checkForSlope / checkForStep / checkForRoughness   :774-921
+//
+// k_fp_mask   one thread per cell: the pure per-cell predicate isTraversableForFilters (the reference
+//             memoises it in slope_footprint / step_footprint / roughness_footprint).  Only cells whose
+//             slope/step/roughness score is exactly 0 do any work; the branchy checkForStep geometry
+//             (submap, ray extension, Bresenham line) is evaluated with the reference's own double
+//             formulas (this file is built with -ffp-contract=off).
+// k_fp_slide  sliding-disc kernel (see te_slide_normals.hip): per lane the sum of the traversability
+//             values and the number of untraversable cells of its disc, moved one row per step.  A disc
+//             without untraversable cell gives the mean directly (sums of float values are exact in
+//             double, so the result equals the reference's spiral-order sum bit for bit); otherwise the
+//             lane walks the host-built spiral table (SpiralIterator order) over the rows already staged
+//             in LDS until the first untraversable cell, exactly like isTraversable().
+#include "te_internal.h"
+
+namespace te {
+
+namespace {
+
+constexpr int kLanes = 64;
+
+__device__ __forceinline__ float qnanf() { return __builtin_nanf(""); }
+__device__ __forceinline__ double cell_x(const Geo& g, int i) { return g.ax + g.res * (double)(-i); }
+__device__ __forceinline__ double cell_y(const Geo& g, int j) { return g.ay + g.res * (double)(-j); }
+
+// checkIfPositionWithinMap (grid_map_core)
+__device__ __forceinline__ bool pos_inside(const Geo& g, double x, double y) {
+  const double tx = -((x - g.pos_x) - 0.5 * g.len_x);
+  const double ty = -((y - g.pos_y) - 0.5 * g.len_y);
+  return tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y;
+}
+// getIndexFromPosition (grid_map_core)
+__device__ __forceinline__ bool pos_to_index(const Geo& g, double x, double y, int& i, int& j) {
+  const double vx = ((x - 0.5 * g.len_x) - g.pos_x) / g.res;
+  const double vy = ((y - 0.5 * g.len_y) - g.pos_y) / g.res;
+  i = (int)(-vx);
+  j = (int)(-vy);
+  return pos_inside(g, x, y) && i >= 0 && j >= 0 && i < g.rows && j < g.cols;
+}
+// boundPositionToRange (grid_map_core), one axis
+__device__ __forceinline__ double bound_axis(double position, double len, double mappos) {
+  double shifted = position - mappos + 0.5 * len;
+  double eps = 10.0 * 2.220446049250313e-16;
+  if (fabs(position) > 1.0) eps *= fabs(position);
+  if (shifted <= 0)
+    shifted = eps;
+  else if (shifted >= len)
+    shifted = len - eps;
+  return shifted + mappos - 0.5 * len;
+}
+
+// CircleIterator membership of offset (di, dj) around cell (i, j): integer test, exact double test for ties
+__device__ __forceinline__ bool in_disc(const Geo& g, const Disc& d, int i, int j, int di, int dj) {
+  const int ai = di < 0 ? -di : di, aj = dj < 0 ? -dj : dj;
+  if (aj <= d.R && d.hw[aj] >= 0 && ai <= d.hw[aj]) return true;
+  for (int t = 0; t < d.n_ties; ++t)
+    if (d.tie_di[t] == di && d.tie_dj[t] == dj) {
+      const double dx = cell_x(g, i + di) - cell_x(g, i), dy = cell_y(g, j + dj) - cell_y(g, j);
+      return dx * dx + dy * dy <= d.r2;
+    }
+  return false;
+}
+
+// checkForSlope :867-893 / checkForRoughness :895-921: more than ncrit zeros of `layer` in circle(3*res)?
+__device__ bool count_zero_ok(const Geo& g, const Disc& d, const float* __restrict__ layer, int i, int j, int ncrit) {
+  int n = 0;
+  const int K = d.reach;
+  for (int a = i - K; a <= i + K; ++a) {  // CircleIterator order: row index outer, column index inner
+    if (a < 0 || a >= g.rows) continue;
+    for (int b = j - K; b <= j + K; ++b) {
+      if (b < 0 || b >= g.cols) continue;
+      if (!in_disc(g, d, i, j, a - i, b - j)) continue;
+      if (layer[(size_t)b * g.rows + a] == 0.0f) n++;
+      if (n > ncrit) return false;
+    }
+  }
+  return true;
+}
+
+// checkForStep :794-865
+__device__ bool check_step(const Geo& g, const Disc& d, const float* __restrict__ elev, const float* __restrict__ step,
+                           int ci, int cj, double crit_step, double max_gap) {
+  const double cx = cell_x(g, ci), cy = cell_y(g, cj);
+  double height = (double)elev[(size_t)cj * g.rows + ci];
+  int candi[32], candj[32];
+  int ncand = 0;
+  const int K = d.reach;
+  for (int a = ci - K; a <= ci + K; ++a) {
+    if (a < 0 || a >= g.rows) continue;
+    for (int b = cj - K; b <= cj + K; ++b) {
+      if (b < 0 || b >= g.cols) continue;
+      if (!in_disc(g, d, ci, cj, a - ci, b - cj)) continue;
+      const size_t o = (size_t)b * g.rows + a;
+      if ((double)elev[o] > crit_step + height && step[o] == 0.0f && ncand < 32) {  // :807-809
+        candi[ncand] = a;
+        candj[ncand] = b;
+        ++ncand;
+      }
+    }
+  }
+  if (ncand == 0) {  // :811
+    candi[0] = ci;
+    candj[0] = cj;
+    ncand = 1;
+  }
+  for (int c = 0; c < ncand; ++c) {
+    const int ii = candi[c], ij = candj[c];
+    const double sl = 2.5 * g.res;                         // subMapLength :813
+    const double sx = cell_x(g, ii), sy = cell_y(g, ij);   // subMapPos
+    const double tcx = cx - sx, tcy = cy - sy;             // toCenter :816
+    // GridMap::getSubmap -> getSubmapInformation (grid_map_core)
+    const double tlx = bound_axis(sx + 0.5 * sl, g.len_x, g.pos_x), tly = bound_axis(sy + 0.5 * sl, g.len_y, g.pos_y);
+    int ti, tj, bi, bj;
+    if (!pos_to_index(g, tlx, tly, ti, tj)) return false;  // :818-822
+    const double brx = bound_axis(sx - 0.5 * sl, g.len_x, g.pos_x), bry = bound_axis(sy - 0.5 * sl, g.len_y, g.pos_y);
+    if (!pos_to_index(g, brx, bry, bi, bj)) return false;
+    const double tcornx = cell_x(g, ti) + 0.5 * g.res, tcorny = cell_y(g, tj) + 0.5 * g.res;
+    const int sr = bi - ti + 1, sc = bj - tj + 1;
+    const double slx = (double)sr * g.res, sly = (double)sc * g.res;
+    const double spx = tcornx - 0.5 * slx, spy = tcorny - 0.5 * sly;
+    height = (double)elev[(size_t)ij * g.rows + ii];  // :823
+    for (int lin = 0; lin < sr * sc; ++lin) {         // GridMapIterator over the submap: row index fastest
+      const int a = lin % sr, b = lin / sr;
+      const size_t o = (size_t)(tj + b) * g.rows + (ti + a);
+      if (step[o] == 0.0f && (double)elev[o] < height - crit_step) {  // :825
+        const double px = (spx + (0.5 * slx - 0.5 * g.res)) + g.res * (double)(-a);
+        const double py = (spy + (0.5 * sly - 0.5 * g.res)) + g.res * (double)(-b);
+        const double vx = px - sx, vy = py - sy;
+        if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
+        if (sqrt(tcx * tcx + tcy * tcy) > 0.025) {      // :830-832
+          if (tcx * vx + tcy * vy < 0.0) continue;
+        }
+        double qx = sx + vx, qy = sy + vy;
+        for (int guard = 0; guard < 100000; ++guard) {  // :834
+          const double ex = (qx - sx) + vx, ey = (qy - sy) + vy;
+          if (!(sqrt(ex * ex + ey * ey) < max_gap && pos_inside(g, qx + vx, qy + vy))) break;
+          qx += vx;
+          qy += vy;
+        }
+        int ei, ej;
+        pos_to_index(g, qx, qy, ei, ej);
+        ei = ei < 0 ? 0 : (ei > g.rows - 1 ? g.rows - 1 : ei);
+        ej = ej < 0 ? 0 : (ej > g.cols - 1 ? g.cols - 1 : ej);
+        // LineIterator (Bresenham, grid_map_core) from `index` to `endIndex` :839-852
+        const int dx = ei > ii ? ei - ii : ii - ei, dy = ej > ij ? ej - ij : ij - ej;
+        int inc1i = (ei >= ii) ? 1 : -1, inc2i = inc1i, inc1j = (ej >= ij) ? 1 : -1, inc2j = inc1j;
+        int den, num, numadd, ncells;
+        if (dx >= dy) {
+          inc1i = 0; inc2j = 0; den = dx; num = dx / 2; numadd = dy; ncells = dx + 1;
+        } else {
+          inc2i = 0; inc1j = 0; den = dy; num = dy / 2; numadd = dx; ncells = dy + 1;
+        }
+        int li = ii, lj = ij;
+        bool gap_start = false, gap_end = false;
+        for (int icell = 0; icell < ncells; ++icell) {
+          const float ef = elev[(size_t)lj * g.rows + li];
+          if ((double)ef > height + crit_step) return false;  // :840-843
+          if ((double)ef < height - crit_step || !__builtin_isfinite(ef)) {
+            gap_start = true;
+          } else if (gap_start) {
+            gap_end = true;
+            break;
+          }
+          num += numadd;
+          if (num >= den) {
+            num -= den;
+            li += inc1i;
+            lj += inc1j;
+          }
+          li += inc2i;
+          lj += inc2j;
+        }
+        if (gap_start && !gap_end) return false;  // :853-856
+      }
+    }
+  }
+  return true;
+}
+
+struct MaskArgs {
+  Disc slope_disc;  // circle(3*res)
+  Disc step_disc;   // circle(2.5*res)
+  int ncrit_slope, ncrit_rough, check_rough, write_memo;
+  double crit_step, max_gap;
+};
+
+// isTraversableForFilters :774-792 for every cell
+__global__ __launch_bounds__(256) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
+                                                 const float* __restrict__ slope, const float* __restrict__ step,
+                                                 const float* __restrict__ rough, uint8_t* __restrict__ untrav,
+                                                 float* __restrict__ slope_fp, float* __restrict__ step_fp,
+                                                 float* __restrict__ rough_fp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i >= g.rows) return;
+  const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
+  const size_t o = mo + (size_t)j * g.rows + i;
+  float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
+  bool ok = true;
+  if (slope[o] == 0.0f) {  // checkForSlope
+    ok = count_zero_ok(g, a.slope_disc, slope + mo, i, j, a.ncrit_slope);
+    m_slope = ok ? 1.0f : 0.0f;
+  }
+  if (ok && step[o] == 0.0f) {  // checkForStep
+    ok = check_step(g, a.step_disc, elev + mo, step + mo, i, j, a.crit_step, a.max_gap);
+    m_step = ok ? 1.0f : 0.0f;
+  }
+  if (ok && a.check_rough && rough[o] == 0.0f) {  // checkForRoughness
+    ok = count_zero_ok(g, a.slope_disc, rough + mo, i, j, a.ncrit_rough);
+    m_rough = ok ? 1.0f : 0.0f;
+  }
+  untrav[o] = ok ? 0 : 1;
+  if (a.write_memo) {
+    slope_fp[o] = m_slope;
+    step_fp[o] = m_step;
+    rough_fp[o] = m_rough;
+  }
+}
+
+struct SpiralArgs {
+  int h[kMaxRadiusCells + 1];  // half-heights of the tie-free part of the footprint disc
+  int n_ties;
+  int8_t tie_di[kMaxTies], tie_dj[kMaxTies];
+  double r2;
+  int n_spiral;               // entries of the ordered offset table
+  const int16_t* table;       // [n_spiral][4]: di, dj, ring (integer norm), tie flag
+  const int* gtab;            // clip table of the tie-free part: {n, ...} per (ky, kx)
+  double rmin, rmax, def;
+  int out_rows;
+};
+
+template <int R>
+__global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const float* __restrict__ trav,
+                                                     const uint8_t* __restrict__ untrav,
+                                                     float* __restrict__ footprint) {
+  constexpr int W = kLanes + 2 * R;
+  constexpr int NR = 2 * R + 2;
+  constexpr int NX = (W + kLanes - 1) / kLanes;
+  __shared__ double tring[NR * W];  // traversability (NaN -> default), 0 outside the map
+  __shared__ int uring[NR * W];     // 1 = untraversable, 0 otherwise / outside the map
+  const int lane = threadIdx.x;
+  const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
+  const int i0 = blockIdx.x * kLanes;
+  const int js = blockIdx.y * a.out_rows;
+  const int jend = js + a.out_rows < g.cols ? js + a.out_rows : g.cols;
+  const int i = i0 + lane;
+  const int c = lane + R;
+  const int kx = (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
+
+  for (int idx = lane; idx < NR * W; idx += kLanes) {
+    tring[idx] = 0.0;
+    uring[idx] = 0;
+  }
+  __syncthreads();
+  auto stage_row = [&](int r, int slot) {
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+      const int cc = lane + x * kLanes;
+      const int ci = i0 - R + cc;
+      if (cc < W) {
+        double t = 0.0;
+        int u = 0;
+        if (ci >= 0 && ci < g.rows && r >= 0 && r < g.cols) {
+          const size_t o = mo + (size_t)r * g.rows + ci;
+          const float tv = trav[o];
+          t = __builtin_isfinite(tv) ? (double)tv : a.def;  // :719-724
+          u = untrav[o];
+        }
+        tring[slot * W + cc] = t;
+        uring[slot * W + cc] = u;
+      }
+    }
+  };
+
+  double S = 0.0;
+  int U = 0;
+  const int jstart = js - (2 * R + 1);
+  int slot_j = 0;
+#pragma unroll 1
+  for (int j = jstart; j < jend; ++j) {
+    if (j >= js && i < g.rows) {
+      const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);
+      // cells on the circle itself (tie radii): CircleIterator/SpiralIterator::isInside per cell
+      double St = S;
+      int Ut = U, nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
+      for (int t = 0; t < a.n_ties; ++t) {
+        const int di = a.tie_di[t], dj = a.tie_dj[t];
+        const int ii = i + di, jj = j + dj;
+        if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
+        const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+        if (dx * dx + dy * dy <= a.r2) {
+          int sl = slot_j + dj;
+          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+          St += tring[sl * W + c + di];
+          Ut += uring[sl * W + c + di];
+          nt += 1;
+        }
+      }
+      float out;
+      if (Ut == 0) {
+        out = (float)(St / (double)nt);  // :732-735 no untraversable cell in the footprint
+      } else {
+        // walk the spiral until the first untraversable cell :687-717
+        double t = 0.0;
+        int ncells = 0;
+        out = qnanf();
+        for (int k = 0; k < a.n_spiral; ++k) {
+          const int di = a.table[4 * k + 0], dj = a.table[4 * k + 1];
+          const int ii = i + di, jj = j + dj;
+          if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
+          if (a.table[4 * k + 3]) {
+            const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+            if (!(dx * dx + dy * dy <= a.r2)) continue;
+          }
+          int sl = slot_j + dj;
+          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+          if (uring[sl * W + c + di]) {
+            const double ru = (double)a.table[4 * k + 2] * g.res;  // getCurrentRadius()
+            if (a.rmin == 0.0 || ru <= a.rmin) {
+              out = 0.0f;  // :694-704
+            } else {
+              const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+              t *= factor / ncells;
+              out = (float)t;
+            }
+            break;
+          }
+          ncells++;
+          t += tring[sl * W + c + di];
+        }
+        if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
+      }
+      footprint[mo + (size_t)j * g.rows + i] = out;
+    }
+    if (j + 1 >= jend) break;
+    {
+      int sl = slot_j + 1 + R;
+      sl = sl >= NR ? sl - NR : sl;
+      stage_row(j + 1 + R, sl);
+    }
+#pragma unroll
+    for (int di = -R; di <= R; ++di) {
+      const int h = a.h[di < 0 ? -di : di];
+      if (h < 0) continue;  // column not in the tie-free disc (only the tie offsets reach it)
+      int sl = slot_j + 1 + h, st = slot_j - h;
+      sl = sl >= NR ? sl - NR : sl;
+      st = st < 0 ? st + NR : st;
+      S += tring[sl * W + c + di] - tring[st * W + c + di];
+      U += uring[sl * W + c + di] - uring[st * W + c + di];
+    }
+    slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
+                            const int* clip_table, bool write_memo, hipStream_t stream) {
+  MaskArgs m;
+  m.slope_disc = p.slope_disc;
+  m.step_disc = p.step_disc;
+  m.ncrit_slope = p.ncrit_slope;
+  m.ncrit_rough = p.ncrit_rough;
+  m.check_rough = p.check_rough;
+  m.write_memo = write_memo ? 1 : 0;
+  m.crit_step = p.crit_step;
+  m.max_gap = p.max_gap;
+  hipLaunchKernelGGL(k_fp_mask, dim3((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch), dim3(256),
+                     0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp);
+  SpiralArgs a;
+  const Disc& d = p.fp_disc;
+  for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = (k <= d.R) ? d.hw[k] : -1;
+  a.n_ties = d.n_ties;
+  for (int t = 0; t < kMaxTies; ++t) {
+    a.tie_di[t] = d.tie_di[t];
+    a.tie_dj[t] = d.tie_dj[t];
+  }
+  a.r2 = d.r2;
+  a.n_spiral = p.n_spiral;
+  a.table = spiral_table;
+  a.gtab = clip_table;
+  a.rmin = p.rmin;
+  a.rmax = p.rmax;
+  a.def = p.def;
+  a.out_rows = 128;
+  const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
+                  (unsigned)g.batch);
+  switch (p.reach) {
+#define X(q) \
+  case q:    \
+    hipLaunchKernelGGL(k_fp_slide<q>, grid, dim3(kLanes), 0, stream, g, a, L.trav, L.untrav, L.footprint); \
+    break;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+#undef X
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace te

@@ -51,10 +51,12 @@ struct Region {  // half-open cell rectangle of one map (or all maps when map < 
 struct FootprintParams {
   Disc slope_disc;   // circle(3*res) of checkForSlope / checkForRoughness
   Disc step_disc;    // circle(2.5*res) of checkForStep
+  Disc fp_disc;      // circle(radiusMax) of the spiral
+  int reach;         // largest |offset| the spiral visits
+  int ncrit_slope, ncrit_rough;
   double rmin, rmax, def, max_gap, crit_step;
   int check_rough;
   int n_spiral;      // entries of the ordered spiral table
-  int n_spiral_tested_from;  // first entry that belongs to the two outer rings (isInside-tested)
 };
 
 struct Layers {
@@ -83,9 +85,9 @@ struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
 hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags,
                         hipStream_t stream);
-hipError_t launch_footprint(const Geo& g, const ChainParams& cp, const FootprintParams& p, const Layers& L,
-                            const int16_t* spiral_di, const int16_t* spiral_dj, const int16_t* spiral_ring,
-                            hipStream_t stream);
+// spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)
+hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
+                            const int* clip_table, bool write_memo, hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
 
 // shape-specialised kernels (te_fast_*.hip); return false when the shape Q is not instantiated
@@ -98,7 +100,7 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
                   const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
-void build_clip_table(const Disc& d, int* out);  // (2R+1)^2 * 6 ints
+void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast
 
 }  // namespace te

@@ -119,6 +119,7 @@ struct te_ctx {
   void* slab = nullptr;
   int16_t* d_spiral = nullptr;
   int* clip_table = nullptr;
+  int* fp_clip_table = nullptr;
   bool tables_ready = false;
 };
 
@@ -148,13 +149,97 @@ int rebuild_tables(te_ctx* c) {
   if (c->cp.normals.n_ties == 0 && c->cp.normals.R >= 1) {
     const int R = c->cp.normals.R;
     std::vector<int> tab((size_t)(2 * R + 1) * (2 * R + 1) * 6);
-    fast::build_clip_table(c->cp.normals, tab.data());
+    fast::build_clip_table(c->cp.normals, R, tab.data());
     HIP_TRY(hipSetDevice(c->device));
     if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1)));
     HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   c->L.clip_table = c->clip_table;
+
+  // ---- circular footprint: discs of the three checks, spiral order, clip table ----------------------
+  {
+    FootprintParams& f = c->fp;
+    if ((rc = build_disc(3.0 * res, res, &f.slope_disc, "footprint slope window"))) return rc;   // TraversabilityMap.cpp:871
+    if ((rc = build_disc(2.5 * res, res, &f.step_disc, "footprint step window"))) return rc;     // :798
+    f.rmin = p.fp_radius;
+    f.rmax = p.fp_radius + p.fp_offset;  // :312 isTraversable(center, radius + offset, ..., radius)
+    if ((rc = build_disc(f.rmax, res, &f.fp_disc, "footprint"))) return rc;
+    f.def = p.fp_default;
+    f.max_gap = p.fp_max_gap;
+    f.crit_step = p.fp_critical_step;
+    f.check_rough = p.fp_check_roughness;
+    {
+      const double wr = 3.0 * res, crit_len = p.fp_max_gap / 3.0;
+      f.ncrit_slope = (int)floor(2 * wr * crit_len / pow(res, 2));    // :873
+      f.ncrit_rough = (int)floor(1.5 * wr * crit_len / pow(res, 2));  // :901
+    }
+    // SpiralIterator order (grid_map_core): centre, then ring d = 1..nRings, each generated by a perimeter
+    // walk from (d, 0) and consumed from the back; only the two outer rings are tested against the circle.
+    const Disc& d = f.fp_disc;
+    const unsigned nrings = (unsigned)ceil(f.rmax / res);
+    std::vector<int16_t> tab;
+    auto tie_of = [&](int di, int dj) {
+      for (int t = 0; t < d.n_ties; ++t)
+        if (d.tie_di[t] == di && d.tie_dj[t] == dj) return true;
+      return false;
+    };
+    auto in_runs = [&](int di, int dj) {
+      const int ai = di < 0 ? -di : di, aj = dj < 0 ? -dj : dj;
+      return aj <= d.R && d.R >= 0 && d.hw[aj] >= 0 && ai <= d.hw[aj];
+    };
+    auto push = [&](int di, int dj, bool tie) {
+      tab.push_back((int16_t)di);
+      tab.push_back((int16_t)dj);
+      tab.push_back((int16_t)(int)sqrt((double)(di * di + dj * dj)));  // getCurrentRadius(): integer norm
+      tab.push_back((int16_t)(tie ? 1 : 0));
+    };
+    push(0, 0, false);
+    int reach = 0;
+    for (unsigned dist = 1; dist <= nrings && dist <= (unsigned)kMaxRadiusCells + 1; ++dist) {
+      std::vector<int> ring;
+      int px = (int)dist, py = 0;
+      do {
+        bool keep = true, tie = false;
+        if (dist == nrings || dist + 1 == nrings) {
+          tie = tie_of(px, py);
+          keep = tie || in_runs(px, py);
+        }
+        if (keep) {
+          ring.push_back(px);
+          ring.push_back(py);
+          ring.push_back(tie ? 1 : 0);
+        }
+        const int nx = -((py > 0) - (py < 0)), ny = (px > 0) - (px < 0);
+        if (nx != 0 && (unsigned)sqrt((double)(px + nx) * (px + nx) + (double)py * py) == dist)
+          px += nx;
+        else if (ny != 0 && (unsigned)sqrt((double)px * px + (double)(py + ny) * (py + ny)) == dist)
+          py += ny;
+        else {
+          px += nx;
+          py += ny;
+        }
+      } while ((unsigned)px != dist || py != 0);
+      for (int k = (int)ring.size() / 3 - 1; k >= 0; --k) {
+        push(ring[3 * k], ring[3 * k + 1], ring[3 * k + 2] != 0);
+        const int ax = abs(ring[3 * k]), ay = abs(ring[3 * k + 1]);
+        reach = ax > reach ? ax : reach;
+        reach = ay > reach ? ay : reach;
+      }
+    }
+    f.n_spiral = (int)tab.size() / 4;
+    f.reach = reach < 1 ? 1 : reach;
+    if (f.reach > 20 || f.n_spiral > kMaxSpiral)
+      return fail(TE_ERR_UNSUPPORTED, "footprint radius %.3g m is %d cells; this build supports up to 20", f.rmax, f.reach);
+    std::vector<int> ctab((size_t)(2 * f.reach + 1) * (2 * f.reach + 1) * 6);
+    fast::build_clip_table(d, f.reach, ctab.data());
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_spiral) HIP_TRY(hipMalloc((void**)&c->d_spiral, sizeof(int16_t) * 4 * kMaxSpiral));
+    if (!c->fp_clip_table) HIP_TRY(hipMalloc((void**)&c->fp_clip_table, sizeof(int) * 6 * 41 * 41));
+    HIP_TRY(hipMemcpyAsync(c->d_spiral, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fp_clip_table, ctab.data(), ctab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   c->tables_ready = true;
   return TE_OK;
 }
@@ -196,6 +281,15 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
+  return TE_OK;
+}
+
+int run_footprint_locked(te_ctx* c, unsigned flags) {
+  if (!c->chain_done || !c->tables_ready)
+    return fail(TE_ERR_NOT_READY, "te_run_footprint: run the filter chain first (it produces the layers the footprint reads)");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
+                           c->stream));
   return TE_OK;
 }
 
@@ -316,6 +410,7 @@ int te_destroy(te_ctx* c) {
     free_layers(c);
     if (c->d_spiral) (void)hipFree(c->d_spiral);
     if (c->clip_table) (void)hipFree(c->clip_table);
+    if (c->fp_clip_table) (void)hipFree(c->fp_clip_table);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -452,7 +547,7 @@ int te_run_chain(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   int rc = run_chain_locked(c, flags, r);
   if (rc) return rc;
-  if (flags & TE_RUN_FOOTPRINT) return fail(TE_ERR_UNSUPPORTED, "footprint pass not built yet");
+  if (flags & TE_RUN_FOOTPRINT) return run_footprint_locked(c, flags);
   return TE_OK;
 }
 
@@ -470,7 +565,8 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
 
 int te_run_footprint(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_footprint: NULL ctx");
-  return fail(TE_ERR_UNSUPPORTED, "footprint pass not built yet");
+  std::lock_guard<std::mutex> lk(c->mu);
+  return run_footprint_locked(c, TE_RUN_FOOTPRINT_MEMO);
 }
 
 int te_sync(te_ctx* c) {
@@ -503,11 +599,13 @@ int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_pe
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   for (int k = 0; k < warmup; ++k) {
     int rc = run_chain_locked(c, flags, r);
+    if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags);
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int k = 0; k < iters; ++k) {
     int rc = run_chain_locked(c, flags, r);
+    if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags);
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(c->ev1, c->stream));

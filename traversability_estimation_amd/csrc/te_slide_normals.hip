@@ -489,15 +489,15 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
 
 // Host side: x/y moments of the disc clipped to di in [lo_i, hi_i], dj in [lo_j, hi_j] for every clip
 // code (kx, ky) in [-R, R]^2 (see k_normals_slide).  out must hold (2R+1)^2 * 6 ints.
-void build_clip_table(const Disc& d, int* out) {
-  const int R = d.R;
+void build_clip_table(const Disc& d, int R, int* out) {
   for (int ky = -R; ky <= R; ++ky)
     for (int kx = -R; kx <= R; ++kx) {
       const int lo_i = kx > 0 ? -R + kx : -R, hi_i = kx < 0 ? R + kx : R;
       const int lo_j = ky > 0 ? -R + ky : -R, hi_j = ky < 0 ? R + ky : R;
       int n = 0, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
       for (int dj = lo_j; dj <= hi_j; ++dj) {
-        const int hw = d.hw[dj < 0 ? -dj : dj];
+        const int adj = dj < 0 ? -dj : dj;
+        const int hw = adj <= d.R ? d.hw[adj] : -1;
         for (int di = -hw; di <= hw; ++di) {
           if (di < lo_i || di > hi_i) continue;
           ++n;
