@@ -20,6 +20,8 @@
  *   te_upload_elevation  <- the "elevation" layer of mapIn handed to every plugin's
  *                           update(const T& mapIn, T& mapOut) (SlopeFilter.cpp:59, StepFilter.cpp:102,
  *                           RoughnessFilter.cpp:73)
+ *   te_run_filter        <- one plugin's update(): SlopeFilter.cpp:59-88 / StepFilter.cpp:102-182 /
+ *                           RoughnessFilter.cpp:73-132, reading the layers that plugin reads from mapIn
  *   te_run_chain         <- filters::FilterChain<GridMap>::update, TraversabilityMap.cpp:214
  *                           (NormalVectorsFilter -> SlopeFilter::update -> StepFilter::update ->
  *                           RoughnessFilter::update -> MathExpressionFilter -> DeletionFilter)
@@ -82,6 +84,16 @@ typedef enum te_layer {
 #define TE_RUN_FOOTPRINT_MEMO 0x8u /* with the footprint pass: also write slope_/step_/roughness_footprint (0/1/NaN) */
 #define TE_RUN_GENERIC_KERNELS 0x4u /* use only the shape-generic kernels (also the path for tie radii); for A/B tests */
 
+/* The reference's plugins one at a time (te_run_filter): what the drop-in adapters of
+ * traversabilityFilters/{Slope,Step,Roughness}Filter call, each reading exactly the layers the
+ * reference plugin reads from mapIn. */
+typedef enum te_filter {
+  TE_FILTER_SLOPE = 1,     /* in: surface_normal_z                      out: traversability_slope     (SlopeFilter.cpp:59-88) */
+  TE_FILTER_STEP = 2,      /* in: elevation                             out: traversability_step      (StepFilter.cpp:102-182) */
+  TE_FILTER_ROUGHNESS = 3, /* in: elevation, surface_normal_{x,y,z}     out: traversability_roughness (RoughnessFilter.cpp:73-132) */
+  TE_FILTER_COMBINE = 4    /* in: the three scores                      out: traversability           (MathExpressionFilter) */
+} te_filter;
+
 /* Filter parameters: same keys, defaults and validity ranges as the reference's configure()s.
  * POD; `size` must be sizeof(te_params) (ABI check).  This is the blob that is broadcast to the
  * other ranks (RCCL) when the batch is sharded over several GPUs. */
@@ -142,6 +154,10 @@ int te_upload_tile(te_ctx* ctx, const float* host_tile, int map, int row0, int c
  * (e.g. a torch tensor filled on the same device); valid until te_set_geometry/te_destroy. */
 int te_device_ptr(te_ctx* ctx, int layer, void** dptr, size_t* bytes);
 
+/* Host -> device copy of any layer (e.g. surface_normal_z for TE_FILTER_SLOPE); elevation marks the context ready. */
+int te_upload_layer(te_ctx* ctx, int layer, const float* host, int map0, int nmaps);
+/* Run ONE of the reference's plugins on the resident layers (see te_filter). */
+int te_run_filter(te_ctx* ctx, int filter, unsigned flags);
 int te_run_chain(te_ctx* ctx, unsigned flags);
 /* Re-filter only the cells whose outputs can change when the h x w rectangle at (row0,col0) of map
  * `map` changed (the rectangle dilated by the chain's reach). */

@@ -243,3 +243,25 @@ def test_footprint_tie_radius_and_zero_rmin(capi, oracle):
         got, want, op = both_fp(capi, oracle, elev, rows, cols, res, normals_radius=r, rough_radius=r,
                                 step_radius1=r, step_radius2=r, fp_radius=fr, fp_offset=fo)
         check_fp(got, want, op, f"tie footprint {fr}+{fo}")
+
+
+def test_single_plugin_entry_points(capi, oracle):
+    """te_run_filter: each reference plugin on exactly the layers it reads from mapIn (normals are INPUT)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 170, 130, 0.04
+    elev = synth.with_holes(synth.with_steps(synth.perlin_elevation(rows, cols, seed=61), 8, seed=62), 0.02, seed=63)
+    op = oracle.default_params(normals_radius=0.09, rough_radius=0.15, step_radius1=0.1, step_radius2=0.07)
+    want = oracle.chain(oracle.geom(rows, cols, res), op, elev, want_normals=True)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(elev)
+        for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z"):
+            ctx.upload_layer(k, want[k])
+        for f in ("slope", "step", "roughness", "combine"):
+            ctx.run_filter(f)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+    assert_layers_match(got, want, ctx="single plugins")
+    # with the reference's float32 normals as input the slope is the same double acos of the same float
+    assert (got["traversability_step"].view(np.uint32) == want["traversability_step"].view(np.uint32)).all()

@@ -18,6 +18,7 @@ TE_ERR_INVALID_ARG, TE_ERR_BAD_PARAM, TE_ERR_NOT_READY, TE_ERR_HIP, TE_ERR_NO_DE
 LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traversability_roughness=3,
               traversability=4, traversability_footprint=5, surface_normal_x=6, surface_normal_y=7,
               surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11)
+FILTERS = dict(slope=1, step=2, roughness=3, combine=4)
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
 RUN_GENERIC_KERNELS = 0x4
@@ -26,7 +27,7 @@ RUN_FOOTPRINT_MEMO = 0x8
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
-           "te_device_ptr", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_sync",
+           "te_device_ptr", "te_upload_layer", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_sync",
            "te_download_layer", "te_time_chain", "te_last_error", "te_version"]
 
 
@@ -73,6 +74,8 @@ def load():
         L.te_upload_elevation.argtypes = [vp, fp, C.c_int, C.c_int]
         L.te_upload_tile.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
+        L.te_run_filter.argtypes = [vp, C.c_int, C.c_uint]
         L.te_run_chain.argtypes = [vp, C.c_uint]
         L.te_run_chain_region.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_run_footprint.argtypes = [vp]
@@ -172,6 +175,16 @@ class Context:
         _check(load().te_device_ptr(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), C.byref(p),
                                     C.byref(n)))
         return p.value, n.value
+
+    def upload_layer(self, layer, data, map0=0):
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        per = self.rows * self.cols
+        assert a.size % per == 0, (a.size, per)
+        _check(load().te_upload_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
+                                      a.ctypes.data_as(C.POINTER(C.c_float)), int(map0), a.size // per))
+
+    def run_filter(self, which, flags=0):
+        _check(load().te_run_filter(self._h, FILTERS[which] if isinstance(which, str) else int(which), int(flags)))
 
     def run_chain(self, flags=0):
         _check(load().te_run_chain(self._h, int(flags)))

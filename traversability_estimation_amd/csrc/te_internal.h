@@ -83,6 +83,8 @@ struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 
 };
 
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
+hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, int filter, unsigned flags,
+                         hipStream_t stream);
 hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags,
                         hipStream_t stream);
 // spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)

@@ -187,6 +187,7 @@ struct NormalsArgs {
   double slope_crit, rough_crit;
   float w_scale, w_slope, w_step, w_rough;
   int combine;  // also write the traversability layer (reads the step layer)
+  int given_normals;  // RoughnessFilter alone: surface_normal_{x,y,z} are INPUT layers (RoughnessFilter.cpp:108-110)
 };
 
 // One cell from the LDS tile: normals -> slope -> roughness (-> combine), all outputs written.
@@ -198,6 +199,26 @@ __device__ __forceinline__ void normals_cell(const Geo& g, const NormalsArgs& a,
   const float z0f = *ctr;
   const float qnan = __builtin_nanf("");
   float o_slope = qnan, o_rough = qnan, nf[3] = {qnan, qnan, qnan};
+  if (a.given_normals) {  // RoughnessFilter::update as a stand-alone plugin: the normals come from the map
+    nf[0] = onx[o];
+    nf[1] = ony[o];
+    nf[2] = onz[o];
+    if (__builtin_isfinite(nf[0])) {  // RoughnessFilter.cpp:84 (hard-coded surface_normal_x validity)
+      Mom m;
+      double cov[6];
+      mom_zero(m);
+      // the reference gathers the valid elevations of the window even if the centre itself is invalid
+      accumulate_disc(m, g, a.dr, ctr, tw, i, j, (z0f == z0f) ? (double)z0f : 0.0);
+      if (m.n >= 1) {
+        covariance(m, g.res, cov);
+        o_rough = roughness_score(m, cov, nf, a.rough_crit);
+      } else {
+        o_rough = 0.0f;  // 0 points: mean = 0/0, roughness NaN -> "roughness < crit" false -> 0.0
+      }
+    }
+    rough[o] = o_rough;
+    return;
+  }
   if (z0f == z0f) {  // normals only where the input layer is valid; slope/roughness follow (SlopeFilter.cpp:71, RoughnessFilter.cpp:84)
     const double z0 = (double)z0f;
     Mom m;
@@ -327,6 +348,15 @@ __global__ void k_combine(Geo g, float w_scale, float w_slope, float w_step, flo
   trav[o] = w_scale * abc;
 }
 
+// SlopeFilter::update as a stand-alone plugin: surface_normal_z is an INPUT layer (SlopeFilter.cpp:67-84)
+__global__ void k_slope_from_nz(Geo g, double crit, const float* __restrict__ nz, float* __restrict__ slope) {
+  const size_t n = (size_t)g.rows * g.cols * g.batch;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  const float v = nz[o];
+  slope[o] = __builtin_isfinite(v) ? slope_score(v, crit) : __builtin_nanf("");
+}
+
 inline Region clamp_region(const Geo& g, const Region& r, int grow) {
   Region o = r;
   o.i0 = r.i0 - grow < 0 ? 0 : r.i0 - grow;
@@ -349,6 +379,46 @@ int chain_max_reach(const ChainParams& p) {
   int a = p.normals.reach > p.rough.reach ? p.normals.reach : p.rough.reach;
   int b = p.step1.reach + p.step2.reach;
   return a > b ? a : b;
+}
+
+// One reference plugin at a time (the drop-in SlopeFilter / StepFilter / RoughnessFilter adapters).
+hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, int filter, unsigned flags,
+                         hipStream_t stream) {
+  const Region r = {-1, 0, 0, g.rows, g.cols};
+  const dim3 blk(TX, BY);
+  const bool use_fast = (flags & TE_RUN_GENERIC_KERNELS) == 0;
+  if (filter == TE_FILTER_SLOPE) {
+    const size_t n = (size_t)g.rows * g.cols * g.batch;
+    hipLaunchKernelGGL(k_slope_from_nz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, p.slope_crit, L.nz,
+                       L.slope);
+  } else if (filter == TE_FILTER_STEP) {
+    if (!(use_fast && fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r, stream)))
+      hipLaunchKernelGGL(k_step_height, tile_grid(g, r), blk, tile_bytes(p.step1.reach), stream, g, p.step1, L.elev,
+                         L.step_height, r);
+    if (!(use_fast && fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r, stream)))
+      hipLaunchKernelGGL(k_step_score, tile_grid(g, r), blk, tile_bytes(p.step2.reach), stream, g, p.step2, p.step_crit,
+                         p.step_ncrit, L.step_height, L.step, r);
+  } else if (filter == TE_FILTER_ROUGHNESS) {
+    NormalsArgs na;
+    na.dn = p.rough;
+    na.dr = p.rough;
+    na.same_disc = 1;
+    na.axis = p.axis;
+    na.slope_crit = p.slope_crit;
+    na.rough_crit = p.rough_crit;
+    na.w_scale = na.w_slope = na.w_step = na.w_rough = 0.0f;
+    na.combine = 0;
+    na.given_normals = 1;
+    hipLaunchKernelGGL(k_normals, tile_grid(g, r), blk, tile_bytes(p.rough.reach), stream, g, na, L.elev, L.step, L.slope,
+                       L.rough, L.trav, L.nx, L.ny, L.nz, r);
+  } else if (filter == TE_FILTER_COMBINE) {
+    const dim3 cgrid((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch);
+    hipLaunchKernelGGL(k_combine, cgrid, dim3(256), 0, stream, g, p.w_scale, p.w_slope, p.w_step, p.w_rough, L.slope,
+                       L.step, L.rough, L.trav, r);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags,
@@ -381,6 +451,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   na.w_slope = p.w_slope;
   na.w_step = p.w_step;
   na.w_rough = p.w_rough;
+  na.given_normals = 0;
   na.combine = whole ? 1 : 0;  // region runs: the step reach may exceed the normals reach, combine separately
   float* const knx = keep ? L.nx : nullptr;
   float* const kny = keep ? L.ny : nullptr;

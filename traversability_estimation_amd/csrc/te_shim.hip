@@ -540,6 +540,38 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   return TE_OK;
 }
 
+int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps) {
+  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: NULL");
+  if (layer == TE_LAYER_ELEVATION) return te_upload_elevation(c, host, map0, nmaps);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer: geometry not set");
+  float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: bad layer %d", layer);
+  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
+    return fail(TE_ERR_INVALID_ARG, "te_upload_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  HIP_TRY(hipMemcpyAsync(p + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TE_OK;
+}
+
+int te_run_filter(te_ctx* c, int filter, unsigned flags) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_filter: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->have_params) return fail(TE_ERR_NOT_READY, "te_run_filter: set params and geometry first");
+  if (!c->tables_ready) {
+    int rc = rebuild_tables(c);
+    if (rc) return rc;
+  }
+  if (filter < TE_FILTER_SLOPE || filter > TE_FILTER_COMBINE) return fail(TE_ERR_INVALID_ARG, "te_run_filter: bad filter %d", filter);
+  if ((filter == TE_FILTER_STEP || filter == TE_FILTER_ROUGHNESS) && !c->have_elev)
+    return fail(TE_ERR_NOT_READY, "te_run_filter: no elevation uploaded");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
+  return TE_OK;
+}
+
 int te_run_chain(te_ctx* c, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);
