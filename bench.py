@@ -91,27 +91,17 @@ def main():
     import torch
     from traversability_estimation_amd import capi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from traversability_estimation_amd import dist as tdist
+    rank, world, local_rank = tdist.init_process_group()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     capi.load()
 
-    # filter parameters: rank 0 decides, everyone else receives the te_params blob over RCCL
-    p = make_params(capi, synth, args)
-    if world > 1:
-        blob = torch.frombuffer(bytearray(capi.params_to_bytes(p)), dtype=torch.uint8).cuda()
-        if rank != 0:
-            blob.zero_()
-        dist.broadcast(blob, src=0)
-        p = capi.params_from_bytes(bytes(blob.cpu().numpy().tobytes()))
+    # filter parameters: rank 0 decides, every other rank receives the te_params blob over RCCL
+    p = tdist.broadcast_params(capi, make_params(capi, synth, args), src=0)
 
     with_fp = not args.no_footprint
     flags = capi.RUN_FOOTPRINT if with_fp else 0
@@ -124,9 +114,7 @@ def main():
     ctx.set_geometry(n, n, B, args.res)
     ctx.upload_elevation(np.stack(elevs))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = tdist.barrier
 
     for _ in range(args.warmup):
         ctx.run_chain(flags)
@@ -140,10 +128,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = tdist.max_over_ranks(dt)
 
     # kernel-only duration of the chain: HIP events on the context's own stream
     ms_chain = ctx.time_chain(flags, warmup=1, iters=max(5, min(args.steps, 50)))
@@ -186,7 +171,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 per-cell math on f32 layers",
+            "dtype": "f64",
             "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)",
             "config": {"workload": f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
                                    f" (normals/roughness/step), slope+roughness+step+normals+combine"

@@ -1,0 +1,73 @@
+"""world_size-2 test of the multi-GPU plumbing on CPU (gloo): parameter broadcast from rank 0, batch-axis
+sharding with no data-path collective, max-over-ranks timing.  The per-rank compute is the CPU oracle
+here (no GPU in this container); on the GPU box the same code paths drive libtravgpu via bench.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from tests.conftest import ROOT
+
+WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["TE_ROOT"])
+from traversability_estimation_amd import capi, dist, synth
+from oracle import oracle as O
+rank, world, _ = dist.init_process_group("gloo")
+assert world == 2
+# rank 0 decides the parameters; rank 1 starts from different ones and must end up with rank 0's
+p = capi.default_params(normals_radius=0.11 if rank == 0 else 0.5, step_ncrit=3 if rank == 0 else 9,
+                        w_scale=0.25 if rank == 0 else 0.75)
+p = dist.broadcast_params(capi, p, src=0)
+assert abs(p.normals_radius - 0.11) < 1e-15 and p.step_ncrit == 3 and p.w_scale == 0.25, (rank, p.normals_radius)
+# shard a batch of 5 maps: 3 + 2
+n_maps, rows, cols, res = 5, 48, 40, 0.05
+a, b = dist.shard_range(n_maps, rank, world)
+assert (a, b) == ((0, 3) if rank == 0 else (3, 5))
+op = O.default_params()
+for f, _ in op._fields_:
+    setattr(op, f, getattr(p, f))
+g = O.geom(rows, cols, res)
+local = np.stack([O.chain(g, op, synth.perlin_elevation(rows, cols, seed=2000 + m))["traversability"] for m in range(a, b)])
+full = dist.gather_shards(local, n_maps)
+t = dist.max_over_ranks(1.0 + rank)
+assert t == 2.0
+dist.barrier()
+if rank == 0:
+    np.save(os.environ["TE_OUT"], full)
+'''
+
+
+def test_two_rank_broadcast_and_batch_sharding(tmp_path):
+    out = tmp_path / "full.npy"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, TE_ROOT=ROOT, TE_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    full = np.load(out)
+    # the sharded result equals the single-process one, map by map
+    from oracle import oracle as O
+    from traversability_estimation_amd import capi, synth
+    p = capi.default_params(normals_radius=0.11, step_ncrit=3, w_scale=0.25)
+    op = O.default_params()
+    for f, _ in op._fields_:
+        setattr(op, f, getattr(p, f))
+    g = O.geom(48, 40, 0.05)
+    for m in range(5):
+        want = O.chain(g, op, synth.perlin_elevation(48, 40, seed=2000 + m))["traversability"]
+        assert (full[m].view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_shard_ranges_partition_the_batch():
+    from traversability_estimation_amd import dist
+    for n in (1, 5, 8, 512, 513):
+        for world in (1, 2, 4, 8):
+            spans = [dist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[k][1] == spans[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
