@@ -53,129 +53,201 @@ __device__ __forceinline__ double bound_axis(double position, double len, double
   return shifted + mappos - 0.5 * len;
 }
 
-// CircleIterator membership of offset (di, dj) around cell (i, j): integer test, exact double test for ties
-__device__ __forceinline__ bool in_disc(const Geo& g, const Disc& d, int i, int j, int di, int dj) {
-  const int ai = di < 0 ? -di : di, aj = dj < 0 ? -dj : dj;
-  if (aj <= d.R && d.hw[aj] >= 0 && ai <= d.hw[aj]) return true;
-  for (int t = 0; t < d.n_ties; ++t)
-    if (d.tie_di[t] == di && d.tie_dj[t] == dj) {
-      const double dx = cell_x(g, i + di) - cell_x(g, i), dy = cell_y(g, j + dj) - cell_y(g, j);
-      return dx * dx + dy * dy <= d.r2;
+// A layer seen through the LDS tile of the block (64x16 cells + halo); cells outside the tile are
+// read from global memory (only the rare long Bresenham walks of checkForStep leave the tile).
+constexpr int MX = 64, MY = 32, MBY = 4, MH = 3;  // tile, threads along j, halo (>= reach of both windows + 1)
+constexpr int MTW = MX + 2 * MH, MTH = MY + 2 * MH;
+
+struct TileView {
+  const float* lds;
+  const float* glob;
+  int i0, j0, rows;
+  __device__ __forceinline__ float at(int a, int b) const {
+    const int la = a - i0 + MH, lb = b - j0 + MH;
+    if (lds && (unsigned)la < (unsigned)MTW && (unsigned)lb < (unsigned)MTH) return lds[lb * MTW + la];
+    return glob[(size_t)b * rows + a];
+  }
+};
+
+__device__ __forceinline__ void load_view(float* lds, const float* __restrict__ glob, const Geo& g, int i0, int j0) {
+  for (int tj = threadIdx.y; tj < MTH; tj += MBY) {
+    const int b = j0 - MH + tj;
+    for (int ti = threadIdx.x; ti < MTW; ti += MX) {
+      const int a = i0 - MH + ti;
+      float v = qnanf();
+      if (a >= 0 && a < g.rows && b >= 0 && b < g.cols) v = glob[(size_t)b * g.rows + a];
+      lds[tj * MTW + ti] = v;
     }
-  return false;
+  }
+}
+
+// Visit the in-map cells of CircleIterator(center (i,j), disc d): run table + per-cell test of the tie offsets.
+// (The visiting order differs from CircleIterator's; the predicates below do not depend on it.)
+template <typename F>
+__device__ __forceinline__ void for_disc(const Geo& g, const Disc& d, int i, int j, F&& body) {
+  for (int dj = -d.R; dj <= d.R; ++dj) {
+    const int b = j + dj;
+    if (b < 0 || b >= g.cols) continue;
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) {
+      const int a = i + di;
+      if (a < 0 || a >= g.rows) continue;
+      body(a, b);
+    }
+  }
+  for (int t = 0; t < d.n_ties; ++t) {
+    const int a = i + d.tie_di[t], b = j + d.tie_dj[t];
+    if (a < 0 || a >= g.rows || b < 0 || b >= g.cols) continue;
+    const double dx = cell_x(g, a) - cell_x(g, i), dy = cell_y(g, b) - cell_y(g, j);
+    if (dx * dx + dy * dy <= d.r2) body(a, b);
+  }
 }
 
 // checkForSlope :867-893 / checkForRoughness :895-921: more than ncrit zeros of `layer` in circle(3*res)?
-__device__ bool count_zero_ok(const Geo& g, const Disc& d, const float* __restrict__ layer, int i, int j, int ncrit) {
+__device__ __forceinline__ bool count_zero_ok(const Geo& g, const Disc& d, const TileView& layer, int i, int j, int ncrit) {
   int n = 0;
-  const int K = d.reach;
-  for (int a = i - K; a <= i + K; ++a) {  // CircleIterator order: row index outer, column index inner
-    if (a < 0 || a >= g.rows) continue;
-    for (int b = j - K; b <= j + K; ++b) {
-      if (b < 0 || b >= g.cols) continue;
-      if (!in_disc(g, d, i, j, a - i, b - j)) continue;
-      if (layer[(size_t)b * g.rows + a] == 0.0f) n++;
-      if (n > ncrit) return false;
+  for_disc(g, d, i, j, [&](int a, int b) { n += (layer.at(a, b) == 0.0f) ? 1 : 0; });
+  return !(n > ncrit);
+}
+
+// largest float <= T / smallest float >= T: for a float x,  (double)x > T <=> x > ffloor(T),  (double)x < T <=> x < fceil(T)
+__device__ __forceinline__ float ffloor_d(double T) {
+  float f = (float)T;
+  if ((double)f > T)  // step one float down
+    f = f > 0.0f ? __uint_as_float(__float_as_uint(f) - 1u)
+                 : (f < 0.0f ? __uint_as_float(__float_as_uint(f) + 1u) : __uint_as_float(0x80000001u));
+  return f;
+}
+__device__ __forceinline__ float fceil_d(double T) {
+  float f = (float)T;
+  if ((double)f < T)  // step one float up
+    f = f > 0.0f ? __uint_as_float(__float_as_uint(f) + 1u)
+                 : (f < 0.0f ? __uint_as_float(__float_as_uint(f) - 1u) : __uint_as_float(0x00000001u));
+  return f;
+}
+
+// Screening pass of checkForStep entirely on the LDS tiles (cells outside the map are NaN there, which
+// fails every comparison exactly like being skipped).  The window of circle(2.5*res) and the 3x3
+// submaps around its candidates lie within 3 cells of the centre.  Returns true when no submap cell
+// satisfies the "lower step" condition of :825, in which case checkForStep passes without any of its
+// ray/line geometry; otherwise the full function decides.
+__device__ __forceinline__ bool check_step_screen(const Disc& d, const float* __restrict__ te,
+                                                  const float* __restrict__ tkey,
+                                                  const unsigned char* __restrict__ tlow, int ctr, double crit_step) {
+  if (d.n_ties) return false;
+  const float thr = ffloor_d(crit_step + (double)te[ctr]);
+  bool any_cand = false, hit = false;
+  if (d.Q == 5) {  // circle(2.5*res) is always this 21-cell shape (di^2+dj^2 <= 5): fully unrolled, immediate offsets
+#pragma unroll
+    for (int dj = -2; dj <= 2; ++dj) {
+#pragma unroll
+      for (int di = -2; di <= 2; ++di) {
+        if (di * di + dj * dj > 5) continue;
+        const int idx = ctr + dj * MTW + di;
+        const bool cand = tkey[idx] > thr;
+        any_cand |= cand;
+        hit |= cand && (tlow[idx] != 0);
+      }
+    }
+    if (!any_cand) hit = (tlow[ctr] != 0);
+    return !hit;
+  }
+  for (int dj = -d.R; dj <= d.R; ++dj) {
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) {
+      const int idx = ctr + dj * MTW + di;
+      const bool cand = tkey[idx] > thr;  // :807-809 higher than the centre by more than crit_step, step score 0
+      any_cand |= cand;
+      hit |= cand && (tlow[idx] != 0);
     }
   }
-  return true;
+  if (!any_cand) hit = (tlow[ctr] != 0);  // :811 no candidate: the centre cell itself
+  return !hit;
 }
 
 // checkForStep :794-865
-__device__ bool check_step(const Geo& g, const Disc& d, const float* __restrict__ elev, const float* __restrict__ step,
-                           int ci, int cj, double crit_step, double max_gap) {
+__device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, const TileView& step, int ci, int cj,
+                           double crit_step, double max_gap) {
   const double cx = cell_x(g, ci), cy = cell_y(g, cj);
-  double height = (double)elev[(size_t)cj * g.rows + ci];
-  int candi[32], candj[32];
+  double height = (double)elev.at(ci, cj);
+  int cand[32];
   int ncand = 0;
-  const int K = d.reach;
-  for (int a = ci - K; a <= ci + K; ++a) {
-    if (a < 0 || a >= g.rows) continue;
-    for (int b = cj - K; b <= cj + K; ++b) {
-      if (b < 0 || b >= g.cols) continue;
-      if (!in_disc(g, d, ci, cj, a - ci, b - cj)) continue;
-      const size_t o = (size_t)b * g.rows + a;
-      if ((double)elev[o] > crit_step + height && step[o] == 0.0f && ncand < 32) {  // :807-809
-        candi[ncand] = a;
-        candj[ncand] = b;
-        ++ncand;
-      }
-    }
-  }
-  if (ncand == 0) {  // :811
-    candi[0] = ci;
-    candj[0] = cj;
-    ncand = 1;
-  }
+  for_disc(g, d, ci, cj, [&](int a, int b) {
+    if ((double)elev.at(a, b) > crit_step + height && step.at(a, b) == 0.0f && ncand < 32)  // :807-809
+      cand[ncand++] = (a << 16) | b;
+  });
+  if (ncand == 0) cand[ncand++] = (ci << 16) | cj;  // :811
   for (int c = 0; c < ncand; ++c) {
-    const int ii = candi[c], ij = candj[c];
+    const int ii = cand[c] >> 16, ij = cand[c] & 0xffff;
     const double sl = 2.5 * g.res;                         // subMapLength :813
-    const double sx = cell_x(g, ii), sy = cell_y(g, ij);   // subMapPos
-    const double tcx = cx - sx, tcy = cy - sy;             // toCenter :816
-    // GridMap::getSubmap -> getSubmapInformation (grid_map_core)
-    const double tlx = bound_axis(sx + 0.5 * sl, g.len_x, g.pos_x), tly = bound_axis(sy + 0.5 * sl, g.len_y, g.pos_y);
-    int ti, tj, bi, bj;
-    if (!pos_to_index(g, tlx, tly, ti, tj)) return false;  // :818-822
-    const double brx = bound_axis(sx - 0.5 * sl, g.len_x, g.pos_x), bry = bound_axis(sy - 0.5 * sl, g.len_y, g.pos_y);
-    if (!pos_to_index(g, brx, bry, bi, bj)) return false;
-    const double tcornx = cell_x(g, ti) + 0.5 * g.res, tcorny = cell_y(g, tj) + 0.5 * g.res;
+    // GridMap::getSubmap -> getSubmapInformation (grid_map_core) for a 2.5*res square around a cell centre:
+    // the corners lie 1.25 cells from the centre, i.e. 0.25 cells inside the neighbouring cells (or are
+    // clamped into the border cell by boundPositionToRange), so the submap is exactly the 3x3 block
+    // clipped to the map and the lookup cannot fail (:818-822); rounding (1e-13 cells) cannot move a
+    // corner across a cell boundary a quarter cell away.
+    (void)sl;
+    const int ti = ii > 0 ? ii - 1 : 0, tj = ij > 0 ? ij - 1 : 0;
+    const int bi = ii < g.rows - 1 ? ii + 1 : g.rows - 1, bj = ij < g.cols - 1 ? ij + 1 : g.cols - 1;
     const int sr = bi - ti + 1, sc = bj - tj + 1;
-    const double slx = (double)sr * g.res, sly = (double)sc * g.res;
-    const double spx = tcornx - 0.5 * slx, spy = tcorny - 0.5 * sly;
-    height = (double)elev[(size_t)ij * g.rows + ii];  // :823
-    for (int lin = 0; lin < sr * sc; ++lin) {         // GridMapIterator over the submap: row index fastest
+    height = (double)elev.at(ii, ij);  // :823
+    const double lowest = height - crit_step;
+    for (int lin = 0; lin < sr * sc; ++lin) {  // GridMapIterator over the submap: row index fastest
       const int a = lin % sr, b = lin / sr;
-      const size_t o = (size_t)(tj + b) * g.rows + (ti + a);
-      if (step[o] == 0.0f && (double)elev[o] < height - crit_step) {  // :825
-        const double px = (spx + (0.5 * slx - 0.5 * g.res)) + g.res * (double)(-a);
-        const double py = (spy + (0.5 * sly - 0.5 * g.res)) + g.res * (double)(-b);
-        const double vx = px - sx, vy = py - sy;
-        if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
-        if (sqrt(tcx * tcx + tcy * tcy) > 0.025) {      // :830-832
-          if (tcx * vx + tcy * vy < 0.0) continue;
-        }
-        double qx = sx + vx, qy = sy + vy;
-        for (int guard = 0; guard < 100000; ++guard) {  // :834
-          const double ex = (qx - sx) + vx, ey = (qy - sy) + vy;
-          if (!(sqrt(ex * ex + ey * ey) < max_gap && pos_inside(g, qx + vx, qy + vy))) break;
-          qx += vx;
-          qy += vy;
-        }
-        int ei, ej;
-        pos_to_index(g, qx, qy, ei, ej);
-        ei = ei < 0 ? 0 : (ei > g.rows - 1 ? g.rows - 1 : ei);
-        ej = ej < 0 ? 0 : (ej > g.cols - 1 ? g.cols - 1 : ej);
-        // LineIterator (Bresenham, grid_map_core) from `index` to `endIndex` :839-852
-        const int dx = ei > ii ? ei - ii : ii - ei, dy = ej > ij ? ej - ij : ij - ej;
-        int inc1i = (ei >= ii) ? 1 : -1, inc2i = inc1i, inc1j = (ej >= ij) ? 1 : -1, inc2j = inc1j;
-        int den, num, numadd, ncells;
-        if (dx >= dy) {
-          inc1i = 0; inc2j = 0; den = dx; num = dx / 2; numadd = dy; ncells = dx + 1;
-        } else {
-          inc2i = 0; inc1j = 0; den = dy; num = dy / 2; numadd = dx; ncells = dy + 1;
-        }
-        int li = ii, lj = ij;
-        bool gap_start = false, gap_end = false;
-        for (int icell = 0; icell < ncells; ++icell) {
-          const float ef = elev[(size_t)lj * g.rows + li];
-          if ((double)ef > height + crit_step) return false;  // :840-843
-          if ((double)ef < height - crit_step || !__builtin_isfinite(ef)) {
-            gap_start = true;
-          } else if (gap_start) {
-            gap_end = true;
-            break;
-          }
-          num += numadd;
-          if (num >= den) {
-            num -= den;
-            li += inc1i;
-            lj += inc1j;
-          }
-          li += inc2i;
-          lj += inc2j;
-        }
-        if (gap_start && !gap_end) return false;  // :853-856
+      if (!(step.at(ti + a, tj + b) == 0.0f && (double)elev.at(ti + a, tj + b) < lowest)) continue;  // :825
+      // the submap's own geometry (length re-derived by setGeometry), only needed for the rare hits
+      const double sx = cell_x(g, ii), sy = cell_y(g, ij);   // subMapPos
+      const double tcx = cx - sx, tcy = cy - sy;             // toCenter :816
+      const double tcornx = cell_x(g, ti) + 0.5 * g.res, tcorny = cell_y(g, tj) + 0.5 * g.res;
+      const double slx = (double)sr * g.res, sly = (double)sc * g.res;
+      const double spx = tcornx - 0.5 * slx, spy = tcorny - 0.5 * sly;
+      const double px = (spx + (0.5 * slx - 0.5 * g.res)) + g.res * (double)(-a);
+      const double py = (spy + (0.5 * sly - 0.5 * g.res)) + g.res * (double)(-b);
+      const double vx = px - sx, vy = py - sy;
+      if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
+      if (sqrt(tcx * tcx + tcy * tcy) > 0.025) {      // :830-832
+        if (tcx * vx + tcy * vy < 0.0) continue;
       }
+      double qx = sx + vx, qy = sy + vy;
+      for (int guard = 0; guard < 100000; ++guard) {  // :834
+        const double ex = (qx - sx) + vx, ey = (qy - sy) + vy;
+        if (!(sqrt(ex * ex + ey * ey) < max_gap && pos_inside(g, qx + vx, qy + vy))) break;
+        qx += vx;
+        qy += vy;
+      }
+      int ei, ej;
+      pos_to_index(g, qx, qy, ei, ej);
+      ei = ei < 0 ? 0 : (ei > g.rows - 1 ? g.rows - 1 : ei);
+      ej = ej < 0 ? 0 : (ej > g.cols - 1 ? g.cols - 1 : ej);
+      // LineIterator (Bresenham, grid_map_core) from `index` to `endIndex` :839-852
+      const int dx = ei > ii ? ei - ii : ii - ei, dy = ej > ij ? ej - ij : ij - ej;
+      int inc1i = (ei >= ii) ? 1 : -1, inc2i = inc1i, inc1j = (ej >= ij) ? 1 : -1, inc2j = inc1j;
+      int den, num, numadd, ncells;
+      if (dx >= dy) {
+        inc1i = 0; inc2j = 0; den = dx; num = dx / 2; numadd = dy; ncells = dx + 1;
+      } else {
+        inc2i = 0; inc1j = 0; den = dy; num = dy / 2; numadd = dx; ncells = dy + 1;
+      }
+      int li = ii, lj = ij;
+      bool gap_start = false, gap_end = false;
+      for (int icell = 0; icell < ncells; ++icell) {
+        const float ef = elev.at(li, lj);
+        if ((double)ef > height + crit_step) return false;  // :840-843
+        if ((double)ef < lowest || !__builtin_isfinite(ef)) {
+          gap_start = true;
+        } else if (gap_start) {
+          gap_end = true;
+          break;
+        }
+        num += numadd;
+        if (num >= den) {
+          num -= den;
+          li += inc1i;
+          lj += inc1j;
+        }
+        li += inc2i;
+        lj += inc2j;
+      }
+      if (gap_start && !gap_end) return false;  // :853-856
     }
   }
   return true;
@@ -188,36 +260,78 @@ struct MaskArgs {
   double crit_step, max_gap;
 };
 
-// isTraversableForFilters :774-792 for every cell
-__global__ __launch_bounds__(256) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
-                                                 const float* __restrict__ slope, const float* __restrict__ step,
-                                                 const float* __restrict__ rough, uint8_t* __restrict__ untrav,
-                                                 float* __restrict__ slope_fp, float* __restrict__ step_fp,
-                                                 float* __restrict__ rough_fp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i >= g.rows) return;
+// isTraversableForFilters :774-792 for every cell of a 64x16 tile
+__global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
+                                                     const float* __restrict__ slope, const float* __restrict__ step,
+                                                     const float* __restrict__ rough, uint8_t* __restrict__ untrav,
+                                                     float* __restrict__ slope_fp, float* __restrict__ step_fp,
+                                                     float* __restrict__ rough_fp) {
+  // t_elev = elevation; t_key = elevation where the step score is 0 (NaN elsewhere; NaN outside the map);
+  // t_low[n] = "some cell of the 3x3 block around n has step 0 and lies more than crit_step below n"
+  // (the hit condition of :825, a property of n alone).  Slope / roughness scores are only needed at the
+  // centre cell (plus, for the rare zero scores, their window): they are read straight from global memory.
+  __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH];
+  __shared__ unsigned char t_low[MTW * MTH];
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
-  const size_t o = mo + (size_t)j * g.rows + i;
-  float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
-  bool ok = true;
-  if (slope[o] == 0.0f) {  // checkForSlope
-    ok = count_zero_ok(g, a.slope_disc, slope + mo, i, j, a.ncrit_slope);
-    m_slope = ok ? 1.0f : 0.0f;
+  const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
+  for (int tj = threadIdx.y; tj < MTH; tj += MBY) {
+    const int b = j0 - MH + tj;
+    for (int ti = threadIdx.x; ti < MTW; ti += MX) {
+      const int aa = i0 - MH + ti;
+      float e = qnanf(), k = qnanf();
+      if (aa >= 0 && aa < g.rows && b >= 0 && b < g.cols) {
+        const size_t o = mo + (size_t)b * g.rows + aa;
+        e = elev[o];
+        k = (step[o] == 0.0f) ? e : qnanf();
+      }
+      t_elev[tj * MTW + ti] = e;
+      t_key[tj * MTW + ti] = k;
+    }
   }
-  if (ok && step[o] == 0.0f) {  // checkForStep
-    ok = check_step(g, a.step_disc, elev + mo, step + mo, i, j, a.crit_step, a.max_gap);
-    m_step = ok ? 1.0f : 0.0f;
+  __syncthreads();
+  for (int idx = threadIdx.y * MX + threadIdx.x; idx < MTW * MTH; idx += MX * MBY) {
+    const int lb = idx / MTW, la = idx - lb * MTW;
+    bool hit = false;
+    if (la >= 1 && la < MTW - 1 && lb >= 1 && lb < MTH - 1) {
+      const float lo = fceil_d((double)t_elev[idx] - a.crit_step);
+#pragma unroll
+      for (int b = -1; b <= 1; ++b)
+#pragma unroll
+        for (int aa = -1; aa <= 1; ++aa) hit |= t_key[idx + b * MTW + aa] < lo;
+    }
+    t_low[idx] = hit ? 1 : 0;
   }
-  if (ok && a.check_rough && rough[o] == 0.0f) {  // checkForRoughness
-    ok = count_zero_ok(g, a.slope_disc, rough + mo, i, j, a.ncrit_rough);
-    m_rough = ok ? 1.0f : 0.0f;
-  }
-  untrav[o] = ok ? 0 : 1;
-  if (a.write_memo) {
-    slope_fp[o] = m_slope;
-    step_fp[o] = m_step;
-    rough_fp[o] = m_rough;
+  __syncthreads();
+  const TileView ve = {t_elev, elev + mo, i0, j0, g.rows}, vs = {nullptr, step + mo, i0, j0, g.rows},
+                 vl = {nullptr, slope + mo, i0, j0, g.rows}, vr = {nullptr, rough + mo, i0, j0, g.rows};
+  const int i = i0 + threadIdx.x;
+  if (i >= g.rows) return;
+  for (int c = 0; c < MY / MBY; ++c) {
+    const int j = j0 + threadIdx.y + c * MBY;
+    if (j >= g.cols) break;
+    const size_t o = mo + (size_t)j * g.rows + i;
+    float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
+    bool ok = true;
+    const int ctr = (threadIdx.y + c * MBY + MH) * MTW + (threadIdx.x + MH);
+    if (slope[o] == 0.0f) {  // checkForSlope
+      ok = count_zero_ok(g, a.slope_disc, vl, i, j, a.ncrit_slope);
+      m_slope = ok ? 1.0f : 0.0f;
+    }
+    if (ok && step[o] == 0.0f) {  // checkForStep
+      ok = check_step_screen(a.step_disc, t_elev, t_key, t_low, ctr, a.crit_step) ||
+           check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap);
+      m_step = ok ? 1.0f : 0.0f;
+    }
+    if (ok && a.check_rough && rough[o] == 0.0f) {  // checkForRoughness
+      ok = count_zero_ok(g, a.slope_disc, vr, i, j, a.ncrit_rough);
+      m_rough = ok ? 1.0f : 0.0f;
+    }
+    untrav[o] = ok ? 0 : 1;
+    if (a.write_memo) {
+      slope_fp[o] = m_slope;
+      step_fp[o] = m_step;
+      rough_fp[o] = m_rough;
+    }
   }
 }
 
@@ -369,8 +483,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.write_memo = write_memo ? 1 : 0;
   m.crit_step = p.crit_step;
   m.max_gap = p.max_gap;
-  hipLaunchKernelGGL(k_fp_mask, dim3((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch), dim3(256),
-                     0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp);
+  hipLaunchKernelGGL(k_fp_mask, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + MY - 1) / MY), (unsigned)g.batch),
+                     dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp);
   SpiralArgs a;
   const Disc& d = p.fp_disc;
   for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = (k <= d.R) ? d.hw[k] : -1;
