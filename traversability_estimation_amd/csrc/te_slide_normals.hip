@@ -90,6 +90,24 @@ __device__ __forceinline__ double acos_poly(double x) {
   return x < 0.0 ? 3.141592653589793 - r : r;
 }
 
+// float32 acos on [-1, 1]: same reduction, degree-5 fit (5e-10) + float rounding; 1 - |x| is exact for
+// |x| >= 1/2, so the result keeps its RELATIVE accuracy for near-flat cells (acos -> 0).
+__device__ __forceinline__ float acosf_poly(float x) {
+  const float ax = fabsf(x);
+  const bool big = ax > 0.5f;
+  const float u = big ? 0.5f * (1.0f - ax) : ax * ax;
+  const float y = big ? __builtin_amdgcn_sqrtf(u) : ax;
+  float p = 3.369084721e-02f;
+  p = fmaf(p, u, 1.714923835e-02f);
+  p = fmaf(p, u, 3.110066274e-02f);
+  p = fmaf(p, u, 4.459940153e-02f);
+  p = fmaf(p, u, 7.500094543e-02f);
+  p = fmaf(p, u, 1.666666634e-01f);
+  const float as = fmaf(y * u, p, y);
+  const float r = big ? 2.0f * as : 1.57079637f - as;
+  return x < 0.0f ? 3.14159274f - r : r;
+}
+
 // General tail for a disc clipped by the map border (or any validity pattern whose x/y moments are
 // known): population covariance from the moments, smallest eigenpair of the 3x3 via a Jacobi
 // rotation of the x/y block and a safeguarded Newton iteration on the secular equation of the
@@ -187,63 +205,70 @@ constexpr int ring_rows(int R) {
   return n;
 }
 
-template <int R>
-__global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
-                                                          const float* __restrict__ step, float* __restrict__ slope,
-                                                          float* __restrict__ rough, float* __restrict__ trav,
-                                                          float* __restrict__ onx, float* __restrict__ ony,
-                                                          float* __restrict__ onz, int* __restrict__ tile_flags,
-                                                          Region rg) {
+// One strip of one rectangle.  BORDER selects the variant that also handles discs clipped by the map
+// border (slower, branchy).  In the interior variant the per-row work -- closed-form tail of row j,
+// staging of row j+1+R, slide to row j+1 -- is ONE straight-line block (loads use clamped addresses,
+// LDS writes are unconditional), so the latency-bound tail overlaps with the issue-bound slide; the
+// predicated global stores of row j come last.
+template <int R, bool BORDER>
+__device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, const SlideArgs& a, int k,
+                                      const float* __restrict__ elev, const float* __restrict__ step,
+                                      float* __restrict__ slope, float* __restrict__ rough, float* __restrict__ trav,
+                                      float* __restrict__ onx, float* __restrict__ ony, float* __restrict__ onz,
+                                      int* __restrict__ tile_flags, const Region& rg) {
   constexpr int W = kLanes + 2 * R;
   constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R are live while the disc moves from j to j+1
   constexpr int NX = (W + kLanes - 1) / kLanes;
-  __shared__ double ring[NR * W];
+  constexpr int kAhead = 4;      // rows (and step values) are fetched kAhead steps before they are needed
   const int lane = threadIdx.x;
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  int k = 0;  // which rectangle this block works on (uniform)
-#pragma unroll
-  for (int t = 1; t < 5; ++t)
-    if (t < a.nsub && (int)blockIdx.x >= a.sub[t].first) k = t;
   const int lb = (int)blockIdx.x - a.sub[k].first;
   const int sub_i1 = a.sub[k].i1, sub_j1 = a.sub[k].j1, out_rows = a.sub[k].out_rows;
-  const bool BORDER = a.sub[k].border != 0;
   const int i0 = a.sub[k].i0 + (lb % a.sub[k].nbx) * kLanes;
   const int js = a.sub[k].j0 + (lb / a.sub[k].nbx) * out_rows;
   const int jend = (js + out_rows < sub_j1) ? js + out_rows : sub_j1;
   const int i = i0 + lane;
+  const int ic = i < g.rows ? i : g.rows - 1;
   const float* __restrict__ em = elev + mo;
   // clip of my disc by the left/right map border (0: none; k>0: columns di < -R+k missing; k<0: di > R+k missing)
-  const int kx = (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
+  // (lanes beyond the map edge compute garbage that is never stored: keep their table index in range)
+  const int kx = (i >= g.rows) ? 0 : (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
   const int c = lane + R;  // my column inside a staged row
 
-  // ---- stage one row into the ring; returns whether it contains an invalid in-map cell ----------
-  int dirty_until = js - R - 1;  // outputs j <= dirty_until may see an invalid / out-of-map cell
+  int dirty_until = js - R - 1;  // outputs j <= dirty_until may see an invalid cell
   double zref = 0.0;
+  // global loads use clamped (always valid) addresses; whether the cell exists is decided when it is staged
   auto load_row = [&](int r, float (&pf)[NX]) {
+    const int rc = r < 0 ? 0 : (r >= g.cols ? g.cols - 1 : r);
+    const float* __restrict__ src = em + (size_t)rc * g.rows;
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
-      const int cc = lane + x * kLanes;
-      const int ci = i0 - R + cc;
-      float t = 0.0f;  // cells outside the map contribute nothing to the z-sums (their x/y moments: gtab)
-      if (cc < W && ci >= 0 && ci < g.rows && r >= 0 && r < g.cols) t = em[(size_t)r * g.rows + ci];
-      pf[x] = t;
+      int ci = i0 - R + lane + x * kLanes;
+      ci = ci < 0 ? 0 : (ci >= g.rows ? g.rows - 1 : ci);
+      pf[x] = src[ci];
     }
   };
   auto store_row = [&](int r, int slot, const float (&pf)[NX]) {
+    const bool rin = r >= 0 && r < g.cols;
     bool bad = false;
     double* dst = ring + slot * W;
+    double v0 = 0.0;
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
       const int cc = lane + x * kLanes;
       const int ci = i0 - R + cc;
-      const bool inmap = cc < W && ci >= 0 && ci < g.rows && r >= 0 && r < g.cols;
+      const bool inmap = rin && cc < W && ci >= 0 && ci < g.rows;
       const float t = pf[x];
       const bool ok = inmap && __builtin_isfinite(t);
       bad |= inmap && !ok;
-      if (cc < W) dst[cc] = ok ? (double)t - zref : 0.0;  // invalid / outside the map: contributes nothing
+      const double v = ok ? (double)t - zref : 0.0;  // invalid / outside the map: contributes nothing to the z-sums
+      if (x == 0) v0 = v;
+      // lanes beyond the end of the row repeat their first write (same address, same value): no predication
+      dst[cc < W ? cc : lane] = cc < W ? v : v0;
     }
-    if (__any(bad)) dirty_until = r + R > dirty_until ? r + R : dirty_until;
+    const int cand = __any(bad) ? r + R : dirty_until;
+    dirty_until = cand > dirty_until ? cand : dirty_until;
   };
 
   // ---- prologue: empty ring, reference height -------------------------------------------------------
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
   {
     float pf0[NX];
     bool found = false;
-    for (int r = js - R; r <= js + R && !found; ++r) {  // uniform loop; normally one iteration
+    for (int r = (js - R < 0 ? 0 : js - R); r <= js + R && r < g.cols && !found; ++r) {  // uniform; normally one pass
       load_row(r, pf0);
 #pragma unroll
       for (int x = 0; x < NX; ++x) {
@@ -273,111 +298,35 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
   const double inv_np = 1.0 / (double)a.np;
   const double cxx = g.res * g.res * ((double)a.sii * inv_np);
   const double nm1 = (double)a.np / (double)(a.np > 1 ? a.np - 1 : 1);
+  const float slope_critf = (float)a.slope_crit, inv_slope_critf = (float)a.inv_slope_crit;
+  const float rough_critf = (float)a.rough_crit, inv_rough_critf = (float)a.inv_rough_crit;
   // fix-up flags: one per 64x16 tile of the whole region the chain runs on (origin a.fi0, a.fj0)
   int* const flag_col = tile_flags + (size_t)(rg.map >= 0 ? 0 : blockIdx.z) * a.ntx * a.nty + ((i0 - a.fi0) >> 6);
 
-  // rows (and the step values of the combine) are fetched kAhead steps before they are needed
-  constexpr int kAhead = 4;
   float pfq[kAhead][NX];
   float stq[kAhead];
   auto load_step = [&](int jj) -> float {
-    float v = 0.0f;
-    if (a.combine && jj >= js && jj < jend && i < sub_i1) v = step[mo + (size_t)jj * g.rows + i];
-    return v;
+    const int jc = jj < 0 ? 0 : (jj >= g.cols ? g.cols - 1 : jj);
+    return step[mo + (size_t)jc * g.rows + ic];
   };
 #pragma unroll
   for (int d = 0; d < kAhead; ++d) {
     load_row(jstart + 1 + R + d, pfq[d]);
     stq[d] = load_step(jstart + d);
   }
-
-#pragma unroll 1
-  for (int j0 = jstart; j0 < jend; j0 += kAhead) {
+  // bring in row j+1+R, fetch the row kAhead further down, slide the disc from row j to row j+1
+  auto advance = [&](int j) {
+    int sr = slot_j + 1 + R;
+    sr = sr >= NR ? sr - NR : sr;
+    store_row(j + 1 + R, sr, pfq[0]);
 #pragma unroll
-  for (int d = 0; d < kAhead; ++d) {
-    const int j = j0 + d;
-    if (j >= jend) break;
-    float (&pf)[NX] = pfq[d];
-    // ---- emit row j ---------------------------------------------------------------------------
-    bool need_fixup = false;
-    if (j >= js && i < sub_i1) {
-      const size_t o = mo + (size_t)j * g.rows + i;
-      const float stepv = stq[d];
-      float nx = qnanf(), ny = qnanf(), nz = qnanf(), o_slope = qnanf(), o_rough = qnanf();
-      bool done = false;
-      double qrough = 0.0;
-      const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
-      if (!BORDER && (kx != 0 || ky != 0)) {
-        // not launched on border cells (see normals_fast); if it ever happens the fix-up pass takes the cell
-      } else if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
-        // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
-        // the x/y moments of the clipped disc come from the host-built table
-        const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
-        done = border_tail(g.res, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, nx, ny, nz, qrough);
-        if (done) {
-          const double sl = acos_poly((double)nz);
-          o_slope = sl < a.slope_crit ? (float)(1.0 - sl * a.inv_slope_crit) : 0.0f;
-          const int n = gt[0];
-          const double rgh = n > 1 ? sqrt_nr(qrough * ((double)n / (double)(n - 1))) : 1e300;
-          o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh * a.inv_rough_crit) : 0.0f;
-        }
-      } else if (j > dirty_until) {
-        const double mz = Sz * inv_np;
-        const double ca = -g.res * Siz * inv_np;  // cov(x,z), x = -res*di
-        const double cb = -g.res * Sjz * inv_np;  // cov(y,z)
-        const double cd = fma(Szz, inv_np, -mz * mz);
-        const double delta = 0.5 * (cxx - cd);
-        const double h2 = fma(ca, ca, cb * cb);
-        const double s = sqrt_nr(fma(delta, delta, h2));
-        const double t = delta >= 0.0 ? delta + s : h2 * rcp_nr(s - delta);
-        if (t > 0.0 && t < 1e300) {
-          if (cxx > 1e-8) {  // eigenvalues(1) == cxx here (NormalVectorsFilter's "> 1e-8" test)
-            const double inv = rsqrt_nr(fma(t, t, h2));
-            nx = (float)(-ca * inv);
-            ny = (float)(-cb * inv);
-            nz = (float)(t * inv);
-          } else {
-            nx = 0.0f;
-            ny = 0.0f;
-            nz = 1.0f;
-          }
-          const double sl = acos_poly((double)nz);  // SlopeFilter.cpp:74
-          o_slope = sl < a.slope_crit ? (float)(1.0 - sl * a.inv_slope_crit) : 0.0f;
-          // n^T C n with the float32 normal, C = [[c,0,a],[0,c,b],[a,b,d]]  (RoughnessFilter.cpp:105-117)
-          const double x = (double)nx, y = (double)ny, z = (double)nz;
-          double q = fma(cxx, fma(x, x, y * y), fma(2.0 * z, fma(ca, x, cb * y), cd * z * z));
-          q = q > 0.0 ? q : 0.0;
-          const double rgh = sqrt_nr(q * nm1);
-          o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh * a.inv_rough_crit) : 0.0f;
-          done = true;
-        }
-      }
-      need_fixup = !done;
-      slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
-      rough[o] = o_rough;
-      if (a.combine) {
-        const float ta = a.w_slope * o_slope, tb = a.w_step * stepv, tc = a.w_rough * o_rough;
-        const float tab = ta + tb;
-        const float tabc = tab + tc;
-        trav[o] = a.w_scale * tabc;
-      }
-      if (onx) {
-        onx[o] = nx;
-        ony[o] = ny;
-        onz[o] = nz;
-      }
+    for (int d = 0; d + 1 < kAhead; ++d) {
+#pragma unroll
+      for (int x = 0; x < NX; ++x) pfq[d][x] = pfq[d + 1][x];
+      stq[d] = stq[d + 1];
     }
-    if (__any(need_fixup) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
-    if (j + 1 >= jend) break;
-    // ---- bring in row j+1+R, start the load of the one after ------------------------------------
-    {
-      int sl = slot_j + 1 + R;
-      sl = sl >= NR ? sl - NR : sl;
-      store_row(j + 1 + R, sl, pf);
-    }
-    load_row(j + 1 + R + kAhead, pf);
-    stq[d] = load_step(j + kAhead);
-    // ---- slide the disc from row j to row j+1 ---------------------------------------------------
+    load_row(j + 1 + R + kAhead, pfq[kAhead - 1]);
+    stq[kAhead - 1] = load_step(j + kAhead);
     double sj = 0.0;
 #pragma unroll
     for (int di = -R; di <= R; ++di) {
@@ -395,8 +344,105 @@ __global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, co
     }
     Sjz = (Sjz + sj) - Sz;
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
+  };
+
+#pragma unroll 1
+  for (int j = jstart; j < js; ++j) advance(j);  // warm-up: fill the disc
+
+#pragma unroll 1
+  for (int j = js; j < jend; ++j) {
+    // ---- tail of row j (values stay in registers until the stores below) --------------------------
+    float nx = qnanf(), ny = qnanf(), nz = qnanf(), o_slope = qnanf(), o_rough = qnanf();
+    bool done = false;
+    const float stepv = stq[0];
+    const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
+    if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
+      // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
+      // the x/y moments of the clipped disc come from the host-built table
+      double qrough = 0.0;
+      const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+      done = border_tail(g.res, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, nx, ny, nz, qrough);
+      if (done) {
+        const double sl = acos_poly((double)nz);
+        o_slope = sl < a.slope_crit ? (float)(1.0 - sl * a.inv_slope_crit) : 0.0f;
+        const int n = gt[0];
+        const double rgh = n > 1 ? sqrt_nr(qrough * ((double)n / (double)(n - 1))) : 1e300;
+        o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh * a.inv_rough_crit) : 0.0f;
+      }
+    } else {
+      // straight-line closed-form tail; cells it cannot finish (dirty rows, degenerate t) are masked to NaN
+      const double mz = Sz * inv_np;
+      const double ca = -g.res * Siz * inv_np;  // cov(x,z), x = -res*di
+      const double cb = -g.res * Sjz * inv_np;  // cov(y,z)
+      const double cd = fma(Szz, inv_np, -mz * mz);
+      const double delta = 0.5 * (cxx - cd);
+      const double h2 = fma(ca, ca, cb * cb);
+      const double s = sqrt_nr(fma(delta, delta, h2));
+      // t = delta + s loses relative accuracy only when delta < 0 and h << |delta| (z-variance above the
+      // x/y variance and almost no tilt: normal nearly horizontal); those cells go to the general path
+      const double t = delta + s;
+      done = (j > dirty_until) && (t > 0.0) && (t < 1e300) && (delta >= 0.0 || t > 1e-6 * s) && (kx == 0) &&
+             (ky == 0);  // clipped discs belong to the BORDER launch
+      const bool eig_ok = cxx > 1e-8;  // eigenvalues(1) == cxx here (NormalVectorsFilter's "> 1e-8" test)
+      const double inv = rsqrt_nr(fma(t, t, h2));
+      const float fz = eig_ok ? (float)(t * inv) : 1.0f;
+      const float fx = eig_ok ? (float)(-ca * inv) : 0.0f;
+      const float fy = eig_ok ? (float)(-cb * inv) : 0.0f;
+      // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
+      const float sl = acosf_poly(fz);
+      const float ss = sl < slope_critf ? 1.0f - sl * inv_slope_critf : 0.0f;
+      // roughness^2 * (N-1)/N = n^T C n = smallest eigenvalue (RoughnessFilter.cpp:105-117); with the
+      // float32-rounded normal the quadratic form differs from lambda0 by O(c * 1e-15)
+      double q = eig_ok ? 0.5 * (cxx + cd) - s : cd;
+      q = q > 0.0 ? q : 0.0;
+      const float rgh = __builtin_amdgcn_sqrtf((float)(q * nm1));
+      const float rs = rgh < rough_critf ? 1.0f - rgh * inv_rough_critf : 0.0f;
+      nx = done ? fx : qnanf();
+      ny = done ? fy : qnanf();
+      nz = done ? fz : qnanf();
+      o_slope = done ? ss : qnanf();
+      o_rough = done ? rs : qnanf();
+    }
+    const float ta = a.w_slope * o_slope, tb = a.w_step * stepv, tc = a.w_rough * o_rough;
+    const float tab = ta + tb;
+    const float tabc = tab + tc;
+    const float o_trav = a.w_scale * tabc;
+
+    advance(j);  // (the last one of a strip is not needed, but keeps the loop body branch-free)
+
+    // ---- stores of row j ------------------------------------------------------------------------------
+    const bool emit = i < sub_i1;
+    if (emit) {
+      const size_t o = mo + (size_t)j * g.rows + i;
+      slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
+      rough[o] = o_rough;
+      if (a.combine) trav[o] = o_trav;
+      if (onx) {
+        onx[o] = nx;
+        ony[o] = ny;
+        onz[o] = nz;
+      }
+    }
+    if (__any(emit && !done) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
   }
-  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
+                                                          const float* __restrict__ step, float* __restrict__ slope,
+                                                          float* __restrict__ rough, float* __restrict__ trav,
+                                                          float* __restrict__ onx, float* __restrict__ ony,
+                                                          float* __restrict__ onz, int* __restrict__ tile_flags,
+                                                          Region rg) {
+  __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+  int k = 0;  // which rectangle this block works on (uniform)
+#pragma unroll
+  for (int t = 1; t < 5; ++t)
+    if (t < a.nsub && (int)blockIdx.x >= a.sub[t].first) k = t;
+  if (a.sub[k].border)
+    march<R, true>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
+  else
+    march<R, false>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
 }
 
 constexpr int kStripRows = 128;       // interior strips
@@ -420,13 +466,30 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
                           {r.i0, r.i1, r.j0, ja, 1},    // top
                           {r.i0, r.i1, jb, r.j1, 1},    // bottom
                           {il, ir, ja, jb, 0}};         // interior
+  // interior strip height: as many strips as fit in ONE round of resident waves (3 per SIMD at <=168
+  // VGPRs and 13 KB of LDS), so that no second, mostly idle, round is needed
+  int border_blocks = 0;
+  for (int t = 0; t < 4; ++t)
+    if (rect[t][1] > rect[t][0] && rect[t][3] > rect[t][2])
+      border_blocks += ((rect[t][1] - rect[t][0] + kLanes - 1) / kLanes) *
+                       ((rect[t][3] - rect[t][2] + kBorderStripRows - 1) / kBorderStripRows);
+  int interior_rows = kStripRows;
+  if (ir > il && jb > ja) {
+    const int maps = r.map >= 0 ? 1 : g.batch;
+    const int capacity = 3 * 4 * 256 / (maps > 0 ? maps : 1) - border_blocks;
+    const int nbx_in = (ir - il + kLanes - 1) / kLanes;
+    int strips = capacity / nbx_in;
+    strips = strips < 1 ? 1 : strips;
+    interior_rows = (jb - ja + strips - 1) / strips;
+    interior_rows = interior_rows < 48 ? 48 : (interior_rows > 512 ? 512 : interior_rows);
+  }
   int n = 0, first = 0;
   for (int t = 0; t < 5; ++t) {
     if (rect[t][1] <= rect[t][0] || rect[t][3] <= rect[t][2]) continue;
     SlideArgs::Sub& u = a.sub[n++];
     u.i0 = rect[t][0]; u.i1 = rect[t][1]; u.j0 = rect[t][2]; u.j1 = rect[t][3];
     u.border = rect[t][4];
-    u.out_rows = u.border ? kBorderStripRows : kStripRows;
+    u.out_rows = u.border ? kBorderStripRows : interior_rows;
     u.nbx = (u.i1 - u.i0 + kLanes - 1) / kLanes;
     u.first = first;
     first += u.nbx * ((u.j1 - u.j0 + u.out_rows - 1) / u.out_rows);
