@@ -347,6 +347,12 @@ struct SpiralArgs {
   int out_rows;
 };
 
+// Ring encoding: one double per cell, T' + kUOff * U with T' = traversability (NaN -> default) and
+// U = 1 for an untraversable cell.  T' is a float in (-kUOff/2, kUOff/2) (scores live in [0, 1]), so
+// both the per-cell value and the disc sum  sum(T') + kUOff * sum(U)  are exact in double and split
+// back exactly:  sum(U) = floor((S + kUOff/2) / kUOff).
+constexpr double kUOff = 4096.0;
+
 template <int R>
 __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const float* __restrict__ trav,
                                                      const uint8_t* __restrict__ untrav,
@@ -354,8 +360,8 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
   constexpr int W = kLanes + 2 * R;
   constexpr int NR = 2 * R + 2;
   constexpr int NX = (W + kLanes - 1) / kLanes;
-  __shared__ double tring[NR * W];  // traversability (NaN -> default), 0 outside the map
-  __shared__ int uring[NR * W];     // 1 = untraversable, 0 otherwise / outside the map
+  constexpr int kAhead = 4;
+  __shared__ double ring[NR * W];
   const int lane = threadIdx.x;
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
   const int i0 = blockIdx.x * kLanes;
@@ -363,110 +369,142 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
   const int jend = js + a.out_rows < g.cols ? js + a.out_rows : g.cols;
   const int i = i0 + lane;
   const int c = lane + R;
-  const int kx = (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
+  const int kx = (i >= g.rows) ? 0 : (i < R) ? (R - i) : ((g.rows - 1 - i < R) ? -(R - (g.rows - 1 - i)) : 0);
 
-  for (int idx = lane; idx < NR * W; idx += kLanes) {
-    tring[idx] = 0.0;
-    uring[idx] = 0;
-  }
+  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
   __syncthreads();
-  auto stage_row = [&](int r, int slot) {
+  // clamped (always valid) addresses; whether the cell exists is decided when it is staged
+  auto load_row = [&](int r, float (&pt)[NX], int (&pu)[NX]) {
+    const int rc = r < 0 ? 0 : (r >= g.cols ? g.cols - 1 : r);
+    const size_t base = mo + (size_t)rc * g.rows;
+#pragma unroll
+    for (int x = 0; x < NX; ++x) {
+      int ci = i0 - R + lane + x * kLanes;
+      ci = ci < 0 ? 0 : (ci >= g.rows ? g.rows - 1 : ci);
+      pt[x] = trav[base + ci];
+      pu[x] = untrav[base + ci];
+    }
+  };
+  auto store_row = [&](int r, int slot, const float (&pt)[NX], const int (&pu)[NX]) {
+    const bool rin = r >= 0 && r < g.cols;
+    double* dst = ring + slot * W;
+    double v0 = 0.0;
 #pragma unroll
     for (int x = 0; x < NX; ++x) {
       const int cc = lane + x * kLanes;
       const int ci = i0 - R + cc;
-      if (cc < W) {
-        double t = 0.0;
-        int u = 0;
-        if (ci >= 0 && ci < g.rows && r >= 0 && r < g.cols) {
-          const size_t o = mo + (size_t)r * g.rows + ci;
-          const float tv = trav[o];
-          t = __builtin_isfinite(tv) ? (double)tv : a.def;  // :719-724
-          u = untrav[o];
-        }
-        tring[slot * W + cc] = t;
-        uring[slot * W + cc] = u;
-      }
+      const bool inmap = rin && cc < W && ci >= 0 && ci < g.rows;
+      const double t = __builtin_isfinite(pt[x]) ? (double)pt[x] : a.def;  // :719-724
+      const double v = inmap ? t + (pu[x] ? kUOff : 0.0) : 0.0;             // cells outside the map: nothing
+      if (x == 0) v0 = v;
+      dst[cc < W ? cc : lane] = cc < W ? v : v0;
     }
   };
 
   double S = 0.0;
-  int U = 0;
   const int jstart = js - (2 * R + 1);
   int slot_j = 0;
+  int lead[R + 1], trail[R + 1];
+  bool inside[R + 1];
+#pragma unroll
+  for (int d = 0; d <= R; ++d) {
+    const int h = a.h[d] < 0 ? 0 : a.h[d];
+    inside[d] = a.h[d] >= 0;
+    lead[d] = ((1 + h) % NR) * W;
+    trail[d] = ((NR - h) % NR) * W;
+  }
+  float ptq[kAhead][NX];
+  int puq[kAhead][NX];
+#pragma unroll
+  for (int d = 0; d < kAhead; ++d) load_row(jstart + 1 + R + d, ptq[d], puq[d]);
+  auto advance = [&](int j) {
+    int sr = slot_j + 1 + R;
+    sr = sr >= NR ? sr - NR : sr;
+    store_row(j + 1 + R, sr, ptq[0], puq[0]);
+#pragma unroll
+    for (int d = 0; d + 1 < kAhead; ++d)
+#pragma unroll
+      for (int x = 0; x < NX; ++x) {
+        ptq[d][x] = ptq[d + 1][x];
+        puq[d][x] = puq[d + 1][x];
+      }
+    load_row(j + 1 + R + kAhead, ptq[kAhead - 1], puq[kAhead - 1]);
+    double acc = 0.0;
+#pragma unroll
+    for (int d = 0; d <= R; ++d) {
+      // columns +d and -d share their leading and trailing rows; a column outside the tie-free disc
+      // (h < 0: only tie offsets reach it) contributes nothing
+      const double* rl = ring + lead[d] + c;
+      const double* rt = ring + trail[d] + c;
+      double e = rl[d] - rt[d];
+      if (d != 0) e += rl[-d] - rt[-d];
+      acc += inside[d] ? e : 0.0;
+      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
+      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+    }
+    S += acc;  // all terms are exact, so is the order
+    slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
+  };
+
 #pragma unroll 1
-  for (int j = jstart; j < jend; ++j) {
-    if (j >= js && i < g.rows) {
-      const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);
-      // cells on the circle itself (tie radii): CircleIterator/SpiralIterator::isInside per cell
-      double St = S;
-      int Ut = U, nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
-      for (int t = 0; t < a.n_ties; ++t) {
-        const int di = a.tie_di[t], dj = a.tie_dj[t];
+  for (int j = jstart; j < js; ++j) advance(j);
+
+#pragma unroll 1
+  for (int j = js; j < jend; ++j) {
+    const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);
+    double St = S;
+    int nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
+    // cells on the circle itself (tie radii): SpiralIterator::isInside per cell
+    for (int t = 0; t < a.n_ties; ++t) {
+      const int di = a.tie_di[t], dj = a.tie_dj[t];
+      const int ii = i + di, jj = j + dj;
+      if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
+      const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+      if (dx * dx + dy * dy <= a.r2) {
+        int sl = slot_j + dj;
+        sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+        St += ring[sl * W + c + di];
+        nt += 1;
+      }
+    }
+    const int Ut = (int)floor((St + 0.5 * kUOff) * (1.0 / kUOff));
+    float out;
+    if (Ut == 0) {
+      out = (float)(St / (double)nt);  // :732-735 no untraversable cell in the footprint
+    } else {
+      // walk the spiral until the first untraversable cell :687-717
+      double t = 0.0;
+      int ncells = 0;
+      out = qnanf();
+      for (int kk = 0; kk < a.n_spiral; ++kk) {
+        const int di = a.table[4 * kk + 0], dj = a.table[4 * kk + 1];
         const int ii = i + di, jj = j + dj;
         if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
-        const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
-        if (dx * dx + dy * dy <= a.r2) {
-          int sl = slot_j + dj;
-          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
-          St += tring[sl * W + c + di];
-          Ut += uring[sl * W + c + di];
-          nt += 1;
+        if (a.table[4 * kk + 3]) {
+          const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+          if (!(dx * dx + dy * dy <= a.r2)) continue;
         }
-      }
-      float out;
-      if (Ut == 0) {
-        out = (float)(St / (double)nt);  // :732-735 no untraversable cell in the footprint
-      } else {
-        // walk the spiral until the first untraversable cell :687-717
-        double t = 0.0;
-        int ncells = 0;
-        out = qnanf();
-        for (int k = 0; k < a.n_spiral; ++k) {
-          const int di = a.table[4 * k + 0], dj = a.table[4 * k + 1];
-          const int ii = i + di, jj = j + dj;
-          if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
-          if (a.table[4 * k + 3]) {
-            const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
-            if (!(dx * dx + dy * dy <= a.r2)) continue;
+        int sl = slot_j + dj;
+        sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+        const double v = ring[sl * W + c + di];
+        if (v >= 0.5 * kUOff) {
+          const double ru = (double)a.table[4 * kk + 2] * g.res;  // getCurrentRadius()
+          if (a.rmin == 0.0 || ru <= a.rmin) {
+            out = 0.0f;  // :694-704
+          } else {
+            const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+            t *= factor / ncells;
+            out = (float)t;
           }
-          int sl = slot_j + dj;
-          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
-          if (uring[sl * W + c + di]) {
-            const double ru = (double)a.table[4 * k + 2] * g.res;  // getCurrentRadius()
-            if (a.rmin == 0.0 || ru <= a.rmin) {
-              out = 0.0f;  // :694-704
-            } else {
-              const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
-              t *= factor / ncells;
-              out = (float)t;
-            }
-            break;
-          }
-          ncells++;
-          t += tring[sl * W + c + di];
+          break;
         }
-        if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
+        ncells++;
+        t += v;
       }
-      footprint[mo + (size_t)j * g.rows + i] = out;
+      if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
     }
-    if (j + 1 >= jend) break;
-    {
-      int sl = slot_j + 1 + R;
-      sl = sl >= NR ? sl - NR : sl;
-      stage_row(j + 1 + R, sl);
-    }
-#pragma unroll
-    for (int di = -R; di <= R; ++di) {
-      const int h = a.h[di < 0 ? -di : di];
-      if (h < 0) continue;  // column not in the tie-free disc (only the tie offsets reach it)
-      int sl = slot_j + 1 + h, st = slot_j - h;
-      sl = sl >= NR ? sl - NR : sl;
-      st = st < 0 ? st + NR : st;
-      S += tring[sl * W + c + di] - tring[st * W + c + di];
-      U += uring[sl * W + c + di] - uring[st * W + c + di];
-    }
-    slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
+    advance(j);
+    if (i < g.rows) footprint[mo + (size_t)j * g.rows + i] = out;
   }
 }
 
@@ -500,7 +538,13 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.rmin = p.rmin;
   a.rmax = p.rmax;
   a.def = p.def;
-  a.out_rows = 128;
+  {  // one round of resident waves (<= 3 per SIMD): as many strips as fit
+    const int nbx = (g.rows + kLanes - 1) / kLanes;
+    int strips = (3 * 4 * 256) / (nbx * (g.batch > 0 ? g.batch : 1));
+    strips = strips < 1 ? 1 : strips;
+    int rows_per = (g.cols + strips - 1) / strips;
+    a.out_rows = rows_per < 48 ? 48 : (rows_per > 512 ? 512 : rows_per);
+  }
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
                   (unsigned)g.batch);
   switch (p.reach) {

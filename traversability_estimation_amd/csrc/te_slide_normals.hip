@@ -303,6 +303,16 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   // fix-up flags: one per 64x16 tile of the whole region the chain runs on (origin a.fi0, a.fj0)
   int* const flag_col = tile_flags + (size_t)(rg.map >= 0 ? 0 : blockIdx.z) * a.ntx * a.nty + ((i0 - a.fi0) >> 6);
 
+  // ring offsets (in doubles) of the leading / trailing row of disc column |di| = d, advanced every step
+  int lead[R + 1], trail[R + 1];
+  double hd[R + 1];
+#pragma unroll
+  for (int d = 0; d <= R; ++d) {
+    const int h = a.h[d];
+    lead[d] = ((1 + h) % NR) * W;
+    trail[d] = ((NR - h) % NR) * W;
+    hd[d] = (double)h;
+  }
   float pfq[kAhead][NX];
   float stq[kAhead];
   auto load_step = [&](int jj) -> float {
@@ -329,18 +339,29 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     stq[kAhead - 1] = load_step(j + kAhead);
     double sj = 0.0;
 #pragma unroll
-    for (int di = -R; di <= R; ++di) {
-      const int h = a.h[di < 0 ? -di : di];
-      int sl = slot_j + 1 + h, st = slot_j - h;
-      sl = sl >= NR ? sl - NR : sl;
-      st = st < 0 ? st + NR : st;
-      const double zl = ring[sl * W + c + di];
-      const double zt = ring[st * W + c + di];
-      const double u = zl - zt, v = zl + zt;
-      Sz += u;
-      if (di != 0) Siz = fma((double)di, u, Siz);
-      Szz = fma(u, v, Szz);
-      sj += fma((double)h, v, zl);
+    for (int d = 0; d <= R; ++d) {
+      // columns +d and -d of the disc share their leading row (j+1+h) and trailing row (j-h)
+      const double* rl = ring + lead[d] + c;
+      const double* rt = ring + trail[d] + c;
+      const double hh = hd[d];
+      {
+        const double zl = rl[d], zt = rt[d];
+        const double u = zl - zt, v = zl + zt;
+        Sz += u;
+        if (d != 0) Siz = fma((double)d, u, Siz);
+        Szz = fma(u, v, Szz);
+        sj += fma(hh, v, zl);
+      }
+      if (d != 0) {
+        const double zl = rl[-d], zt = rt[-d];
+        const double u = zl - zt, v = zl + zt;
+        Sz += u;
+        Siz = fma(-(double)d, u, Siz);
+        Szz = fma(u, v, Szz);
+        sj += fma(hh, v, zl);
+      }
+      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
+      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
     }
     Sjz = (Sjz + sj) - Sz;
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
