@@ -274,18 +274,33 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __shared__ unsigned char t_low[MTW * MTH];
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
   const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
-  for (int tj = threadIdx.y; tj < MTH; tj += MBY) {
-    const int b = j0 - MH + tj;
-    for (int ti = threadIdx.x; ti < MTW; ti += MX) {
-      const int aa = i0 - MH + ti;
-      float e = qnanf(), k = qnanf();
-      if (aa >= 0 && aa < g.rows && b >= 0 && b < g.cols) {
-        const size_t o = mo + (size_t)b * g.rows + aa;
-        e = elev[o];
-        k = (step[o] == 0.0f) ? e : qnanf();
+  {
+    // all loads of the tile in flight at once (clamped addresses), then the LDS writes
+    constexpr int NT = MX * MBY, NL = (MTW * MTH + NT - 1) / NT;
+    const int tid = threadIdx.y * MX + threadIdx.x;
+    float le[NL], ls[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      int idx = tid + k * NT;
+      idx = idx < MTW * MTH ? idx : MTW * MTH - 1;
+      const int tj = idx / MTW, ti = idx - tj * MTW;
+      int aa = i0 - MH + ti, bb = j0 - MH + tj;
+      aa = aa < 0 ? 0 : (aa >= g.rows ? g.rows - 1 : aa);
+      bb = bb < 0 ? 0 : (bb >= g.cols ? g.cols - 1 : bb);
+      const size_t o = mo + (size_t)bb * g.rows + aa;
+      le[k] = elev[o];
+      ls[k] = step[o];
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = tid + k * NT;
+      const int tj = idx / MTW, ti = idx - tj * MTW;
+      const int aa = i0 - MH + ti, bb = j0 - MH + tj;
+      const bool in = aa >= 0 && aa < g.rows && bb >= 0 && bb < g.cols;
+      if (idx < MTW * MTH) {
+        t_elev[idx] = in ? le[k] : qnanf();
+        t_key[idx] = (in && ls[k] == 0.0f) ? le[k] : qnanf();
       }
-      t_elev[tj * MTW + ti] = e;
-      t_key[tj * MTW + ti] = k;
     }
   }
   __syncthreads();
@@ -306,23 +321,37 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
                  vl = {nullptr, slope + mo, i0, j0, g.rows}, vr = {nullptr, rough + mo, i0, j0, g.rows};
   const int i = i0 + threadIdx.x;
   if (i >= g.rows) return;
+  // the scores of my cells are fetched one cell ahead (clamped addresses)
+  auto fetch = [&](int c, float& fs, float& ft, float& fr) {
+    int j = j0 + threadIdx.y + c * MBY;
+    j = j < g.cols ? j : g.cols - 1;
+    const size_t o = mo + (size_t)j * g.rows + i;
+    fs = slope[o];
+    ft = step[o];
+    fr = a.check_rough ? rough[o] : 1.0f;
+  };
+  float n_slope, n_step, n_rough;
+  fetch(0, n_slope, n_step, n_rough);
+#pragma unroll 1
   for (int c = 0; c < MY / MBY; ++c) {
     const int j = j0 + threadIdx.y + c * MBY;
     if (j >= g.cols) break;
     const size_t o = mo + (size_t)j * g.rows + i;
+    const float c_slope = n_slope, c_step = n_step, c_rough = n_rough;
+    fetch(c + 1, n_slope, n_step, n_rough);
     float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
     bool ok = true;
     const int ctr = (threadIdx.y + c * MBY + MH) * MTW + (threadIdx.x + MH);
-    if (slope[o] == 0.0f) {  // checkForSlope
+    if (c_slope == 0.0f) {  // checkForSlope
       ok = count_zero_ok(g, a.slope_disc, vl, i, j, a.ncrit_slope);
       m_slope = ok ? 1.0f : 0.0f;
     }
-    if (ok && step[o] == 0.0f) {  // checkForStep
+    if (ok && c_step == 0.0f) {  // checkForStep
       ok = check_step_screen(a.step_disc, t_elev, t_key, t_low, ctr, a.crit_step) ||
            check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap);
       m_step = ok ? 1.0f : 0.0f;
     }
-    if (ok && a.check_rough && rough[o] == 0.0f) {  // checkForRoughness
+    if (ok && a.check_rough && c_rough == 0.0f) {  // checkForRoughness
       ok = count_zero_ok(g, a.slope_disc, vr, i, j, a.ncrit_rough);
       m_rough = ok ? 1.0f : 0.0f;
     }
