@@ -23,6 +23,7 @@ RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
 RUN_GENERIC_KERNELS = 0x4
 RUN_FOOTPRINT_MEMO = 0x8
+RUN_SEQUENTIAL = 0x10
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",

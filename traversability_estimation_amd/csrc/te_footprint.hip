@@ -258,6 +258,8 @@ struct MaskArgs {
   Disc step_disc;   // circle(2.5*res)
   int ncrit_slope, ncrit_rough, check_rough, write_memo;
   double crit_step, max_gap;
+  int combine;  // also write traversability = w_scale*((w_slope*slope + w_step*step) + w_rough*roughness) (float32)
+  float w_scale, w_slope, w_step, w_rough;
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64x16 tile
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
                                                      const float* __restrict__ slope, const float* __restrict__ step,
                                                      const float* __restrict__ rough, uint8_t* __restrict__ untrav,
                                                      float* __restrict__ slope_fp, float* __restrict__ step_fp,
-                                                     float* __restrict__ rough_fp) {
+                                                     float* __restrict__ rough_fp, float* __restrict__ trav) {
   // t_elev = elevation; t_key = elevation where the step score is 0 (NaN elsewhere; NaN outside the map);
   // t_low[n] = "some cell of the 3x3 block around n has step 0 and lies more than crit_step below n"
   // (the hit condition of :825, a property of n alone).  Slope / roughness scores are only needed at the
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     const size_t o = mo + (size_t)j * g.rows + i;
     fs = slope[o];
     ft = step[o];
-    fr = a.check_rough ? rough[o] : 1.0f;
+    fr = (a.check_rough || a.combine) ? rough[o] : 1.0f;
   };
   float n_slope, n_step, n_rough;
   fetch(0, n_slope, n_step, n_rough);
@@ -356,6 +358,12 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       m_rough = ok ? 1.0f : 0.0f;
     }
     untrav[o] = ok ? 0 : 1;
+    if (a.combine) {  // MathExpressionFilter, fixed form, float32, left to right
+      const float ta = a.w_slope * c_slope, tb = a.w_step * c_step, tc = a.w_rough * c_rough;
+      const float tab = ta + tb;
+      const float tabc = tab + tc;
+      trav[o] = a.w_scale * tabc;
+    }
     if (a.write_memo) {
       slope_fp[o] = m_slope;
       step_fp[o] = m_step;
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
 }  // namespace
 
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, hipStream_t stream) {
+                            const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream) {
   MaskArgs m;
   m.slope_disc = p.slope_disc;
   m.step_disc = p.step_disc;
@@ -550,8 +558,13 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.write_memo = write_memo ? 1 : 0;
   m.crit_step = p.crit_step;
   m.max_gap = p.max_gap;
+  m.combine = combine ? 1 : 0;
+  m.w_scale = combine ? combine->w_scale : 0.0f;
+  m.w_slope = combine ? combine->w_slope : 0.0f;
+  m.w_step = combine ? combine->w_step : 0.0f;
+  m.w_rough = combine ? combine->w_rough : 0.0f;
   hipLaunchKernelGGL(k_fp_mask, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + MY - 1) / MY), (unsigned)g.batch),
-                     dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp);
+                     dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
   SpiralArgs a;
   const Disc& d = p.fp_disc;
   for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = (k <= d.R) ? d.hw[k] : -1;

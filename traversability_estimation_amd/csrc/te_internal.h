@@ -44,6 +44,8 @@ struct ChainParams {
   float w_scale, w_slope, w_step, w_rough;
 };
 
+constexpr unsigned kDeferCombine = 0x8000u;  // internal launch_chain flag: the footprint mask kernel will write `traversability`
+
 struct Region {  // half-open cell rectangle of one map (or all maps when map < 0)
   int map, i0, j0, i1, j1;
 };
@@ -76,6 +78,9 @@ struct Layers {
   uint8_t* untrav;     // !isTraversableForFilters per cell
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
   int* clip_table;     // x/y moments of the normals disc clipped by the map border (build_clip_table)
+  // second stream + fork/join events: step filter || normals kernel on whole-map runs (nullptr: sequential)
+  hipStream_t aux_stream;
+  hipEvent_t ev_fork, ev_join;
 };
 
 struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
@@ -89,7 +94,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
                         hipStream_t stream);
 // spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, hipStream_t stream);
+                            const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
 
 // shape-specialised kernels (te_fast_*.hip); return false when the shape Q is not instantiated

@@ -35,7 +35,7 @@ struct Shape {
 };
 
 constexpr int kLanes = 64;
-constexpr int kStripTarget = 128;  // rows of output per strip (rounded so that the strip is whole periods)
+constexpr int kStripTarget = 128;  // rows of output per strip (rounded up to whole periods)
 
 template <int Q, int TARGET = kStripTarget>
 struct Strip {

@@ -109,6 +109,8 @@ struct te_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   te_params params;
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false;
   Geo geo;
@@ -120,6 +122,7 @@ struct te_ctx {
   int16_t* d_spiral = nullptr;
   int* clip_table = nullptr;
   int* fp_clip_table = nullptr;
+  bool combine_deferred = false;
   bool tables_ready = false;
 };
 
@@ -279,6 +282,12 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   }
   if (!c->have_elev) return fail(TE_ERR_NOT_READY, "te_run_chain: no elevation uploaded");
   HIP_TRY(hipSetDevice(c->device));
+  c->L.aux_stream = (flags & TE_RUN_SEQUENTIAL) ? nullptr : c->aux_stream;
+  // whole-map run with the footprint pass right behind: the mask kernel writes the combined layer
+  c->combine_deferred = (r.map < 0) && c->L.aux_stream && (flags & TE_RUN_FOOTPRINT);
+  if (c->combine_deferred) flags |= kDeferCombine;
+  c->L.ev_fork = c->ev_fork;
+  c->L.ev_join = c->ev_join;
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   return TE_OK;
@@ -289,7 +298,8 @@ int run_footprint_locked(te_ctx* c, unsigned flags) {
     return fail(TE_ERR_NOT_READY, "te_run_footprint: run the filter chain first (it produces the layers the footprint reads)");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
-                           c->stream));
+                           c->combine_deferred ? &c->cp : nullptr, c->stream));
+  c->combine_deferred = false;
   return TE_OK;
 }
 
@@ -393,6 +403,9 @@ int te_create(int device, te_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
     return fail(TE_ERR_HIP, "te_create: %s", hipGetErrorString(e));
@@ -413,6 +426,10 @@ int te_destroy(te_ctx* c) {
     if (c->fp_clip_table) (void)hipFree(c->fp_clip_table);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;

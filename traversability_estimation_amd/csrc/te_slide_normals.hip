@@ -250,7 +250,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     }
   };
   auto store_row = [&](int r, int slot, const float (&pf)[NX]) {
-    const bool rin = r >= 0 && r < g.cols;
+    const bool rin = r >= 0 && r < g.cols && r >= js - R;  // rows above the strip's first disc stay zero
     bool bad = false;
     double* dst = ring + slot * W;
     double v0 = 0.0;
@@ -292,7 +292,8 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   }
   __syncthreads();
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
-  const int jstart = js - (2 * R + 1);
+  constexpr int WU = ((2 * R + 1 + kAhead - 1) / kAhead) * kAhead;  // warm-up steps: whole groups of kAhead
+  const int jstart = js - WU;
   int slot_j = 0;  // ring slot of row j (slot(r) = (r - jstart) mod NR)
 
   const double inv_np = 1.0 / (double)a.np;
@@ -325,18 +326,13 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     stq[d] = load_step(jstart + d);
   }
   // bring in row j+1+R, fetch the row kAhead further down, slide the disc from row j to row j+1
-  auto advance = [&](int j) {
+  // (qs = j mod kAhead is a compile-time queue slot: the loops below are unrolled by kAhead)
+  auto advance = [&](int j, float (&pf)[NX], float& st) {
     int sr = slot_j + 1 + R;
     sr = sr >= NR ? sr - NR : sr;
-    store_row(j + 1 + R, sr, pfq[0]);
-#pragma unroll
-    for (int d = 0; d + 1 < kAhead; ++d) {
-#pragma unroll
-      for (int x = 0; x < NX; ++x) pfq[d][x] = pfq[d + 1][x];
-      stq[d] = stq[d + 1];
-    }
-    load_row(j + 1 + R + kAhead, pfq[kAhead - 1]);
-    stq[kAhead - 1] = load_step(j + kAhead);
+    store_row(j + 1 + R, sr, pf);
+    load_row(j + 1 + R + kAhead, pf);
+    st = load_step(j + kAhead);
     double sj = 0.0;
 #pragma unroll
     for (int d = 0; d <= R; ++d) {
@@ -368,14 +364,22 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   };
 
 #pragma unroll 1
-  for (int j = jstart; j < js; ++j) advance(j);  // warm-up: fill the disc
+  for (int j0 = jstart; j0 < js; j0 += kAhead) {  // warm-up: fill the disc
+#pragma unroll
+    for (int qs = 0; qs < kAhead; ++qs) advance(j0 + qs, pfq[qs], stq[qs]);
+  }
 
 #pragma unroll 1
-  for (int j = js; j < jend; ++j) {
+  for (int j0 = js; j0 < jend; j0 += kAhead) {
+#pragma unroll
+  for (int qs = 0; qs < kAhead; ++qs) {
+    const int j = j0 + qs;
+    if (j >= jend) break;
+    __builtin_amdgcn_sched_barrier(0);  // keep the kAhead unrolled rows apart (register pressure)
     // ---- tail of row j (values stay in registers until the stores below) --------------------------
     float nx = qnanf(), ny = qnanf(), nz = qnanf(), o_slope = qnanf(), o_rough = qnanf();
     bool done = false;
-    const float stepv = stq[0];
+    const float stepv = stq[qs];
     const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
     if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
       // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
@@ -429,7 +433,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     const float tabc = tab + tc;
     const float o_trav = a.w_scale * tabc;
 
-    advance(j);  // (the last one of a strip is not needed, but keeps the loop body branch-free)
+    advance(j, pfq[qs], stq[qs]);  // (the last one of a strip is not needed, but keeps the body branch-free)
 
     // ---- stores of row j ------------------------------------------------------------------------------
     const bool emit = i < sub_i1;
@@ -446,10 +450,11 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     }
     if (__any(emit && !done) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
   }
+  }
 }
 
 template <int R>
-__global__ __launch_bounds__(kLanes) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
+__global__ __launch_bounds__(kLanes, 3) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
                                                           float* __restrict__ onx, float* __restrict__ ony,
