@@ -403,7 +403,11 @@ int te_create(int device, te_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->ev0);
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {  // the (shorter) step-filter kernels go first when both streams have work
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    e = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
