@@ -183,6 +183,13 @@ def main():
                          "kernel": "chain launch sequence (all kernels of one te_run_chain)",
                          "ms_per_launch": ms_chain, "algorithmic_bytes_per_cell": bytes_per_cell},
         }
+        # HBM traffic of the same launch sequence: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
+        # WRITE_SIZE do not fit one pass), so the number is taken from the committed profile of this exact
+        # workload (profiles/r01_hbm_traffic.json), never measured inside the timed run
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0:
+            out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes"]
+            out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
         if check is not None:
