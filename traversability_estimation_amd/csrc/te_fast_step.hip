@@ -14,9 +14,14 @@ namespace fast {
 
 namespace {
 
+// waves per SIMD the kernels are compiled for (register budget 512 / waves); the launchers size the
+// strips so that the whole grid is resident at this occupancy
+constexpr int kHeightWaves = 3, kScoreWaves = 3;
+
 template <int Q>
-__global__ __launch_bounds__(kLanes) void k_step_height_fast(Geo g, const float* __restrict__ elev,
-                                                             float* __restrict__ sh, Region rg) {
+__global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g, const float* __restrict__ elev,
+                                                                           float* __restrict__ sh, Region rg,
+                                                                           int periods) {
   using S = Shape<Q>;
   using T = Strip<Q>;
   constexpr int R = S::R, P = S::P, W = T::W;
@@ -25,66 +30,100 @@ __global__ __launch_bounds__(kLanes) void k_step_height_fast(Geo g, const float*
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
   const int i0 = rg.i0 + blockIdx.x * kLanes;
-  const int js = rg.j0 + blockIdx.y * T::out_rows;
+  const int out_rows = T::out_rows(periods);
+  const int js = rg.j0 + blockIdx.y * out_rows;
   const int i = i0 + lane;
   float amax[P], amin[P], zc[P];
-#pragma unroll
-  for (int k = 0; k < P; ++k) amax[k] = amin[k] = zc[k] = qnan();
+  static_for<P>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    amax[k] = amin[k] = zc[k] = qnan();
+  });
 
-  float stage[T::NLD];
-  load_period<Q>(stage, elev + mo, g, js - R, i0 - R, lane);
+  PeriodLoader<Q> loader;
+  float stage[PeriodLoader<Q>::NLD];
+  loader.init(g, lane);
+  loader.load(stage, elev + mo, g, js - R, i0 - R, lane);
 #pragma unroll 1
-  for (int per = 0; per < T::periods; ++per) {
+  for (int per = 0; per < periods; ++per) {
     const int rbase = js - R + per * P;
     if (rbase - R >= rg.j1) break;  // nothing left to emit (uniform)
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < T::NLD; ++k) {
-      const int idx = lane + k * kLanes;
-      const float t = stage[k];
-      if (idx < P * W) rowbuf[idx] = __builtin_isfinite(t) ? t : qnan();
-    }
+    loader.store(rowbuf, stage, lane, [](float t) { return __builtin_isfinite(t) ? t : qnan(); });
     __syncthreads();
-    if (per + 1 < T::periods) load_period<Q>(stage, elev + mo, g, rbase + P, i0 - R, lane);  // in flight during the period
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
+    if (per + 1 < periods) loader.load(stage, elev + mo, g, rbase + P, i0 - R, lane);  // in flight during the period
+    // Two rows per pass: every pending output takes the run values of both rows with ONE v_max3/v_min3.
+    // Row p is at offset e1 (slot = (p+e1) mod P) and row p+1 at e1-1 of the same output; the output that
+    // completes with row p (e1 == -R) is emitted in between and its slot restarts with row p+1 (offset +R).
+    auto horiz = [&](int p, float (&mx)[R + 1], float (&mn)[R + 1]) __attribute__((always_inline)) {
       const float* row = rowbuf + p * W + lane + R;
-      float mx[R + 1], mn[R + 1];
       mx[0] = mn[0] = row[0];
-#pragma unroll
-      for (int d = 1; d <= R; ++d) {
+      static_for<R>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value + 1;
         const float a = row[-d], b = row[d];
-        mx[d] = vmax3(mx[d - 1], a, b);
-        mn[d] = vmin3(mn[d - 1], a, b);
-      }
+        vmax3_min3(mx[d], mn[d], mx[d - 1], mn[d - 1], a, b);
+      });
       zc[p] = row[0];
-#pragma unroll
-      for (int e = -R; e <= R; ++e) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int slot = (p + e + P) % P;
-        const int w = S::hw(e < 0 ? -e : e);
-        amax[slot] = vmax2(amax[slot], mx[w]);
-        amin[slot] = vmin2(amin[slot], mn[w]);
-      }
+    };
+    auto emit = [&](int p, float vmx, float vmn) __attribute__((always_inline)) {  // the output row completed by row p of this period
       const int so = (p + R + 1) % P;
       const int j = rbase + p - R;
-      if (j >= js && j < js + T::out_rows && j < rg.j1 && i < rg.i1) {
+      if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
         const float z0 = zc[so];
         // StepFilter.cpp:113 only valid centres; :143 double difference stored as float
-        const float out = (z0 == z0) ? (float)((double)amax[so] - (double)amin[so]) : qnan();
+        const float out = (z0 == z0) ? (float)((double)vmx - (double)vmn) : qnan();
         sh[mo + (size_t)j * g.rows + i] = out;
       }
-      amax[so] = amin[so] = qnan();
-    }
+    };
+    static_for<(P + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
+      constexpr int p = 2 * decltype(pc)::value;
+      // keep the passes of the period apart: otherwise the scheduler hoists the LDS reads of many passes
+      // and the run arrays of all of them are live at once
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (p + 1 < P) {
+        float mx1[R + 1], mn1[R + 1], mx2[R + 1], mn2[R + 1];
+        horiz(p, mx1, mn1);
+        horiz(p + 1, mx2, mn2);
+        static_for<P>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int sl = decltype(sc)::value;
+          constexpr int e0 = ((sl - p) % P + P) % P;
+          constexpr int e1 = e0 > R ? e0 - P : e0;
+          if constexpr (e1 == -R) {
+            emit(p, vmax2(amax[sl], mx1[S::hw(R)]), vmin2(amin[sl], mn1[S::hw(R)]));
+            amax[sl] = mx2[S::hw(R)];
+            amin[sl] = mn2[S::hw(R)];
+          } else {
+            constexpr int w1 = S::hw(e1 < 0 ? -e1 : e1), w2 = S::hw(e1 - 1 < 0 ? 1 - e1 : e1 - 1);
+            vmax3_min3(amax[sl], amin[sl], amax[sl], amin[sl], mx1[w1], mx2[w2], mn1[w1], mn2[w2]);
+            if constexpr (e1 - 1 == -R) {
+              emit(p + 1, amax[sl], amin[sl]);
+              amax[sl] = amin[sl] = qnan();
+            }
+          }
+        });
+      } else {  // last (odd) row of the period on its own
+        float mx[R + 1], mn[R + 1];
+        horiz(p, mx, mn);
+        static_for<P>([&](auto ec) __attribute__((always_inline)) {
+          constexpr int e = decltype(ec)::value - R;
+          constexpr int slot = (p + e + P) % P;
+          constexpr int w = S::hw(e < 0 ? -e : e);
+          amax[slot] = vmax2(amax[slot], mx[w]);
+          amin[slot] = vmin2(amin[slot], mn[w]);
+        });
+        constexpr int so = (p + R + 1) % P;
+        emit(p, amax[so], amin[so]);
+        amax[so] = amin[so] = qnan();
+      }
+    });
   }
 }
 
 // crit_lo = largest float <= critical_value, so that for a float s:  (double)s > crit  <=>  s > crit_lo.
 template <int Q>
-__global__ __launch_bounds__(kLanes) void k_step_score_fast(Geo g, double crit, float crit_lo, int ncrit,
-                                                            const float* __restrict__ shl,
-                                                            float* __restrict__ out, Region rg) {
+__global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, double crit, double rcrit, float crit_lo, int ncrit,
+                                                                         const float* __restrict__ shl,
+                                                                         float* __restrict__ out, Region rg,
+                                                                         int periods) {
   using S = Shape<Q>;
   using T = Strip<Q>;
   constexpr int R = S::R, P = S::P, W = T::W;
@@ -93,88 +132,141 @@ __global__ __launch_bounds__(kLanes) void k_step_score_fast(Geo g, double crit, 
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
   const int i0 = rg.i0 + blockIdx.x * kLanes;
-  const int js = rg.j0 + blockIdx.y * T::out_rows;
+  const int out_rows = T::out_rows(periods);
+  const int js = rg.j0 + blockIdx.y * out_rows;
   const int i = i0 + lane;
+  // nCells / nCellCritical_ for every possible count, divided once per block (exactly the reference's
+  // double division); first read after the barriers of the first period
+  __shared__ double ratio[S::npoints() + 1];
+  for (int k = lane; k <= S::npoints(); k += kLanes) ratio[k] = (double)k / (double)ncrit;
   float vm[P];  // NaN-ignoring max of the valid step heights (NaN == no valid cell yet)
   int cnt[P];
-#pragma unroll
-  for (int k = 0; k < P; ++k) {
+  static_for<P>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
     vm[k] = qnan();
     cnt[k] = 0;
-  }
+  });
 
-  float stage[T::NLD];
-  load_period<Q>(stage, shl + mo, g, js - R, i0 - R, lane);
+  PeriodLoader<Q> loader;
+  float stage[PeriodLoader<Q>::NLD];
+  loader.init(g, lane);
+  loader.load(stage, shl + mo, g, js - R, i0 - R, lane);
 #pragma unroll 1
-  for (int per = 0; per < T::periods; ++per) {
+  for (int per = 0; per < periods; ++per) {
     const int rbase = js - R + per * P;
     if (rbase - R >= rg.j1) break;
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < T::NLD; ++k) {
-      const int idx = lane + k * kLanes;
-      const float v = stage[k];  // finite or NaN
-      if (idx < P * W) rowbuf[idx] = make_float2(v, __int_as_float(v > crit_lo ? 1 : 0));
-    }
+    // staged step heights are finite or NaN
+    loader.store(rowbuf, stage, lane, [&](float v) { return make_float2(v, __int_as_float(v > crit_lo ? 1 : 0)); });
     __syncthreads();
-    if (per + 1 < T::periods) load_period<Q>(stage, shl + mo, g, rbase + P, i0 - R, lane);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
+    if (per + 1 < periods) loader.load(stage, shl + mo, g, rbase + P, i0 - R, lane);
+    auto horiz = [&](int p, float (&mx)[R + 1], int (&cn)[R + 1]) __attribute__((always_inline)) {
       const float2* row = rowbuf + p * W + lane + R;
-      float mx[R + 1];
-      int cn[R + 1];
       {
         const float2 c = row[0];
         mx[0] = c.x;
         cn[0] = __float_as_int(c.y);
       }
-#pragma unroll
-      for (int d = 1; d <= R; ++d) {
+      static_for<R>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value + 1;
+        if constexpr (R >= 6 && d == R / 2 + 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
         const float2 a = row[-d], b = row[d];
-        mx[d] = vmax3(mx[d - 1], a.x, b.x);
-        cn[d] = cn[d - 1] + __float_as_int(a.y) + __float_as_int(b.y);
-      }
-#pragma unroll
-      for (int e = -R; e <= R; ++e) {
-        const int slot = (p + e + P) % P;
-        const int w = S::hw(e < 0 ? -e : e);
-        vm[slot] = vmax2(vm[slot], mx[w]);
-        cnt[slot] += cn[w];
-      }
-      const int so = (p + R + 1) % P;
+        vmax3_add3(mx[d], cn[d], mx[d - 1], a.x, b.x, cn[d - 1], __float_as_int(a.y), __float_as_int(b.y));
+      });
+    };
+    auto emit = [&](int p, float m, int count) __attribute__((always_inline)) {
       const int j = rbase + p - R;
-      if (j >= js && j < js + T::out_rows && j < rg.j1 && i < rg.i1) {
-        const float m = vm[so];
-        float o = qnan();
-        if (m == m) {  // isValid: at least one valid step_height in the window (StepFilter.cpp:161)
-          const double sm = (double)vmax2(m, 0.0f);  // stepMax starts at 0.0 (:149)
-          const double a1 = (double)cnt[so] / (double)ncrit * sm;
-          const double step = sm < a1 ? sm : a1;  // :170
-          o = step < crit ? (float)(1.0 - step / crit) : 0.0f;
-        }
+      if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
+        // isValid: at least one valid step_height in the window (StepFilter.cpp:161), else the cell stays NaN
+        const double sm = (double)vmax2_zero(m);  // stepMax starts at 0.0 (:149)
+        const double a1 = ratio[count] * sm;       // nCells / nCellCritical_ * stepMax (:169)
+        const double step = sm < a1 ? sm : a1;     // :170
+        // step / crit without the division sequence: q0 = step * RN(1/crit), then two residual corrections
+        // (Markstein: the first makes q faithful, the second correctly rounded), all branch-free
+        const double q0 = step * rcrit;
+        const double q1 = fma(fma(-q0, crit, step), rcrit, q0);
+        const double q = fma(fma(-q1, crit, step), rcrit, q1);
+        float o = step < crit ? (float)(1.0 - q) : 0.0f;
+        o = (m == m) ? o : qnan();
         out[mo + (size_t)j * g.rows + i] = o;
       }
-      vm[so] = qnan();
-      cnt[so] = 0;
-    }
+    };
+    static_for<(P + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
+      constexpr int p = 2 * decltype(pc)::value;
+      __builtin_amdgcn_sched_barrier(0);  // see k_step_height_fast
+      if constexpr (p + 1 < P) {  // two rows per pass
+        float mx1[R + 1], mx2[R + 1];
+        int cn1[R + 1], cn2[R + 1];
+        horiz(p, mx1, cn1);
+        __builtin_amdgcn_sched_barrier(0);  // float2 rows: do not hold both rows' LDS reads at once
+        horiz(p + 1, mx2, cn2);
+        static_for<P>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int sl = decltype(sc)::value;
+          constexpr int e0 = ((sl - p) % P + P) % P;
+          constexpr int e1 = e0 > R ? e0 - P : e0;
+          if constexpr (e1 == -R) {
+            emit(p, vmax2(vm[sl], mx1[S::hw(R)]), cnt[sl] + cn1[S::hw(R)]);
+            vm[sl] = mx2[S::hw(R)];
+            cnt[sl] = cn2[S::hw(R)];
+          } else {
+            constexpr int w1 = S::hw(e1 < 0 ? -e1 : e1), w2 = S::hw(e1 - 1 < 0 ? 1 - e1 : e1 - 1);
+            vmax3_add3(vm[sl], cnt[sl], vm[sl], mx1[w1], mx2[w2], cnt[sl], cn1[w1], cn2[w2]);
+            if constexpr (e1 - 1 == -R) {
+              emit(p + 1, vm[sl], cnt[sl]);
+              vm[sl] = qnan();
+              cnt[sl] = 0;
+            }
+          }
+        });
+      } else {
+        float mx[R + 1];
+        int cn[R + 1];
+        horiz(p, mx, cn);
+        static_for<P>([&](auto ec) __attribute__((always_inline)) {
+          constexpr int e = decltype(ec)::value - R;
+          constexpr int slot = (p + e + P) % P;
+          constexpr int w = S::hw(e < 0 ? -e : e);
+          vm[slot] = vmax2(vm[slot], mx[w]);
+          cnt[slot] += cn[w];
+        });
+        constexpr int so = (p + R + 1) % P;
+        emit(p, vm[so], cnt[so]);
+        vm[so] = qnan();
+        cnt[so] = 0;
+      }
+    });
   }
+}
+
+// resident wave slots of the device for a kernel compiled for `waves` waves per SIMD
+long wave_slots(int waves) {
+  static long simds = 0;
+  if (!simds) {
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    simds = 4L * cus;
+  }
+  return simds * waves;
 }
 
 template <int Q>
 void launch_height(const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
   using T = Strip<Q>;
-  dim3 grid((unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), (unsigned)((r.j1 - r.j0 + T::out_rows - 1) / T::out_rows),
-            (unsigned)(r.map >= 0 ? 1 : g.batch));
-  hipLaunchKernelGGL(k_step_height_fast<Q>, grid, dim3(kLanes), 0, s, g, elev, sh, r);
+  const unsigned nx = (unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), nz = (unsigned)(r.map >= 0 ? 1 : g.batch);
+  const int periods = plan_periods(T::P, T::R, r.j1 - r.j0, (long)nx * nz, wave_slots(kHeightWaves));
+  dim3 grid(nx, (unsigned)((r.j1 - r.j0 + T::out_rows(periods) - 1) / T::out_rows(periods)), nz);
+  hipLaunchKernelGGL(k_step_height_fast<Q>, grid, dim3(kLanes), 0, s, g, elev, sh, r, periods);
 }
 
 template <int Q>
 void launch_score(const Geo& g, double crit, float crit_lo, int ncrit, const float* sh, float* out, const Region& r,
                   hipStream_t s) {
   using T = Strip<Q>;
-  dim3 grid((unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), (unsigned)((r.j1 - r.j0 + T::out_rows - 1) / T::out_rows),
-            (unsigned)(r.map >= 0 ? 1 : g.batch));
-  hipLaunchKernelGGL(k_step_score_fast<Q>, grid, dim3(kLanes), 0, s, g, crit, crit_lo, ncrit, sh, out, r);
+  const unsigned nx = (unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), nz = (unsigned)(r.map >= 0 ? 1 : g.batch);
+  const int periods = plan_periods(T::P, T::R, r.j1 - r.j0, (long)nx * nz, wave_slots(kScoreWaves));
+  dim3 grid(nx, (unsigned)((r.j1 - r.j0 + T::out_rows(periods) - 1) / T::out_rows(periods)), nz);
+  hipLaunchKernelGGL(k_step_score_fast<Q>, grid, dim3(kLanes), 0, s, g, crit, 1.0 / crit, crit_lo, ncrit, sh, out, r, periods);
 }
 
 }  // namespace

@@ -10,6 +10,9 @@
 // stencil costs O(R) operations per cell instead of O(R^2) and nothing but the single row is staged
 // on chip.  The disc shape (Q) is a template parameter: the run table is constexpr.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "te_internal.h"
 
 namespace te {
@@ -35,37 +38,116 @@ struct Shape {
 };
 
 constexpr int kLanes = 64;
-constexpr int kStripTarget = 128;  // rows of output per strip (rounded up to whole periods)
 
-template <int Q, int TARGET = kStripTarget>
+// A strip is `periods` unrolled periods of P rows; the first and last R rows visited only feed the halo.
+// The number of periods is a launch parameter: the launcher picks it so that the grid fills the resident
+// wave slots of the chip in one round (plan_periods below).
+template <int Q>
 struct Strip {
   static constexpr int R = Shape<Q>::R, P = Shape<Q>::P;
-  static constexpr int periods = (TARGET + 2 * R + P - 1) / P;
-  static constexpr int steps = periods * P;       // rows visited per strip
-  static constexpr int out_rows = steps - 2 * R;  // rows produced per strip
-  static constexpr int W = kLanes + 2 * R;        // staged row width
-  static constexpr int NLD = (P * W + kLanes - 1) / kLanes;  // global loads per lane per period
+  static constexpr int W = kLanes + 2 * R;  // staged row width
+  __host__ __device__ static constexpr int out_rows(int periods) { return periods * P - 2 * R; }
 };
 
 __device__ __forceinline__ float qnan() { return __builtin_nanf(""); }
 
-// Issue the loads of one period (P rows x W columns starting at map row r0, map column c0) into
-// registers; NaN outside the map.  All loads are issued back to back (they stay in flight while the
-// previous period is processed); the caller writes them to LDS later.
-template <int Q, int TARGET = kStripTarget, int NLD>
-__device__ __forceinline__ void load_period(float (&v)[NLD], const float* __restrict__ layer, const Geo& g, int r0,
-                                            int c0, int lane) {
-  constexpr int P = Shape<Q>::P, W = Strip<Q, TARGET>::W;
-  static_assert(NLD == Strip<Q, TARGET>::NLD, "staging register count");
-#pragma unroll
-  for (int k = 0; k < NLD; ++k) {
-    const int idx = lane + k * kLanes;
-    const int rr = idx / W, cc = idx - rr * W;
-    const int r = r0 + rr, ci = c0 + cc;
-    float t = qnan();
-    if (idx < P * W && r >= 0 && r < g.cols && ci >= 0 && ci < g.rows) t = layer[(size_t)r * g.rows + ci];
-    v[k] = t;
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Used where every
+// register-array index has to be a constant (a "#pragma unroll" the optimiser declines leaves dynamic
+// indices behind and the arrays go to scratch).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Loads of one period (P rows x W columns starting at map row r0, map column c0) into registers; NaN
+// outside the map.  All loads are issued back to back (they stay in flight while the previous period is
+// processed); store() writes them to LDS later.
+//   main part: row rr, columns c0+R .. c0+R+63  -> one 256-byte coalesced load per row, address =
+//              uniform row base + lane*4 (no per-load address arithmetic)
+//   halo part: the 2R border columns of all P rows, flattened over the lanes: NH loads whose per-lane
+//              byte offset and LDS slot never change and are computed once (init)
+// A period completely inside the map (wave-uniform test) takes the unchecked path.
+template <int Q>
+struct PeriodLoader {
+  static constexpr int R = Shape<Q>::R, P = Shape<Q>::P, W = Strip<Q>::W, H = 2 * R;
+  static constexpr int NH = (P * H + kLanes - 1) / kLanes, NLD = P + NH;
+  unsigned hoff[NH ? NH : 1];  // byte offset of the lane's m-th halo cell relative to (r0, c0)
+  int hpos[NH ? NH : 1];       // its slot in the staged period (row * W + column), -1 = none
+
+  __device__ __forceinline__ void init(const Geo& g, int lane) {
+    static_for<NH>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      const int h = lane + m * kLanes;
+      const int hr = h / (H ? H : 1), hc = h - hr * H;
+      const int cc = hc < R ? hc : hc + kLanes;
+      const bool used = h < P * H;
+      hoff[m] = used ? 4u * (unsigned)(hr * g.rows + cc) : 0u;
+      hpos[m] = used ? hr * W + cc : -1;
+    });
   }
+
+  __device__ __forceinline__ void load(float (&v)[NLD], const float* __restrict__ layer, const Geo& g, int r0, int c0,
+                                       int lane) const {
+    if (r0 >= 0 && r0 + P <= g.cols && c0 >= 0 && c0 + W <= g.rows) {
+      const float* base = layer + (size_t)r0 * g.rows + c0;
+      static_for<P>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int rr = decltype(rc)::value;
+        v[rr] = (base + (size_t)rr * g.rows + R)[lane];
+      });
+      static_for<NH>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        v[P + m] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + hoff[m]);
+      });
+    } else {
+      static_for<P>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int rr = decltype(rc)::value;
+        const int r = r0 + rr, ci = c0 + R + lane;
+        float t = qnan();
+        if (r >= 0 && r < g.cols && ci >= 0 && ci < g.rows) t = layer[(size_t)r * g.rows + ci];
+        v[rr] = t;
+      });
+      static_for<NH>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        const int hr = hpos[m] / W, cc = hpos[m] - hr * W;
+        const int r = r0 + hr, ci = c0 + cc;
+        float t = qnan();
+        if (hpos[m] >= 0 && r >= 0 && r < g.cols && ci >= 0 && ci < g.rows) t = layer[(size_t)r * g.rows + ci];
+        v[P + m] = t;
+      });
+    }
+  }
+
+  // rowbuf[slot] = f(value) for every staged cell of the period
+  template <class E, class F>
+  __device__ __forceinline__ void store(E* rowbuf, const float (&v)[NLD], int lane, F&& f) const {
+    static_for<P>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int rr = decltype(rc)::value;
+      rowbuf[rr * W + R + lane] = f(v[rr]);
+    });
+    static_for<NH>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      if (hpos[m] >= 0) rowbuf[hpos[m]] = f(v[P + m]);
+    });
+  }
+};
+
+// Number of periods per strip for a region of `rows` output rows and `columns` 64-lane column blocks
+// (x batch): the smallest strip count whose grid still fits the `slots` resident waves of the device in
+// one round gives the longest strips (least halo re-reading) without a second, mostly empty round.
+inline int plan_periods(int P, int R, int rows, long columns, long slots) {
+  const int min_periods = (2 * R + P) / P + 1;  // at least P output rows or so
+  long strips = slots / (columns > 0 ? columns : 1);
+  if (strips < 1) strips = 1;
+  // rows per strip if `strips` strips cover the region, rounded up to whole periods
+  long per = ((rows + strips - 1) / strips + 2 * R + P - 1) / P;
+  const long max_periods = (128 + 2 * R + P - 1) / P;  // more than ~128 rows per strip gains nothing
+  if (per > max_periods) per = max_periods;
+  if (per < min_periods) per = min_periods;
+  return (int)per;
 }
 
 // min/max that ignore (quiet) NaN operands, without the canonicalisation instruction the compiler
@@ -78,6 +160,29 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
 __device__ __forceinline__ float vmin3(float a, float b, float c) {
   float r;
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max3 + integer add3 issued as one unit: {m, c} = {max3(m0, x, y), c0 + i + j}.  One asm statement so that
+// the scheduler cannot drift the adds away from the max (which would keep every staged flag register
+// alive across the emit blocks).
+__device__ __forceinline__ void vmax3_add3(float& m, int& c, float m0, float x, float y, int c0, int i, int j) {
+  asm("v_max3_f32 %0, %2, %3, %4\n\tv_add3_u32 %1, %5, %6, %7"
+      : "=&v"(m), "=v"(c)
+      : "v"(m0), "v"(x), "v"(y), "v"(c0), "v"(i), "v"(j));
+}
+// running max and min of the same operands as one unit (same reason as vmax3_add3)
+__device__ __forceinline__ void vmax3_min3(float& mx, float& mn, float mx0, float mn0, float x, float y) {
+  asm("v_max3_f32 %0, %2, %4, %5\n\tv_min3_f32 %1, %3, %4, %5" : "=&v"(mx), "=v"(mn) : "v"(mx0), "v"(mn0), "v"(x), "v"(y));
+}
+__device__ __forceinline__ void vmax3_min3(float& mx, float& mn, float mx0, float mn0, float x1, float x2, float n1,
+                                           float n2) {
+  asm("v_max3_f32 %0, %2, %4, %5\n\tv_min3_f32 %1, %3, %6, %7"
+      : "=&v"(mx), "=v"(mn)
+      : "v"(mx0), "v"(mn0), "v"(x1), "v"(x2), "v"(n1), "v"(n2));
+}
+__device__ __forceinline__ float vmax2_zero(float a) {  // max(a, 0) ignoring NaN (NaN -> 0)
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
   return r;
 }
 __device__ __forceinline__ float vmax2(float a, float b) {
