@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-footprint", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
     ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
     return ap.parse_args()
 
@@ -105,6 +106,8 @@ def main():
 
     with_fp = not args.no_footprint
     flags = capi.RUN_FOOTPRINT if with_fp else 0
+    if args.sequential:
+        flags |= capi.RUN_SEQUENTIAL
     n = args.size
     B = args.maps_per_gpu
     # shard of the batch owned by this rank: maps rank*B .. rank*B+B-1 (seed = 1235 + global map index)

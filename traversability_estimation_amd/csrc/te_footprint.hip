@@ -389,13 +389,14 @@ struct SpiralArgs {
 // both the per-cell value and the disc sum  sum(T') + kUOff * sum(U)  are exact in double and split
 // back exactly:  sum(U) = floor((S + kUOff/2) / kUOff).
 constexpr double kUOff = 4096.0;
+constexpr int kFpWaves = 2;  // waves per SIMD k_fp_slide is compiled for; the launcher fills exactly these slots
 
 template <int R>
-__global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const float* __restrict__ trav,
+__global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs a, const float* __restrict__ trav,
                                                      const uint8_t* __restrict__ untrav,
                                                      float* __restrict__ footprint) {
   constexpr int W = kLanes + 2 * R;
-  constexpr int NR = 2 * R + 2;
+  constexpr int NR = 2 * R + 3;  // rows j-R .. j+2+R: the reads of step j+1 are issued during step j
   constexpr int NX = (W + kLanes - 1) / kLanes;
   constexpr int kAhead = 4;
   __shared__ double ring[NR * W];
@@ -439,58 +440,95 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
   };
 
   double S = 0.0;
-  const int jstart = js - (2 * R + 1);
+  constexpr int WU = ((2 * R + 1 + kAhead - 1) / kAhead) * kAhead;  // warm-up steps: whole groups of kAhead
+  const int jstart = js - WU;
   int slot_j = 0;
+  // ring offsets (in doubles) of the leading (j+1+h) / trailing (j-h) row of disc column |di| = d for the
+  // NEXT fetch; a column outside the tie-free disc (h < 0: only tie offsets reach it) reads the same row
+  // twice, so it contributes exactly 0
   int lead[R + 1], trail[R + 1];
-  bool inside[R + 1];
 #pragma unroll
   for (int d = 0; d <= R; ++d) {
-    const int h = a.h[d] < 0 ? 0 : a.h[d];
-    inside[d] = a.h[d] >= 0;
-    lead[d] = ((1 + h) % NR) * W;
-    trail[d] = ((NR - h) % NR) * W;
+    const int h = a.h[d];
+    lead[d] = h >= 0 ? ((1 + h) % NR) * W : 0;
+    trail[d] = h >= 0 ? ((NR - h) % NR) * W : 0;
   }
   float ptq[kAhead][NX];
   int puq[kAhead][NX];
 #pragma unroll
-  for (int d = 0; d < kAhead; ++d) load_row(jstart + 1 + R + d, ptq[d], puq[d]);
-  auto advance = [&](int j) {
-    int sr = slot_j + 1 + R;
-    sr = sr >= NR ? sr - NR : sr;
-    store_row(j + 1 + R, sr, ptq[0], puq[0]);
-#pragma unroll
-    for (int d = 0; d + 1 < kAhead; ++d)
-#pragma unroll
-      for (int x = 0; x < NX; ++x) {
-        ptq[d][x] = ptq[d + 1][x];
-        puq[d][x] = puq[d + 1][x];
-      }
-    load_row(j + 1 + R + kAhead, ptq[kAhead - 1], puq[kAhead - 1]);
-    double acc = 0.0;
+  for (int d = 0; d < kAhead; ++d) load_row(jstart + 2 + R + d, ptq[d], puq[d]);
+  // Software pipeline: step j (disc row j -> j+1) consumes the 4(R+1)-2 ring values that were read during
+  // step j-1 and, before that, issues the reads of step j+1 -- the LDS latency is covered by the adds.
+  struct Vals {
+    double lp[R + 1], lm[R + 1], tp[R + 1], tm[R + 1];
+  };
+  auto fetch = [&](Vals& v) {
 #pragma unroll
     for (int d = 0; d <= R; ++d) {
-      // columns +d and -d share their leading and trailing rows; a column outside the tie-free disc
-      // (h < 0: only tie offsets reach it) contributes nothing
       const double* rl = ring + lead[d] + c;
       const double* rt = ring + trail[d] + c;
-      double e = rl[d] - rt[d];
-      if (d != 0) e += rl[-d] - rt[-d];
-      acc += inside[d] ? e : 0.0;
+      v.lp[d] = rl[d];
+      v.tp[d] = rt[d];
+      v.lm[d] = d ? rl[-d] : 0.0;
+      v.tm[d] = d ? rt[-d] : 0.0;
       lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
       trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
     }
+  };
+  auto consume = [&](const Vals& v) {
+    double acc = v.lp[0] - v.tp[0];
+#pragma unroll
+    for (int d = 1; d <= R; ++d) acc += (v.lp[d] - v.tp[d]) + (v.lm[d] - v.tm[d]);
     S += acc;  // all terms are exact, so is the order
+  };
+  // step j: stage row j+2+R, refill the load queue, read for step j+1, slide with the values read earlier
+  auto advance = [&](int j, float (&pt)[NX], int (&pu)[NX], Vals& next, const Vals& cur) {
+    int sr = slot_j + 2 + R;
+    sr = sr >= NR ? sr - NR : sr;
+    store_row(j + 2 + R, sr, pt, pu);
+    load_row(j + 2 + R + kAhead, pt, pu);
+    fetch(next);
+    consume(cur);
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
   };
+  Vals va, vb;
+  {  // rows <= jstart+R are virtual zeros (ring cleared); row jstart+1+R is the first real one
+    float pt0[NX];
+    int pu0[NX];
+    load_row(jstart + 1 + R, pt0, pu0);
+    store_row(jstart + 1 + R, (1 + R) % NR, pt0, pu0);
+    fetch(va);
+  }
+  static_assert(kAhead % 2 == 0, "the value buffers alternate with the queue slots");
 
 #pragma unroll 1
-  for (int j = jstart; j < js; ++j) advance(j);
+  for (int j0 = jstart; j0 < js; j0 += kAhead) {  // warm-up: fill the disc
+#pragma unroll
+    for (int qs = 0; qs < kAhead; ++qs) {
+      if (qs % 2 == 0)
+        advance(j0 + qs, ptq[qs], puq[qs], vb, va);
+      else
+        advance(j0 + qs, ptq[qs], puq[qs], va, vb);
+    }
+  }
 
+  int nt_next = a.gtab[(((js < R) ? (R - js) : ((g.cols - 1 - js < R) ? -(R - (g.cols - 1 - js)) : 0)) + R) * (2 * R + 1) * 6 +
+                       (kx + R) * 6];
+  int nt_cached = 0;
+  double rnt = 0.0;
 #pragma unroll 1
-  for (int j = js; j < jend; ++j) {
-    const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);
+  for (int j0 = js; j0 < jend; j0 += kAhead) {
+#pragma unroll
+  for (int qs = 0; qs < kAhead; ++qs) {
+    const int j = j0 + qs;
+    if (j >= jend) break;
     double St = S;
-    int nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
+    int nt = nt_next;
+    {  // cell count of the clipped tie-free disc for the next row (only changes near the map border)
+      const int jn = j + 1 < g.cols ? j + 1 : j;
+      const int kyn = (jn < R) ? (R - jn) : ((g.cols - 1 - jn < R) ? -(R - (g.cols - 1 - jn)) : 0);
+      nt_next = a.gtab[((kyn + R) * (2 * R + 1) + (kx + R)) * 6];
+    }
     // cells on the circle itself (tie radii): SpiralIterator::isInside per cell
     for (int t = 0; t < a.n_ties; ++t) {
       const int di = a.tie_di[t], dj = a.tie_dj[t];
@@ -507,7 +545,17 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
     const int Ut = (int)floor((St + 0.5 * kUOff) * (1.0 / kUOff));
     float out;
     if (Ut == 0) {
-      out = (float)(St / (double)nt);  // :732-735 no untraversable cell in the footprint
+      // :732-735 no untraversable cell in the footprint: mean = St / nt.  nt is constant away from the map
+      // border, so the division is a multiplication by the cached RN(1/nt) plus two residual corrections
+      // (the second one makes the quotient correctly rounded)
+      if (nt != nt_cached) {
+        nt_cached = nt;
+        rnt = 1.0 / (double)nt;
+      }
+      const double dn = (double)nt;
+      const double q0 = St * rnt;
+      const double q1 = fma(fma(-q0, dn, St), rnt, q0);
+      out = (float)fma(fma(-q1, dn, St), rnt, q1);
     } else {
       // walk the spiral until the first untraversable cell :687-717
       double t = 0.0;
@@ -540,8 +588,12 @@ __global__ __launch_bounds__(kLanes) void k_fp_slide(Geo g, SpiralArgs a, const 
       }
       if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
     }
-    advance(j);
+    if (qs % 2 == 0)
+      advance(j, ptq[qs], puq[qs], vb, va);
+    else
+      advance(j, ptq[qs], puq[qs], va, vb);
     if (i < g.rows) footprint[mo + (size_t)j * g.rows + i] = out;
+  }
   }
 }
 
@@ -580,9 +632,9 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.rmin = p.rmin;
   a.rmax = p.rmax;
   a.def = p.def;
-  {  // one round of resident waves (<= 3 per SIMD): as many strips as fit
+  {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
-    int strips = (3 * 4 * 256) / (nbx * (g.batch > 0 ? g.batch : 1));
+    int strips = (kFpWaves * 4 * 256) / (nbx * (g.batch > 0 ? g.batch : 1));
     strips = strips < 1 ? 1 : strips;
     int rows_per = (g.cols + strips - 1) / strips;
     a.out_rows = rows_per < 48 ? 48 : (rows_per > 512 ? 512 : rows_per);
