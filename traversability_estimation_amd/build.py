@@ -1,19 +1,22 @@
 """Builds libtravgpu.so (the gfx950 HIP kernels + the C-ABI shim) in-tree with hipcc.
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels with
-the gpurun snapshot, so the GPU box uses the prebuilt file.
+the gpurun snapshot, so the GPU box uses the prebuilt file.  Every source is compiled to its own object
+(in parallel, cached under _build/ by modification time) and the objects are linked into the library.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_slide_normals.hip", "csrc/te_footprint.hip"]
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+OBJDIR = os.path.join(_HERE, "_build")
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 
 
 def hipcc():
@@ -23,20 +26,42 @@ def hipcc():
     return exe
 
 
+def _mtime(rel):
+    return os.path.getmtime(os.path.join(_HERE, rel))
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(_HERE, f)) > t for f in SOURCES + HEADERS)
+    return any(_mtime(f) > t for f in SOURCES + HEADERS)
+
+
+def _obj(src):
+    return os.path.join(OBJDIR, os.path.basename(src) + ".o")
+
+
+def _compile(src, verbose):
+    cmd = [hipcc()] + CFLAGS + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
+                               os.path.join(_HERE, src), "-o", _obj(src) + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(_obj(src) + ".tmp", _obj(src))
 
 
 def build_lib(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")]
-    cmd += [os.path.join(_HERE, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
+    todo = [s for s in SOURCES
+            if not os.path.exists(_obj(s)) or os.path.getmtime(_obj(s)) < max(_mtime(s), newest_header)]
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        list(pool.map(lambda s: _compile(s, verbose), todo))
+    cmd = [hipcc()] + LDFLAGS + [_obj(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
   constexpr int NR = 2 * R + 3;  // rows j-R .. j+2+R: the reads of step j+1 are issued during step j
   constexpr int NX = (W + kLanes - 1) / kLanes;
   constexpr int kAhead = 4;
+  constexpr bool kPipe = R <= 10;  // software-pipelined ring reads (needs 8(R+1) more VGPRs)
   __shared__ double ring[NR * W];
   const int lane = threadIdx.x;
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
@@ -487,8 +488,13 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     sr = sr >= NR ? sr - NR : sr;
     store_row(j + 2 + R, sr, pt, pu);
     load_row(j + 2 + R + kAhead, pt, pu);
-    fetch(next);
-    consume(cur);
+    if (kPipe) {
+      fetch(next);
+      consume(cur);
+    } else {  // large discs: two value buffers do not fit the register file, read and add in the same step
+      fetch(next);
+      consume(next);
+    }
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
   };
   Vals va, vb;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     int pu0[NX];
     load_row(jstart + 1 + R, pt0, pu0);
     store_row(jstart + 1 + R, (1 + R) % NR, pt0, pu0);
-    fetch(va);
+    if (kPipe) fetch(va);
   }
   static_assert(kAhead % 2 == 0, "the value buffers alternate with the queue slots");
 
@@ -634,7 +640,11 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.def = p.def;
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
-    int strips = (kFpWaves * 4 * 256) / (nbx * (g.batch > 0 ? g.batch : 1));
+    const int Rk = p.reach;
+    const long ring_bytes = (long)(2 * Rk + 3) * (kLanes + 2 * Rk) * 8;
+    long per_cu = 160 * 1024 / ring_bytes;  // blocks (= waves) per CU the LDS allows
+    if (per_cu > kFpWaves * 4) per_cu = kFpWaves * 4;
+    int strips = (int)((per_cu * 256) / (nbx * (g.batch > 0 ? g.batch : 1)));
     strips = strips < 1 ? 1 : strips;
     int rows_per = (g.cols + strips - 1) / strips;
     a.out_rows = rows_per < 48 ? 48 : (rows_per > 512 ? 512 : rows_per);

@@ -26,6 +26,7 @@
 // lanes next to the left/right border) are left NaN and flagged; the general kernel recomputes just
 // those cells afterwards (te_kernels.hip: k_normals_fixup).  Invalid cells are staged as 0, so the
 // exact sums recover as soon as the hole has left the window.
+#include <cstdlib>
 #include "te_internal.h"
 
 namespace te {
@@ -33,10 +34,14 @@ namespace fast {
 
 namespace {
 
+// waves per SIMD k_normals_slide is compiled for; launch_r sizes the interior strips to fill exactly these slots in one round
+constexpr int kNormWaves = 2;
+
 constexpr int kLanes = 64;
 
 struct SlideArgs {
   int h[kMaxRadiusCells + 1];  // half-height of disc column |di| (== half-width of row |dj|)
+  double hd[kMaxRadiusCells + 1];  // the same as doubles (kernel arguments stay in scalar registers)
   int np;                      // cells in the disc
   int sii;                     // sum of di^2 over the disc
   double slope_crit, inv_slope_crit, rough_crit, inv_rough_crit;
@@ -217,7 +222,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
                                       float* __restrict__ onx, float* __restrict__ ony, float* __restrict__ onz,
                                       int* __restrict__ tile_flags, const Region& rg) {
   constexpr int W = kLanes + 2 * R;
-  constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R are live while the disc moves from j to j+1
+  constexpr int NR = 2 * R + 3;  // rows j-R .. j+2+R: the ring reads of step j+1 are issued during step j
   constexpr int NX = (W + kLanes - 1) / kLanes;
   constexpr int kAhead = 4;      // rows (and step values) are fetched kAhead steps before they are needed
   const int lane = threadIdx.x;
@@ -296,9 +301,27 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   const int jstart = js - WU;
   int slot_j = 0;  // ring slot of row j (slot(r) = (r - jstart) mod NR)
 
-  const double inv_np = 1.0 / (double)a.np;
-  const double cxx = g.res * g.res * ((double)a.sii * inv_np);
-  const double nm1 = (double)a.np / (double)(a.np > 1 ? a.np - 1 : 1);
+  // Loop constants are pinned in VGPRs: as scalars they (with the 2(R+1) ring row offsets) overflow the
+  // 102 SGPRs and every use in the row loop becomes a v_readlane from the spill register.
+  double inv_np = 1.0 / (double)a.np;
+  double cxx = g.res * g.res * ((double)a.sii * inv_np);
+  double nm1 = (double)a.np / (double)(a.np > 1 ? a.np - 1 : 1);
+  double nres = -g.res;
+  asm volatile("" : "+v"(inv_np), "+v"(cxx), "+v"(nm1), "+v"(nres));
+  double hdv[R + 1];
+#pragma unroll
+  for (int d = 0; d <= R; ++d) {
+    hdv[d] = a.hd[d];
+    asm volatile("" : "+v"(hdv[d]));
+  }
+  // the same for the output pointers (per-lane element 0 of this strip's map)
+  float* v_slope = slope + mo;
+  float* v_rough = rough + mo;
+  float* v_trav = trav + mo;
+  float* v_nx = onx ? onx + mo : nullptr;
+  float* v_ny = onx ? ony + mo : nullptr;
+  float* v_nz = onx ? onz + mo : nullptr;
+  asm volatile("" : "+v"(v_slope), "+v"(v_rough), "+v"(v_trav), "+v"(v_nx), "+v"(v_ny), "+v"(v_nz));
   const float slope_critf = (float)a.slope_crit, inv_slope_critf = (float)a.inv_slope_crit;
   const float rough_critf = (float)a.rough_crit, inv_rough_critf = (float)a.inv_rough_crit;
   // fix-up flags: one per 64x16 tile of the whole region the chain runs on (origin a.fi0, a.fj0)
@@ -306,13 +329,11 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
 
   // ring offsets (in doubles) of the leading / trailing row of disc column |di| = d, advanced every step
   int lead[R + 1], trail[R + 1];
-  double hd[R + 1];
 #pragma unroll
   for (int d = 0; d <= R; ++d) {
     const int h = a.h[d];
     lead[d] = ((1 + h) % NR) * W;
     trail[d] = ((NR - h) % NR) * W;
-    hd[d] = (double)h;
   }
   float pfq[kAhead][NX];
   float stq[kAhead];
@@ -322,26 +343,38 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   };
 #pragma unroll
   for (int d = 0; d < kAhead; ++d) {
-    load_row(jstart + 1 + R + d, pfq[d]);
+    load_row(jstart + 2 + R + d, pfq[d]);
     stq[d] = load_step(jstart + d);
   }
-  // bring in row j+1+R, fetch the row kAhead further down, slide the disc from row j to row j+1
-  // (qs = j mod kAhead is a compile-time queue slot: the loops below are unrolled by kAhead)
-  auto advance = [&](int j, float (&pf)[NX], float& st) {
-    int sr = slot_j + 1 + R;
-    sr = sr >= NR ? sr - NR : sr;
-    store_row(j + 1 + R, sr, pf);
-    load_row(j + 1 + R + kAhead, pf);
-    st = load_step(j + kAhead);
-    double sj = 0.0;
+  // Software pipeline in two groups of disc columns, A = |di| <= RA and B = the rest: the ring reads of
+  // group B (step j) are in flight while group A is summed, and those of group A (step j+1) while group B
+  // is summed and the tail of row j+1 runs -- no more values are live than when a whole step was read at
+  // once, but the LDS latency is off the critical path.
+  constexpr int RA = (R + 1) / 3;
+  struct Vals {
+    double lp[R + 1], lm[R + 1], tp[R + 1], tm[R + 1];  // leading / trailing row, column +d / -d
+  };
+  auto fetch = [&](Vals& v, auto lo, auto hi) {
 #pragma unroll
-    for (int d = 0; d <= R; ++d) {
+    for (int d = decltype(lo)::value; d <= decltype(hi)::value; ++d) {
       // columns +d and -d of the disc share their leading row (j+1+h) and trailing row (j-h)
       const double* rl = ring + lead[d] + c;
       const double* rt = ring + trail[d] + c;
-      const double hh = hd[d];
+      v.lp[d] = rl[d];
+      v.tp[d] = rt[d];
+      v.lm[d] = d ? rl[-d] : 0.0;
+      v.tm[d] = d ? rt[-d] : 0.0;
+      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
+      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+    }
+  };
+  double sj = 0.0;
+  auto consume = [&](const Vals& q, auto lo, auto hi) {
+#pragma unroll
+    for (int d = decltype(lo)::value; d <= decltype(hi)::value; ++d) {
+      const double hh = hdv[d];
       {
-        const double zl = rl[d], zt = rt[d];
+        const double zl = q.lp[d], zt = q.tp[d];
         const double u = zl - zt, v = zl + zt;
         Sz += u;
         if (d != 0) Siz = fma((double)d, u, Siz);
@@ -349,19 +382,42 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
         sj += fma(hh, v, zl);
       }
       if (d != 0) {
-        const double zl = rl[-d], zt = rt[-d];
+        const double zl = q.lm[d], zt = q.tm[d];
         const double u = zl - zt, v = zl + zt;
         Sz += u;
         Siz = fma(-(double)d, u, Siz);
         Szz = fma(u, v, Szz);
         sj += fma(hh, v, zl);
       }
-      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
-      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
     }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IA = std::integral_constant<int, RA>;
+  using IB = std::integral_constant<int, RA + 1>;
+  using IR = std::integral_constant<int, R>;
+  Vals vals;
+  // bring in row j+2+R, fetch the row kAhead further down, slide the disc from row j to row j+1
+  // (qs = j mod kAhead is a compile-time queue slot: the loops below are unrolled by kAhead)
+  auto advance = [&](int j, float (&pf)[NX], float& st) {
+    int sr = slot_j + 2 + R;
+    sr = sr >= NR ? sr - NR : sr;
+    store_row(j + 2 + R, sr, pf);
+    load_row(j + 2 + R + kAhead, pf);
+    st = load_step(j + kAhead);
+    sj = 0.0;
+    if (RA < R) fetch(vals, IB{}, IR{});  // group B of step j
+    consume(vals, I0{}, IA{});            // group A of step j (read during step j-1)
+    fetch(vals, I0{}, IA{});              // group A of step j+1 (needs row j+2+R, staged above)
+    if (RA < R) consume(vals, IB{}, IR{});
     Sjz = (Sjz + sj) - Sz;
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
   };
+  {  // row jstart+1+R (the first that can be real); everything above is a virtual zero row
+    float pf0[NX];
+    load_row(jstart + 1 + R, pf0);
+    store_row(jstart + 1 + R, (1 + R) % NR, pf0);
+    fetch(vals, I0{}, IA{});
+  }
 
 #pragma unroll 1
   for (int j0 = jstart; j0 < js; j0 += kAhead) {  // warm-up: fill the disc
@@ -379,7 +435,11 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     // ---- tail of row j (values stay in registers until the stores below) --------------------------
     float nx = qnanf(), ny = qnanf(), nz = qnanf(), o_slope = qnanf(), o_rough = qnanf();
     bool done = false;
-    const float stepv = stq[qs];
+    // step score of this row, consumed HERE: if its use sank below advance() (which refills the queue slot) the
+    // old value would still be live when the new load is issued, the load would get another register and the
+    // copy back would force a full vmcnt(0) drain at the end of every row
+    float tb = a.w_step * stq[qs];
+    asm volatile("" : "+v"(tb));
     const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
     if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
       // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
@@ -397,8 +457,8 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     } else {
       // straight-line closed-form tail; cells it cannot finish (dirty rows, degenerate t) are masked to NaN
       const double mz = Sz * inv_np;
-      const double ca = -g.res * Siz * inv_np;  // cov(x,z), x = -res*di
-      const double cb = -g.res * Sjz * inv_np;  // cov(y,z)
+      const double ca = nres * Siz * inv_np;  // cov(x,z), x = -res*di
+      const double cb = nres * Sjz * inv_np;  // cov(y,z)
       const double cd = fma(Szz, inv_np, -mz * mz);
       const double delta = 0.5 * (cxx - cd);
       const double h2 = fma(ca, ca, cb * cb);
@@ -428,24 +488,25 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
       o_slope = done ? ss : qnanf();
       o_rough = done ? rs : qnanf();
     }
-    const float ta = a.w_slope * o_slope, tb = a.w_step * stepv, tc = a.w_rough * o_rough;
+    const float ta = a.w_slope * o_slope, tc = a.w_rough * o_rough;
     const float tab = ta + tb;
     const float tabc = tab + tc;
     const float o_trav = a.w_scale * tabc;
 
-    advance(j, pfq[qs], stq[qs]);  // (the last one of a strip is not needed, but keeps the body branch-free)
+    // (the last one of a strip is not needed, but keeps the body branch-free)
+    advance(j, pfq[qs], stq[qs]);
 
     // ---- stores of row j ------------------------------------------------------------------------------
     const bool emit = i < sub_i1;
     if (emit) {
-      const size_t o = mo + (size_t)j * g.rows + i;
-      slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
-      rough[o] = o_rough;
-      if (a.combine) trav[o] = o_trav;
+      const size_t o = (size_t)j * g.rows + i;
+      v_slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
+      v_rough[o] = o_rough;
+      if (a.combine) v_trav[o] = o_trav;
       if (onx) {
-        onx[o] = nx;
-        ony[o] = ny;
-        onz[o] = nz;
+        v_nx[o] = nx;
+        v_ny[o] = ny;
+        v_nz[o] = nz;
       }
     }
     if (__any(emit && !done) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
@@ -454,13 +515,13 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
 }
 
 template <int R>
-__global__ __launch_bounds__(kLanes, 3) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
+__global__ __launch_bounds__(kLanes, kNormWaves) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
                                                           float* __restrict__ onx, float* __restrict__ ony,
                                                           float* __restrict__ onz, int* __restrict__ tile_flags,
                                                           Region rg) {
-  __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+  __shared__ double ring[(2 * R + 3) * (kLanes + 2 * R)];
   int k = 0;  // which rectangle this block works on (uniform)
 #pragma unroll
   for (int t = 1; t < 5; ++t)
@@ -472,7 +533,8 @@ __global__ __launch_bounds__(kLanes, 3) void k_normals_slide(Geo g, SlideArgs a,
 }
 
 constexpr int kStripRows = 128;       // interior strips
-constexpr int kBorderStripRows = 32;  // the clipped-disc tail is slower: shorter strips finish with the rest
+static const int kBorderStripRows = getenv("TE_NR_BROWS") ? atoi(getenv("TE_NR_BROWS")) : 32;  // EXPERIMENT
+constexpr int kBorderStripRows_unused = 32;  // the clipped-disc tail is slower: shorter strips finish with the rest
 
 // Split the region into the frame (clipped discs; launched first, short strips) and the cells whose
 // disc lies inside the map; every rectangle keeps its 64-column blocks aligned to r.i0.
@@ -502,7 +564,8 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
   int interior_rows = kStripRows;
   if (ir > il && jb > ja) {
     const int maps = r.map >= 0 ? 1 : g.batch;
-    const int capacity = 3 * 4 * 256 / (maps > 0 ? maps : 1) - border_blocks;
+    static const int cap_pct = getenv("TE_NR_CAP") ? atoi(getenv("TE_NR_CAP")) : 100;  // EXPERIMENT
+    const int capacity = (kNormWaves * 4 * 256 * cap_pct / 100) / (maps > 0 ? maps : 1) - border_blocks;
     const int nbx_in = (ir - il + kLanes - 1) / kLanes;
     int strips = capacity / nbx_in;
     strips = strips < 1 ? 1 : strips;
@@ -538,7 +601,10 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   if (d.n_ties != 0 || d.R < 1 || d.R > 16 || d.npoints < 3) return false;
   SlideArgs a;
   int sii = 0;
-  for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = k <= d.R ? d.hw[k] : -1;
+  for (int k = 0; k <= kMaxRadiusCells; ++k) {
+    a.h[k] = k <= d.R ? d.hw[k] : -1;
+    a.hd[k] = (double)a.h[k];
+  }
   for (int dj = -d.R; dj <= d.R; ++dj) {
     const int hw = d.hw[dj < 0 ? -dj : dj];
     for (int di = -hw; di <= hw; ++di) sii += di * di;
