@@ -16,6 +16,7 @@
 //             lane walks the host-built spiral table (SpiralIterator order) over the rows already staged
 //             in LDS until the first untraversable cell, exactly like isTraversable().
 #include "te_internal.h"
+#include "te_march.h"
 
 namespace te {
 
@@ -128,40 +129,31 @@ __device__ __forceinline__ float fceil_d(double T) {
 
 // Screening pass of checkForStep entirely on the LDS tiles (cells outside the map are NaN there, which
 // fails every comparison exactly like being skipped).  The window of circle(2.5*res) and the 3x3
-// submaps around its candidates lie within 3 cells of the centre.  Returns true when no submap cell
-// satisfies the "lower step" condition of :825, in which case checkForStep passes without any of its
-// ray/line geometry; otherwise the full function decides.
+// submaps around its candidates lie within 3 cells of the centre.
+//   tkey[n] = elevation of n where its step score is 0, NaN elsewhere: n is a candidate of centre c iff
+//             tkey[n] > elev[c] + crit_step (:807-809)
+//   tkl[n]  = tkey[n] where additionally some cell of the 3x3 block around n has step 0 and lies more than
+//             crit_step below n (the hit condition of :825, a property of n alone), NaN elsewhere
+// so "some candidate has a lower step neighbour" is  max over the window of tkl > thr  and "there is a
+// candidate" is  max over the window of tkey > thr  (NaN-ignoring maxima).  Without a candidate the
+// centre itself is examined (:811); its step score is 0 here, so its flag is "tkl[c] is not NaN".
+// Returns true when no submap cell satisfies :825, in which case checkForStep passes without any of its
+// ray/line geometry; otherwise the full function decides.  General disc shapes: plain loop.
 __device__ __forceinline__ bool check_step_screen(const Disc& d, const float* __restrict__ te,
-                                                  const float* __restrict__ tkey,
-                                                  const unsigned char* __restrict__ tlow, int ctr, double crit_step) {
+                                                  const float* __restrict__ tkey, const float* __restrict__ tkl,
+                                                  int ctr, double crit_step) {
   if (d.n_ties) return false;
   const float thr = ffloor_d(crit_step + (double)te[ctr]);
   bool any_cand = false, hit = false;
-  if (d.Q == 5) {  // circle(2.5*res) is always this 21-cell shape (di^2+dj^2 <= 5): fully unrolled, immediate offsets
-#pragma unroll
-    for (int dj = -2; dj <= 2; ++dj) {
-#pragma unroll
-      for (int di = -2; di <= 2; ++di) {
-        if (di * di + dj * dj > 5) continue;
-        const int idx = ctr + dj * MTW + di;
-        const bool cand = tkey[idx] > thr;
-        any_cand |= cand;
-        hit |= cand && (tlow[idx] != 0);
-      }
-    }
-    if (!any_cand) hit = (tlow[ctr] != 0);
-    return !hit;
-  }
   for (int dj = -d.R; dj <= d.R; ++dj) {
     const int hw = d.hw[dj < 0 ? -dj : dj];
     for (int di = -hw; di <= hw; ++di) {
       const int idx = ctr + dj * MTW + di;
-      const bool cand = tkey[idx] > thr;  // :807-809 higher than the centre by more than crit_step, step score 0
-      any_cand |= cand;
-      hit |= cand && (tlow[idx] != 0);
+      any_cand |= tkey[idx] > thr;
+      hit |= tkl[idx] > thr;
     }
   }
-  if (!any_cand) hit = (tlow[ctr] != 0);  // :811 no candidate: the centre cell itself
+  if (!any_cand) hit = tkl[ctr] == tkl[ctr];
   return !hit;
 }
 
@@ -268,12 +260,10 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
                                                      const float* __restrict__ rough, uint8_t* __restrict__ untrav,
                                                      float* __restrict__ slope_fp, float* __restrict__ step_fp,
                                                      float* __restrict__ rough_fp, float* __restrict__ trav) {
-  // t_elev = elevation; t_key = elevation where the step score is 0 (NaN elsewhere; NaN outside the map);
-  // t_low[n] = "some cell of the 3x3 block around n has step 0 and lies more than crit_step below n"
-  // (the hit condition of :825, a property of n alone).  Slope / roughness scores are only needed at the
-  // centre cell (plus, for the rare zero scores, their window): they are read straight from global memory.
-  __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH];
-  __shared__ unsigned char t_low[MTW * MTH];
+  // t_elev = elevation; t_key / t_kl: see check_step_screen (NaN outside the map).  Slope / roughness scores
+  // are only needed at the centre cell (plus, for the rare zero scores, their window): they are read
+  // straight from global memory.
+  __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
   const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
   {
@@ -311,46 +301,84 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     bool hit = false;
     if (la >= 1 && la < MTW - 1 && lb >= 1 && lb < MTH - 1) {
       const float lo = fceil_d((double)t_elev[idx] - a.crit_step);
-#pragma unroll
-      for (int b = -1; b <= 1; ++b)
-#pragma unroll
-        for (int aa = -1; aa <= 1; ++aa) hit |= t_key[idx + b * MTW + aa] < lo;
+      const float* k = t_key + idx;  // NaN-ignoring minimum of the 3x3 block
+      const float m = fast::vmin3(fast::vmin3(k[-MTW - 1], k[-MTW], k[-MTW + 1]), fast::vmin3(k[-1], k[0], k[1]),
+                                  fast::vmin3(k[MTW - 1], k[MTW], k[MTW + 1]));
+      hit = m < lo;
     }
-    t_low[idx] = hit ? 1 : 0;
+    t_kl[idx] = hit ? t_key[idx] : qnanf();
   }
   __syncthreads();
   const TileView ve = {t_elev, elev + mo, i0, j0, g.rows}, vs = {nullptr, step + mo, i0, j0, g.rows},
                  vl = {nullptr, slope + mo, i0, j0, g.rows}, vr = {nullptr, rough + mo, i0, j0, g.rows};
   const int i = i0 + threadIdx.x;
   if (i >= g.rows) return;
+  // Every thread walks MY/MBY consecutive rows of its column.  For the 21-cell window of circle(2.5*res)
+  // (di^2+dj^2 <= 5: rows dj=0,+-1 span |di|<=2, rows dj=+-2 span |di|<=1) the two window maxima slide:
+  // each tile row is reduced once along i (H1 = max over |di|<=1, H2 = max over |di|<=2: 5 LDS reads and
+  // 2 v_max3 per array) and an output combines the run values of its 5 rows with 2 more v_max3.
+  constexpr int NC = MY / MBY;
+  const bool q5 = a.step_disc.Q == 5 && a.step_disc.n_ties == 0;
+  const int jb = threadIdx.y * NC;  // first tile row of this thread
   // the scores of my cells are fetched one cell ahead (clamped addresses)
   auto fetch = [&](int c, float& fs, float& ft, float& fr) {
-    int j = j0 + threadIdx.y + c * MBY;
+    int j = j0 + jb + c;
     j = j < g.cols ? j : g.cols - 1;
     const size_t o = mo + (size_t)j * g.rows + i;
     fs = slope[o];
     ft = step[o];
     fr = (a.check_rough || a.combine) ? rough[o] : 1.0f;
   };
+  float h1k[5], h2k[5], h1l[5], h2l[5];  // run maxima of the last 5 tile rows (slot = row mod 5)
+  auto reduce_row = [&](int row, int slot) {  // tile row jb + row (window rows start 2 above the outputs)
+    const int base = (jb + row + MH) * MTW + (threadIdx.x + MH);
+    const float* k = t_key + base;
+    const float* l = t_kl + base;
+    h1k[slot] = fast::vmax3(k[-1], k[0], k[1]);
+    h2k[slot] = fast::vmax3(h1k[slot], k[-2], k[2]);
+    h1l[slot] = fast::vmax3(l[-1], l[0], l[1]);
+    h2l[slot] = fast::vmax3(h1l[slot], l[-2], l[2]);
+  };
+  unsigned screen_mask = 0;  // bit c: the screening pass clears my c-th cell
+  if (q5) {
+    fast::static_for<4>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      reduce_row(r - 2, r);  // rows -2 .. 1
+    });
+    fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int s2 = (c + 4) % 5;  // slot of row c+2
+      reduce_row(c + 2, s2);
+      constexpr int sm2 = c % 5, sm1 = (c + 1) % 5, s0 = (c + 2) % 5, s1 = (c + 3) % 5;
+      const float mk = fast::vmax3(fast::vmax3(h1k[sm2], h2k[sm1], h2k[s0]), h2k[s1], h1k[s2]);
+      const float ml = fast::vmax3(fast::vmax3(h1l[sm2], h2l[sm1], h2l[s0]), h2l[s1], h1l[s2]);
+      const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
+      const float thr = ffloor_d(a.crit_step + (double)t_elev[ctr]);
+      const float lc = t_kl[ctr];
+      const bool hit = (mk > thr) ? (ml > thr) : (lc == lc);
+      screen_mask |= hit ? 0u : (1u << c);
+    });
+  }
   float n_slope, n_step, n_rough;
   fetch(0, n_slope, n_step, n_rough);
 #pragma unroll 1
-  for (int c = 0; c < MY / MBY; ++c) {
-    const int j = j0 + threadIdx.y + c * MBY;
+  for (int c = 0; c < NC; ++c) {
+    const int j = j0 + jb + c;
     if (j >= g.cols) break;
     const size_t o = mo + (size_t)j * g.rows + i;
     const float c_slope = n_slope, c_step = n_step, c_rough = n_rough;
     fetch(c + 1, n_slope, n_step, n_rough);
     float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
     bool ok = true;
-    const int ctr = (threadIdx.y + c * MBY + MH) * MTW + (threadIdx.x + MH);
+    const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
     if (c_slope == 0.0f) {  // checkForSlope
       ok = count_zero_ok(g, a.slope_disc, vl, i, j, a.ncrit_slope);
       m_slope = ok ? 1.0f : 0.0f;
     }
     if (ok && c_step == 0.0f) {  // checkForStep
-      ok = check_step_screen(a.step_disc, t_elev, t_key, t_low, ctr, a.crit_step) ||
-           check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap);
+      const bool screen_ok = q5 ? ((screen_mask >> c) & 1u) != 0
+                                : check_step_screen(a.step_disc, t_elev, t_key, t_kl, ctr, a.crit_step);
+      ok = screen_ok || check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap);
       m_step = ok ? 1.0f : 0.0f;
     }
     if (ok && a.check_rough && c_rough == 0.0f) {  // checkForRoughness
