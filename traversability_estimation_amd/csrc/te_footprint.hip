@@ -296,17 +296,41 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.y * MX + threadIdx.x; idx < MTW * MTH; idx += MX * MBY) {
-    const int lb = idx / MTW, la = idx - lb * MTW;
-    bool hit = false;
-    if (la >= 1 && la < MTW - 1 && lb >= 1 && lb < MTH - 1) {
-      const float lo = fceil_d((double)t_elev[idx] - a.crit_step);
-      const float* k = t_key + idx;  // NaN-ignoring minimum of the 3x3 block
+  {
+    // t_kl for the tile cells the windows can reach (rows 1..MTH-2, columns 1..MTW-2): the 3x3 minimum of
+    // t_key slides down a column (row minimum of 3 cells, then the minimum of 3 consecutive rows).
+    // Columns 2..65 are walked by the 64 lanes (MTH-2 = 36 rows in MBY segments of 9); the four remaining
+    // columns are done cell by cell.
+    static_assert((MTH - 2) % MBY == 0, "row segments");
+    constexpr int SEG = (MTH - 2) / MBY;
+    const int la = threadIdx.x + 2, r0 = 1 + threadIdx.y * SEG;
+    float rm[3];
+    auto row_min = [&](int r) {
+      const float* k = t_key + r * MTW + la;
+      return fast::vmin3(k[-1], k[0], k[1]);
+    };
+    rm[0] = row_min(r0 - 1);
+    rm[1] = row_min(r0);
+    fast::static_for<SEG>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int q = decltype(rc)::value;
+      const int r = r0 + q;
+      const float next = row_min(r + 1);  // slots rotate with q: rows r-1, r, r+1 in rm[q%3], rm[(q+1)%3], rm[(q+2)%3]
+      const float m = fast::vmin3(rm[q % 3], rm[(q + 1) % 3], next);
+      rm[(q + 2) % 3] = next;
+      const int idx = r * MTW + la;
+      const bool hit = (double)m < (double)t_elev[idx] - a.crit_step;  // :825 in the reference's double arithmetic
+      t_kl[idx] = hit ? t_key[idx] : qnanf();
+    });
+    const int tid = threadIdx.y * MX + threadIdx.x;
+    if (tid < 4 * (MTH - 2)) {
+      const int col = (tid & 3) == 0 ? 1 : MTW - 5 + (tid & 3);  // 1, MTW-4, MTW-3, MTW-2
+      const int idx = (1 + (tid >> 2)) * MTW + col;
+      const float* k = t_key + idx;
       const float m = fast::vmin3(fast::vmin3(k[-MTW - 1], k[-MTW], k[-MTW + 1]), fast::vmin3(k[-1], k[0], k[1]),
                                   fast::vmin3(k[MTW - 1], k[MTW], k[MTW + 1]));
-      hit = m < lo;
+      const bool hit = (double)m < (double)t_elev[idx] - a.crit_step;
+      t_kl[idx] = hit ? t_key[idx] : qnanf();
     }
-    t_kl[idx] = hit ? t_key[idx] : qnanf();
   }
   __syncthreads();
   const TileView ve = {t_elev, elev + mo, i0, j0, g.rows}, vs = {nullptr, step + mo, i0, j0, g.rows},
@@ -353,9 +377,9 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       const float mk = fast::vmax3(fast::vmax3(h1k[sm2], h2k[sm1], h2k[s0]), h2k[s1], h1k[s2]);
       const float ml = fast::vmax3(fast::vmax3(h1l[sm2], h2l[sm1], h2l[s0]), h2l[s1], h1l[s2]);
       const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
-      const float thr = ffloor_d(a.crit_step + (double)t_elev[ctr]);
+      const double thr = a.crit_step + (double)t_elev[ctr];  // :807 (double comparison, like the reference)
       const float lc = t_kl[ctr];
-      const bool hit = (mk > thr) ? (ml > thr) : (lc == lc);
+      const bool hit = ((double)mk > thr) ? ((double)ml > thr) : (lc == lc);
       screen_mask |= hit ? 0u : (1u << c);
     });
   }
