@@ -200,6 +200,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     if world > 1:
+        barrier()  # rank 0 is still timing the CPU baseline: leave the group together
         dist.destroy_process_group()
 
 
