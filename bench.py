@@ -93,7 +93,9 @@ def main():
     from traversability_estimation_amd import capi, synth
 
     from traversability_estimation_amd import dist as tdist
-    rank, world, local_rank = tdist.init_process_group()
+    # TE_DIST_BACKEND=gloo lets a 1-GPU box exercise the N>1 code path (ranks then share device 0)
+    rank, world, local_rank = tdist.init_process_group(os.environ.get("TE_DIST_BACKEND"))
+    local_rank %= max(1, torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
