@@ -271,18 +271,13 @@ void launch_score(const Geo& g, double crit, float crit_lo, int ncrit, const flo
 
 }  // namespace
 
-#define TE_STEP_SHAPES(X) \
-  X(0) X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
-  X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
-  X(89) X(90) X(97) X(98) X(100)
-
 bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
   switch (Q) {
 #define X(q) \
   case q:    \
     launch_height<q>(g, elev, sh, r, s); \
     return true;
-    TE_STEP_SHAPES(X)
+    TE_DISC_SHAPES(X)
 #undef X
     default:
       return false;
@@ -299,7 +294,7 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
   case q:    \
     launch_score<q>(g, crit, lo, ncrit, sh, out, r, s); \
     return true;
-    TE_STEP_SHAPES(X)
+    TE_DISC_SHAPES(X)
 #undef X
     default:
       return false;

@@ -443,7 +443,11 @@ struct SpiralArgs {
 constexpr double kUOff = 4096.0;
 constexpr int kFpWaves = 2;  // waves per SIMD k_fp_slide is compiled for; the launcher fills exactly these slots
 
-template <int R>
+// Q >= 0: the (tie-free) disc shape is the compile-time shape fast::Shape<Q> (R == Shape<Q>::R): the ring
+// rows of every column are then fixed positions of a rotating table of row offsets and the per-row
+// wrap-around bookkeeping (3 scalar instructions per column and row) disappears.  Q < 0: run table from
+// the arguments (any radius up to 20 cells, tie radii).
+template <int R, int Q>
 __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs a, const float* __restrict__ trav,
                                                      const uint8_t* __restrict__ untrav,
                                                      float* __restrict__ footprint) {
@@ -499,12 +503,19 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
   // ring offsets (in doubles) of the leading (j+1+h) / trailing (j-h) row of disc column |di| = d for the
   // NEXT fetch; a column outside the tie-free disc (h < 0: only tie offsets reach it) reads the same row
   // twice, so it contributes exactly 0
+  constexpr bool kStatic = Q >= 0;
   int lead[R + 1], trail[R + 1];
+  int rowoff[NR];  // kStatic: ring offset (in doubles) of row j-R+k of the step the next fetch belongs to
+  if (kStatic) {
 #pragma unroll
-  for (int d = 0; d <= R; ++d) {
-    const int h = a.h[d];
-    lead[d] = h >= 0 ? ((1 + h) % NR) * W : 0;
-    trail[d] = h >= 0 ? ((NR - h) % NR) * W : 0;
+    for (int k = 0; k < NR; ++k) rowoff[k] = ((k - R + NR) % NR) * W;
+  } else {
+#pragma unroll
+    for (int d = 0; d <= R; ++d) {
+      const int h = a.h[d];
+      lead[d] = h >= 0 ? ((1 + h) % NR) * W : 0;
+      trail[d] = h >= 0 ? ((NR - h) % NR) * W : 0;
+    }
   }
   float ptq[kAhead][NX];
   int puq[kAhead][NX];
@@ -516,16 +527,29 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     double lp[R + 1], lm[R + 1], tp[R + 1], tm[R + 1];
   };
   auto fetch = [&](Vals& v) {
+    if constexpr (kStatic) {
+      fast::static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int h = fast::Shape<Q>::hw(d);
+        const double* rl = ring + rowoff[R + 1 + h] + c;  // row j+1+h
+        const double* rt = ring + rowoff[R - h] + c;      // row j-h
+        v.lp[d] = rl[d];
+        v.tp[d] = rt[d];
+        v.lm[d] = d ? rl[-d] : 0.0;
+        v.tm[d] = d ? rt[-d] : 0.0;
+      });
+    } else {
 #pragma unroll
-    for (int d = 0; d <= R; ++d) {
-      const double* rl = ring + lead[d] + c;
-      const double* rt = ring + trail[d] + c;
-      v.lp[d] = rl[d];
-      v.tp[d] = rt[d];
-      v.lm[d] = d ? rl[-d] : 0.0;
-      v.tm[d] = d ? rt[-d] : 0.0;
-      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
-      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+      for (int d = 0; d <= R; ++d) {
+        const double* rl = ring + lead[d] + c;
+        const double* rt = ring + trail[d] + c;
+        v.lp[d] = rl[d];
+        v.tp[d] = rt[d];
+        v.lm[d] = d ? rl[-d] : 0.0;
+        v.tm[d] = d ? rt[-d] : 0.0;
+        lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
+        trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+      }
     }
   };
   auto consume = [&](const Vals& v) {
@@ -540,6 +564,14 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     sr = sr >= NR ? sr - NR : sr;
     store_row(j + 2 + R, sr, pt, pu);
     load_row(j + 2 + R + kAhead, pt, pu);
+    if constexpr (kStatic) {  // the table now describes step j+1: the oldest row's slot is the newest row's
+      const int oldest = rowoff[0];
+      fast::static_for<NR - 1>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        rowoff[k] = rowoff[k + 1];
+      });
+      rowoff[NR - 1] = oldest;
+    }
     if (kPipe) {
       fetch(next);
       consume(cur);
@@ -703,10 +735,26 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   }
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
                   (unsigned)g.batch);
+  if (d.n_ties == 0 && d.Q >= 1) {  // tie-free disc of an instantiated shape: compile-time run table
+    switch (d.Q) {
+#define X(q)                                                                                                       \
+  case q:                                                                                                          \
+    if constexpr (q >= 1) {                                                                                        \
+      hipLaunchKernelGGL((k_fp_slide<fast::Shape<q>::R, q>), grid, dim3(kLanes), 0, stream, g, a, L.trav, L.untrav, \
+                         L.footprint);                                                                             \
+      return hipGetLastError();                                                                                    \
+    }                                                                                                              \
+    break;
+      TE_DISC_SHAPES(X)
+#undef X
+      default:
+        break;
+    }
+  }
   switch (p.reach) {
 #define X(q) \
   case q:    \
-    hipLaunchKernelGGL(k_fp_slide<q>, grid, dim3(kLanes), 0, stream, g, a, L.trav, L.untrav, L.footprint); \
+    hipLaunchKernelGGL((k_fp_slide<q, -1>), grid, dim3(kLanes), 0, stream, g, a, L.trav, L.untrav, L.footprint); \
     break;
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
 #undef X
