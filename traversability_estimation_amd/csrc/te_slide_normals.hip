@@ -26,8 +26,8 @@
 // lanes next to the left/right border) are left NaN and flagged; the general kernel recomputes just
 // those cells afterwards (te_kernels.hip: k_normals_fixup).  Invalid cells are staged as 0, so the
 // exact sums recover as soon as the hole has left the window.
-#include <cstdlib>
 #include "te_internal.h"
+#include "te_march.h"
 
 namespace te {
 namespace fast {
@@ -36,8 +36,6 @@ namespace {
 
 // waves per SIMD k_normals_slide is compiled for; launch_r sizes the interior strips to fill exactly these slots in one round
 constexpr int kNormWaves = 2;
-
-constexpr int kLanes = 64;
 
 struct SlideArgs {
   int h[kMaxRadiusCells + 1];  // half-height of disc column |di| (== half-width of row |dj|)
@@ -215,7 +213,10 @@ constexpr int ring_rows(int R) {
 // staging of row j+1+R, slide to row j+1 -- is ONE straight-line block (loads use clamped addresses,
 // LDS writes are unconditional), so the latency-bound tail overlaps with the issue-bound slide; the
 // predicated global stores of row j come last.
-template <int R, bool BORDER>
+// Q >= 0: the disc is the compile-time shape Shape<Q> (R == Shape<Q>::R): run half-heights are literals and
+// the ring rows come from a rotating table of row offsets (no per-column wrap bookkeeping).  Q < 0: run
+// table from the arguments (any tie-free radius up to 16 cells).
+template <int R, int Q, bool BORDER>
 __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, const SlideArgs& a, int k,
                                       const float* __restrict__ elev, const float* __restrict__ step,
                                       float* __restrict__ slope, float* __restrict__ rough, float* __restrict__ trav,
@@ -308,19 +309,23 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   double nm1 = (double)a.np / (double)(a.np > 1 ? a.np - 1 : 1);
   double nres = -g.res;
   asm volatile("" : "+v"(inv_np), "+v"(cxx), "+v"(nm1), "+v"(nres));
+  constexpr bool kStatic = Q >= 0;
   double hdv[R + 1];
 #pragma unroll
   for (int d = 0; d <= R; ++d) {
-    hdv[d] = a.hd[d];
-    asm volatile("" : "+v"(hdv[d]));
+    hdv[d] = kStatic ? 0.0 : a.hd[d];
+    if (!kStatic) asm volatile("" : "+v"(hdv[d]));
   }
   // the same for the output pointers (per-lane element 0 of this strip's map)
-  float* v_slope = slope + mo;
-  float* v_rough = rough + mo;
-  float* v_trav = trav + mo;
-  float* v_nx = onx ? onx + mo : nullptr;
-  float* v_ny = onx ? ony + mo : nullptr;
-  float* v_nz = onx ? onz + mo : nullptr;
+  // (typed as global-address-space pointers: through the asm the compiler would otherwise lose the address
+  // space and emit flat stores, which also count as LDS operations for s_waitcnt)
+  typedef float __attribute__((address_space(1))) gfloat;
+  gfloat* v_slope = (gfloat*)(slope + mo);
+  gfloat* v_rough = (gfloat*)(rough + mo);
+  gfloat* v_trav = (gfloat*)(trav + mo);
+  gfloat* v_nx = (gfloat*)(onx ? onx + mo : nullptr);
+  gfloat* v_ny = (gfloat*)(onx ? ony + mo : nullptr);
+  gfloat* v_nz = (gfloat*)(onx ? onz + mo : nullptr);
   asm volatile("" : "+v"(v_slope), "+v"(v_rough), "+v"(v_trav), "+v"(v_nx), "+v"(v_ny), "+v"(v_nz));
   const float slope_critf = (float)a.slope_crit, inv_slope_critf = (float)a.inv_slope_crit;
   const float rough_critf = (float)a.rough_crit, inv_rough_critf = (float)a.inv_rough_crit;
@@ -329,11 +334,17 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
 
   // ring offsets (in doubles) of the leading / trailing row of disc column |di| = d, advanced every step
   int lead[R + 1], trail[R + 1];
+  int rowoff[NR];  // kStatic: ring offset (in doubles) of row j-R+k of the current step
+  if (kStatic) {
 #pragma unroll
-  for (int d = 0; d <= R; ++d) {
-    const int h = a.h[d];
-    lead[d] = ((1 + h) % NR) * W;
-    trail[d] = ((NR - h) % NR) * W;
+    for (int k = 0; k < NR; ++k) rowoff[k] = ((k - R + NR) % NR) * W;
+  } else {
+#pragma unroll
+    for (int d = 0; d <= R; ++d) {
+      const int h = a.h[d];
+      lead[d] = ((1 + h) % NR) * W;
+      trail[d] = ((NR - h) % NR) * W;
+    }
   }
   float pfq[kAhead][NX];
   float stq[kAhead];
@@ -354,25 +365,40 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   struct Vals {
     double lp[R + 1], lm[R + 1], tp[R + 1], tm[R + 1];  // leading / trailing row, column +d / -d
   };
-  auto fetch = [&](Vals& v, auto lo, auto hi) {
+  // `ahead` = 1: the reads belong to the step after the one the row table describes
+  auto fetch = [&](Vals& v, auto lo, auto hi, auto ahead) {
+    if constexpr (kStatic) {
+      constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+      static_for<HI - LO + 1>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = LO + decltype(dc)::value;
+        constexpr int h = Shape<Q>::hw(d);
+        // columns +d and -d of the disc share their leading row (j+1+h) and trailing row (j-h)
+        const double* rl = ring + rowoff[R + 1 + h + decltype(ahead)::value] + c;
+        const double* rt = ring + rowoff[R - h + decltype(ahead)::value] + c;
+        v.lp[d] = rl[d];
+        v.tp[d] = rt[d];
+        v.lm[d] = d ? rl[-d] : 0.0;
+        v.tm[d] = d ? rt[-d] : 0.0;
+      });
+    } else {
 #pragma unroll
-    for (int d = decltype(lo)::value; d <= decltype(hi)::value; ++d) {
-      // columns +d and -d of the disc share their leading row (j+1+h) and trailing row (j-h)
-      const double* rl = ring + lead[d] + c;
-      const double* rt = ring + trail[d] + c;
-      v.lp[d] = rl[d];
-      v.tp[d] = rt[d];
-      v.lm[d] = d ? rl[-d] : 0.0;
-      v.tm[d] = d ? rt[-d] : 0.0;
-      lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
-      trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+      for (int d = decltype(lo)::value; d <= decltype(hi)::value; ++d) {
+        const double* rl = ring + lead[d] + c;
+        const double* rt = ring + trail[d] + c;
+        v.lp[d] = rl[d];
+        v.tp[d] = rt[d];
+        v.lm[d] = d ? rl[-d] : 0.0;
+        v.tm[d] = d ? rt[-d] : 0.0;
+        lead[d] = lead[d] + W >= NR * W ? 0 : lead[d] + W;
+        trail[d] = trail[d] + W >= NR * W ? 0 : trail[d] + W;
+      }
     }
   };
   double sj = 0.0;
   auto consume = [&](const Vals& q, auto lo, auto hi) {
 #pragma unroll
     for (int d = decltype(lo)::value; d <= decltype(hi)::value; ++d) {
-      const double hh = hdv[d];
+      const double hh = kStatic ? (double)Shape<Q < 0 ? 0 : Q>::hw(d <= Shape<Q < 0 ? 0 : Q>::R ? d : 0) : hdv[d];
       {
         const double zl = q.lp[d], zt = q.tp[d];
         const double u = zl - zt, v = zl + zt;
@@ -392,6 +418,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     }
   };
   using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
   using IA = std::integral_constant<int, RA>;
   using IB = std::integral_constant<int, RA + 1>;
   using IR = std::integral_constant<int, R>;
@@ -405,18 +432,26 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     load_row(j + 2 + R + kAhead, pf);
     st = load_step(j + kAhead);
     sj = 0.0;
-    if (RA < R) fetch(vals, IB{}, IR{});  // group B of step j
-    consume(vals, I0{}, IA{});            // group A of step j (read during step j-1)
-    fetch(vals, I0{}, IA{});              // group A of step j+1 (needs row j+2+R, staged above)
+    if (RA < R) fetch(vals, IB{}, IR{}, I0{});  // group B of step j
+    consume(vals, I0{}, IA{});                  // group A of step j (read during step j-1)
+    fetch(vals, I0{}, IA{}, I1{});              // group A of step j+1 (needs row j+2+R, staged above)
     if (RA < R) consume(vals, IB{}, IR{});
     Sjz = (Sjz + sj) - Sz;
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
+    if constexpr (kStatic) {  // the table moves on to step j+1: the oldest row's slot takes the next new row
+      const int oldest = rowoff[0];
+      static_for<NR - 1>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        rowoff[k] = rowoff[k + 1];
+      });
+      rowoff[NR - 1] = oldest;
+    }
   };
   {  // row jstart+1+R (the first that can be real); everything above is a virtual zero row
     float pf0[NX];
     load_row(jstart + 1 + R, pf0);
     store_row(jstart + 1 + R, (1 + R) % NR, pf0);
-    fetch(vals, I0{}, IA{});
+    fetch(vals, I0{}, IA{}, I0{});
   }
 
 #pragma unroll 1
@@ -514,7 +549,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   }
 }
 
-template <int R>
+template <int R, int Q>
 __global__ __launch_bounds__(kLanes, kNormWaves) void k_normals_slide(Geo g, SlideArgs a, const float* __restrict__ elev,
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
@@ -527,9 +562,9 @@ __global__ __launch_bounds__(kLanes, kNormWaves) void k_normals_slide(Geo g, Sli
   for (int t = 1; t < 5; ++t)
     if (t < a.nsub && (int)blockIdx.x >= a.sub[t].first) k = t;
   if (a.sub[k].border)
-    march<R, true>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
+    march<R, Q, true>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
   else
-    march<R, false>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
+    march<R, Q, false>(ring, g, a, k, elev, step, slope, rough, trav, onx, ony, onz, tile_flags, rg);
 }
 
 constexpr int kStripRows = 128;       // interior strips
@@ -538,7 +573,7 @@ constexpr int kBorderStripRows_unused = 32;  // the clipped-disc tail is slower:
 
 // Split the region into the frame (clipped discs; launched first, short strips) and the cells whose
 // disc lies inside the map; every rectangle keeps its 64-column blocks aligned to r.i0.
-template <int R>
+template <int R, int Q>
 void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Region& r, int* flags, hipStream_t s) {
   const int ja = r.j0 > R ? r.j0 : (R < r.j1 ? R : r.j1);                      // first interior row
   const int jb = r.j1 < g.cols - R ? r.j1 : (g.cols - R > ja ? g.cols - R : ja);  // one past the last
@@ -586,7 +621,7 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
   a.nsub = n;
   for (int t = n; t < 5; ++t) a.sub[t] = a.sub[n ? n - 1 : 0];
   if (first == 0) return;
-  hipLaunchKernelGGL(k_normals_slide<R>, dim3((unsigned)first, 1, (unsigned)(r.map >= 0 ? 1 : g.batch)), dim3(kLanes),
+  hipLaunchKernelGGL((k_normals_slide<R, Q>), dim3((unsigned)first, 1, (unsigned)(r.map >= 0 ? 1 : g.batch)), dim3(kLanes),
                      0, s, g, a, L.elev, L.step, L.slope, L.rough, L.trav, keep ? L.nx : nullptr,
                      keep ? L.ny : nullptr, keep ? L.nz : nullptr, flags, r);
 }
@@ -630,10 +665,25 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.gtab = gtab;
   if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
   (void)hipMemsetAsync(flags, 0, sizeof(int) * (size_t)fg->ntx * fg->nty * fg->nbz, s);
+  if (d.Q >= 1) {  // instantiated shape: compile-time run table
+    switch (d.Q) {
+#define X(q)                                                              \
+  case q:                                                                 \
+    if constexpr (q >= 1) {                                               \
+      launch_r<Shape<q>::R, q>(g, a, L, keep_normals, r, flags, s);       \
+      return true;                                                        \
+    }                                                                     \
+    break;
+      TE_DISC_SHAPES(X)
+#undef X
+      default:
+        break;
+    }
+  }
   switch (d.R) {
 #define X(q) \
   case q:    \
-    launch_r<q>(g, a, L, keep_normals, r, flags, s); \
+    launch_r<q, -1>(g, a, L, keep_normals, r, flags, s); \
     return true;
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X
