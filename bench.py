@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-footprint", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the oracle with OpenMP on all host cores")
     ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
     ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
     return ap.parse_args()
@@ -54,15 +55,15 @@ def make_params(capi, synth, args):
                                fp_offset=synth.benchmark_radius(3.0, args.res))
 
 
-def cpu_baseline(args, elev_full, p, with_footprint):
-    """Time the CPU oracle (single thread, like the reference) on a bounded crop of the same map."""
+def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
+    """Time the CPU oracle (single thread, like the reference; or OpenMP over rows) on a bounded crop of the same map."""
     from oracle import oracle as O
     from tests.helpers import OUT_LAYERS  # noqa: F401
     op = O.default_params()
     for f, _ in op._fields_:
         setattr(op, f, getattr(p, f))
-    O.set_threads(1)
-    n = 128
+    O.set_threads(threads)
+    n = 128 if threads == 1 else 512
     g = O.geom(n, n, args.res)
     crop = np.ascontiguousarray(elev_full[:n, :n])
     t0 = time.perf_counter()
@@ -82,9 +83,10 @@ def cpu_baseline(args, elev_full, p, with_footprint):
     if with_footprint:
         O.footprint(g, op, crop, out)
     dt = time.perf_counter() - t0
-    return {"value": n * n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+    return {"value": n * n / dt, "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"{n}x{n} crop of the same map, full chain{'+footprint' if with_footprint else ''}, "
-                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores (oracle/te_oracle.c, -O3)"}
+                      f"{dt:.1f} s on {threads} of {os.cpu_count()} host cores (oracle/te_oracle.c, -O3"
+                      f"{', OpenMP over rows' if threads > 1 else ''})"}
 
 
 def main():
@@ -137,6 +139,26 @@ def main():
 
     # kernel-only duration of the chain: HIP events on the context's own stream
     ms_chain = ctx.time_chain(flags, warmup=1, iters=max(5, min(args.steps, 50)))
+
+    # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
+    host_path = None
+    if rank == 0:
+        stack = np.stack(elevs)
+        names = ["traversability_slope", "traversability_step", "traversability_roughness", "traversability"]
+        if with_fp:
+            names.append("traversability_footprint")
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.upload_elevation(stack)
+            ctx.run_chain(flags)
+            outs = [ctx.download(k) for k in names]
+            ctx.sync()
+            d = time.perf_counter() - t0
+            best = d if best is None or d < best else best
+        del outs
+        host_path = {"ms": best * 1e3, "cells_per_s": B * n * n / best,
+                     "what": f"upload elevation + chain + download {len(names)} layers through pageable host buffers, best of 3"}
 
     check = None
     if args.check and rank == 0:
@@ -195,8 +217,11 @@ def main():
         if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0:
             out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes"]
             out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
+        out["host_path"] = host_path
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
+            if args.cpu_all_cores:  # extra, not part of the contract: the same oracle on every host core
+                out["cpu_baseline_all_cores"] = cpu_baseline(args, elevs[0], p, with_fp, threads=os.cpu_count() or 1)
         if check is not None:
             out["parity_check"] = {k: {"mismatches": v[0], "max_abs_err": v[1]} for k, v in check.items()}
         print(json.dumps(out))
