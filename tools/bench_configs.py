@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Measures the BASELINE.json configurations that are not the bench.py headline (which is configs[2]):
+
+  cfg2  one 1024 x 1024 map, radius 5 cells                       (launch-latency regime)
+  cfg4  a batch of 512 x 512 maps, radius 5 cells, one launch     (the batch axis, what multi-GPU shards)
+  cfg5  8192 x 8192 resident map, 256 x 256 dirty tiles per tick  (te_upload_tile + te_run_chain_region)
+
+Prints one JSON object; the committed copy is profiles/r01_configs.json.  Needs an MI355X.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def params(capi, synth, cells, res):
+    r = synth.benchmark_radius(cells, res)
+    return capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                               fp_radius=synth.benchmark_radius(6.0, res), fp_offset=synth.benchmark_radius(3.0, res))
+
+
+def main():
+    from traversability_estimation_amd import capi, synth
+    capi.load()
+    res = 0.05
+    out = {}
+
+    # ---- cfg2 -----------------------------------------------------------------------------------------------
+    n = 1024
+    with capi.Context(0) as c:
+        c.set_params(params(capi, synth, 5.0, res))
+        c.set_geometry(n, n, 1, res)
+        c.upload_elevation(synth.perlin_elevation(n, n, seed=1234))
+        for flags, name in ((0, "chain"), (capi.RUN_FOOTPRINT, "chain+footprint")):
+            ms = c.time_chain(flags, warmup=5, iters=100)
+            out[f"cfg2 1024x1024 R5 {name}"] = {"ms_per_launch": ms, "cells_per_s": n * n / (ms * 1e-3)}
+
+    # ---- cfg4 -----------------------------------------------------------------------------------------------
+    n, B = 512, int(os.environ.get("TE_CFG4_MAPS", "512"))
+    base = synth.perlin_elevation(n, n, seed=2000)
+    rng = np.random.default_rng(2000)
+    maps = (base[None, :, :] + rng.normal(0.0, 0.01, size=(B, n, n)).astype(np.float32)).astype(np.float32)
+    with capi.Context(0) as c:
+        c.set_params(params(capi, synth, 5.0, res))
+        c.set_geometry(n, n, B, res)
+        c.upload_elevation(maps)
+        for flags, name in ((0, "chain"), (capi.RUN_FOOTPRINT, "chain+footprint")):
+            ms = c.time_chain(flags, warmup=2, iters=10)
+            out[f"cfg4 {B} x 512x512 R5 {name}"] = {"ms_per_launch": ms, "cells_per_s": B * n * n / (ms * 1e-3)}
+    del maps
+
+    # ---- cfg5 -----------------------------------------------------------------------------------------------
+    n, tile = 8192, 256
+    elev = synth.perlin_elevation(n, n, seed=77)
+    rng = np.random.default_rng(77)
+    with capi.Context(0) as c:
+        c.set_params(params(capi, synth, 5.0, res))
+        c.set_geometry(n, n, 1, res)
+        c.upload_elevation(elev)
+        ms_full = c.time_chain(0, warmup=1, iters=5)
+        lat = []
+        for tick in range(60):
+            r0, c0 = (int(v) for v in rng.integers(0, n - tile, size=2))
+            patch = synth.perlin_elevation(tile, tile, seed=1000 + tick) * 0.5
+            t0 = time.perf_counter()
+            c.upload_tile(patch, 0, r0, c0)
+            c.run_chain_region(0, r0, c0, tile, tile)
+            c.sync()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.array(lat[10:])
+        out["cfg5 8192x8192 R5 resident, 256x256 dirty tile per tick"] = {
+            "full_map_chain_ms": ms_full, "full_map_cells_per_s": n * n / (ms_full * 1e-3),
+            "tick_ms_median": float(np.median(lat)), "tick_ms_p95": float(np.percentile(lat, 95)),
+            "ticks_per_s": 1e3 / float(np.median(lat)),
+            "what": "host-timed: H2D of the tile + re-filter of the dilated region + sync (outputs stay resident)"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
