@@ -42,19 +42,7 @@ __device__ __forceinline__ bool pos_to_index(const Geo& g, double x, double y, i
   j = (int)(-vy);
   return pos_inside(g, x, y) && i >= 0 && j >= 0 && i < g.rows && j < g.cols;
 }
-// boundPositionToRange (grid_map_core), one axis
-__device__ __forceinline__ double bound_axis(double position, double len, double mappos) {
-  double shifted = position - mappos + 0.5 * len;
-  double eps = 10.0 * 2.220446049250313e-16;
-  if (fabs(position) > 1.0) eps *= fabs(position);
-  if (shifted <= 0)
-    shifted = eps;
-  else if (shifted >= len)
-    shifted = len - eps;
-  return shifted + mappos - 0.5 * len;
-}
-
-// A layer seen through the LDS tile of the block (64x16 cells + halo); cells outside the tile are
+// A layer seen through the LDS tile of the block (64x32 cells + halo); cells outside the tile are
 // read from global memory (only the rare long Bresenham walks of checkForStep leave the tile).
 constexpr int MX = 64, MY = 32, MBY = 4, MH = 3;  // tile, threads along j, halo (>= reach of both windows + 1)
 constexpr int MTW = MX + 2 * MH, MTH = MY + 2 * MH;
@@ -70,17 +58,6 @@ struct TileView {
   }
 };
 
-__device__ __forceinline__ void load_view(float* lds, const float* __restrict__ glob, const Geo& g, int i0, int j0) {
-  for (int tj = threadIdx.y; tj < MTH; tj += MBY) {
-    const int b = j0 - MH + tj;
-    for (int ti = threadIdx.x; ti < MTW; ti += MX) {
-      const int a = i0 - MH + ti;
-      float v = qnanf();
-      if (a >= 0 && a < g.rows && b >= 0 && b < g.cols) v = glob[(size_t)b * g.rows + a];
-      lds[tj * MTW + ti] = v;
-    }
-  }
-}
 
 // Visit the in-map cells of CircleIterator(center (i,j), disc d): run table + per-cell test of the tie offsets.
 // (The visiting order differs from CircleIterator's; the predicates below do not depend on it.)
@@ -111,19 +88,12 @@ __device__ __forceinline__ bool count_zero_ok(const Geo& g, const Disc& d, const
   return !(n > ncrit);
 }
 
-// largest float <= T / smallest float >= T: for a float x,  (double)x > T <=> x > ffloor(T),  (double)x < T <=> x < fceil(T)
+// largest float <= T: for a float x,  (double)x > T <=> x > ffloor(T)
 __device__ __forceinline__ float ffloor_d(double T) {
   float f = (float)T;
   if ((double)f > T)  // step one float down
     f = f > 0.0f ? __uint_as_float(__float_as_uint(f) - 1u)
                  : (f < 0.0f ? __uint_as_float(__float_as_uint(f) + 1u) : __uint_as_float(0x80000001u));
-  return f;
-}
-__device__ __forceinline__ float fceil_d(double T) {
-  float f = (float)T;
-  if ((double)f < T)  // step one float up
-    f = f > 0.0f ? __uint_as_float(__float_as_uint(f) + 1u)
-                 : (f < 0.0f ? __uint_as_float(__float_as_uint(f) - 1u) : __uint_as_float(0x00000001u));
   return f;
 }
 

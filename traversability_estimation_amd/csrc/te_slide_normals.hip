@@ -568,8 +568,7 @@ __global__ __launch_bounds__(kLanes, kNormWaves) void k_normals_slide(Geo g, Sli
 }
 
 constexpr int kStripRows = 128;       // interior strips
-static const int kBorderStripRows = getenv("TE_NR_BROWS") ? atoi(getenv("TE_NR_BROWS")) : 32;  // EXPERIMENT
-constexpr int kBorderStripRows_unused = 32;  // the clipped-disc tail is slower: shorter strips finish with the rest
+constexpr int kBorderStripRows = 32;  // the clipped-disc tail is slower: shorter strips finish with the rest
 
 // Split the region into the frame (clipped discs; launched first, short strips) and the cells whose
 // disc lies inside the map; every rectangle keeps its 64-column blocks aligned to r.i0.
@@ -599,8 +598,7 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
   int interior_rows = kStripRows;
   if (ir > il && jb > ja) {
     const int maps = r.map >= 0 ? 1 : g.batch;
-    static const int cap_pct = getenv("TE_NR_CAP") ? atoi(getenv("TE_NR_CAP")) : 100;  // EXPERIMENT
-    const int capacity = (kNormWaves * 4 * 256 * cap_pct / 100) / (maps > 0 ? maps : 1) - border_blocks;
+    const int capacity = kNormWaves * 4 * 256 / (maps > 0 ? maps : 1) - border_blocks;
     const int nbx_in = (ir - il + kLanes - 1) / kLanes;
     int strips = capacity / nbx_in;
     strips = strips < 1 ? 1 : strips;
