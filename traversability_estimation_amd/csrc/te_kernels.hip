@@ -280,22 +280,42 @@ __global__ __launch_bounds__(TX* BY) void k_normals(Geo g, NormalsArgs a, const 
 // degenerate covariance) and raises the flag of its block.  Here a 64x16 tile whose block(s) are
 // flagged collects those cells into a dense list and recomputes them with the general path, so that
 // a thin frame of border cells costs only its own cells.
+constexpr int kFixTiles = 8;  // tiles per workgroup of k_normals_fixup
+
 __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, const float* __restrict__ elev,
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
                                                           float* __restrict__ onx, float* __restrict__ ony,
-                                                          float* __restrict__ onz, const int* __restrict__ flags,
+                                                          float* __restrict__ onz, int* __restrict__ flags,
                                                           FastGrid fg, Region rg) {
   extern __shared__ float tile[];
   __shared__ unsigned short todo[TX * TY];
   __shared__ int ntodo;
-  // one workgroup per 64x16 tile of the region; only flagged tiles do anything
-  const int mapz = rg.map >= 0 ? 0 : blockIdx.z;
-  if (!flags[((size_t)mapz * fg.nty + blockIdx.y) * fg.ntx + blockIdx.x]) return;  // uniform
-  const int map = rg.map >= 0 ? rg.map : blockIdx.z;
+  __shared__ unsigned long long pending;
+  // A workgroup looks at kFixTiles tiles of the region (one flag per lane) and works through the flagged
+  // ones; it clears the flags it consumes, so they are all zero again when the kernel ends and the slide
+  // kernel needs no memset.  A clean map costs one flag load per kFixTiles tiles, a map full of holes still
+  // spreads over ntiles / kFixTiles workgroups.
+  const int ntiles = fg.ntx * fg.nty * fg.nbz;
+  const int tid0 = threadIdx.y * TX + threadIdx.x;
+  if (tid0 < 64) {
+    const int t = blockIdx.x * kFixTiles + tid0;
+    const bool f = tid0 < kFixTiles && t < ntiles && flags[t] != 0;
+    if (f) flags[t] = 0;
+    const unsigned long long m = __ballot(f);
+    if (tid0 == 0) pending = m;
+  }
+  __syncthreads();
+  unsigned long long todo_tiles = pending;
+  while (todo_tiles) {  // uniform
+  const int bit = __ffsll((long long)todo_tiles) - 1;
+  todo_tiles &= todo_tiles - 1;
+  const int t = blockIdx.x * kFixTiles + bit;
+  const int tx = t % fg.ntx, ty = (t / fg.ntx) % fg.nty, mapz = t / (fg.ntx * fg.nty);
+  const int map = rg.map >= 0 ? rg.map : mapz;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  const int i0 = rg.i0 + blockIdx.x * TX;
-  const int jb0 = rg.j0 + blockIdx.y * TY;
+  const int i0 = rg.i0 + tx * TX;
+  const int jb0 = rg.j0 + ty * TY;
   const int jb1 = jb0 + TY < rg.j1 ? jb0 + TY : rg.j1;
   const int K = a.dn.reach > a.dr.reach ? a.dn.reach : a.dr.reach;
   const int tw = TX + 2 * K;
@@ -325,6 +345,7 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       normals_cell(g, a, tile + (lj + K) * tw + (li + K), tw, i, j, mo + (size_t)j * g.rows + i, step, slope, rough,
                    trav, onx, ony, onz);
     }
+  }
   }
 }
 
@@ -472,7 +493,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   FastGrid fg;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream)) {
-    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fg.ntx, (unsigned)fg.nty, (unsigned)fg.nbz), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
+    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)((fg.ntx * fg.nty * fg.nbz + kFixTiles - 1) / kFixTiles)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {
     hipLaunchKernelGGL(k_normals, tile_grid(g, rn), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,

@@ -497,6 +497,8 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
     HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub + fb, c->stream));
+    // the fix-up flags are zero between launches: k_normals_fixup clears every flag it consumes
+    HIP_TRY(hipMemsetAsync(c->L.block_flags, 0, fb, c->stream));
   }
   c->geo.rows = rows;
   c->geo.cols = cols;

@@ -662,7 +662,6 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.combine = combine ? 1 : 0;
   a.gtab = gtab;
   if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
-  (void)hipMemsetAsync(flags, 0, sizeof(int) * (size_t)fg->ntx * fg->nty * fg->nbz, s);
   if (d.Q >= 1) {  // instantiated shape: compile-time run table
     switch (d.Q) {
 #define X(q)                                                              \
