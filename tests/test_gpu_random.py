@@ -1,0 +1,76 @@
+"""Randomised parity sweep (seeded): map sizes that are not multiples of any tile, every instantiated disc
+shape family, tie radii, holes, kerbs, offsets, footprint with and without the roughness check -- the HIP
+chain + footprint (through the C-ABI) against the CPU oracle, mismatch count 0 at 1e-5."""
+import numpy as np
+import pytest
+
+from tests.helpers import OUT_LAYERS
+from tests.test_gpu_chain import both_fp, check_fp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no MI355X visible"
+    return capi
+
+
+def draw_case(seed):
+    from traversability_estimation_amd import synth
+    rng = np.random.default_rng(seed)
+    rows = int(rng.integers(1, 260))
+    cols = int(rng.integers(1, 260))
+    if seed % 11 == 0:  # several strips / periods / tiles in both directions
+        rows, cols = int(rng.integers(260, 700)), int(rng.integers(260, 700))
+    if seed % 7 == 0:  # very flat or very tall maps
+        rows, cols = (int(rng.integers(1, 6)), int(rng.integers(100, 400))) if seed % 2 else \
+                     (int(rng.integers(100, 400)), int(rng.integers(1, 6)))
+    res = float(rng.choice([0.03, 0.05, 0.1]))
+
+    def radius():
+        cells = float(rng.uniform(0.3, 10.4))
+        if rng.random() < 0.25:  # exact multiple of the resolution: cells on the circle (tie radii)
+            return round(cells) * res
+        if rng.random() < 0.5:
+            return synth.benchmark_radius(max(1, round(cells)), res)
+        return cells * res
+
+    same = rng.random() < 0.6
+    rn = radius()
+    over = dict(normals_radius=rn, rough_radius=rn if same else radius(), step_radius1=radius(), step_radius2=radius(),
+                slope_critical=float(rng.uniform(0.3, 1.2)), step_critical=float(rng.uniform(0.05, 0.3)),
+                step_ncrit=int(rng.integers(1, 8)), rough_critical=float(rng.uniform(0.02, 0.1)),
+                fp_radius=float(rng.choice([0.0, 0.1, 0.2, 0.3])) if rng.random() < 0.5 else float(rng.uniform(0.0, 0.5)),
+                fp_offset=float(rng.choice([0.0, 0.05, 0.15])) if rng.random() < 0.5 else float(rng.uniform(0.0, 0.3)),
+                fp_check_roughness=int(rng.random() < 0.5))
+    elev = synth.perlin_elevation(rows, cols, seed=seed, amplitude=float(rng.choice([0.05, 0.2, 0.6])))
+    if rng.random() < 0.6 and rows > 1 and cols > 1:
+        elev = synth.with_steps(elev, int(rng.integers(1, 12)), seed=seed + 1)
+    hole = rng.random()
+    if hole < 0.35:
+        elev = synth.with_holes(elev, float(rng.choice([0.002, 0.02, 0.2])), seed=seed + 2)
+    elif hole < 0.5 and rows > 20 and cols > 20:  # a solid unobserved region
+        a, b = int(rng.integers(0, rows - 10)), int(rng.integers(0, cols - 10))
+        elev[b:b + int(rng.integers(5, 40)), a:a + int(rng.integers(5, 40))] = np.nan
+    pos = (float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20)))
+    return rows, cols, res, pos, elev, over
+
+
+import os
+
+# TE_RANDOM_CASES="first:count" widens the sweep (default: 40 cases)
+_first, _count = (int(v) for v in os.environ.get("TE_RANDOM_CASES", "300:40").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_first, _first + _count))
+def test_random_case(capi, oracle, seed):
+    rows, cols, res, pos, elev, over = draw_case(seed)
+    if (over["fp_radius"] + over["fp_offset"]) / res > 19.5:  # footprint reach limit of the kernels (20 cells)
+        over["fp_offset"] = 0.0
+    got, want, op = both_fp(capi, oracle, elev, rows, cols, res, pos=pos, **over)
+    check_fp(got, want, op, f"random case seed {seed}: {rows}x{cols} res {res} {over}")
+    for k in OUT_LAYERS:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), (seed, k)

@@ -42,6 +42,43 @@ __device__ __forceinline__ bool pos_to_index(const Geo& g, double x, double y, i
   j = (int)(-vy);
   return pos_inside(g, x, y) && i >= 0 && j >= 0 && i < g.rows && j < g.cols;
 }
+// GridMap::getSubmap of the 2.5*res window around a candidate on a map border: the window corner beyond the
+// border is clamped by boundPositionToRange to `length - eps` (eps = 10 ulp(1), scaled by |position| only
+// above 1 m) and looked up again; depending on the map position that value can round onto the border itself,
+// getIndexFromPosition fails, getSubmap reports failure and checkForStep returns false for every cell that has
+// such a candidate (TraversabilityMap.cpp:817-822).  A property of the geometry and of the border side only:
+// bit 0 candidates with i == 0, bit 1 i == rows-1, bit 2 j == 0, bit 3 j == cols-1.
+inline int submap_edge_failures(const Geo& g) {
+  auto bound = [](double position, double len, double mappos) {  // boundPositionToRange, one axis
+    double shifted = position - mappos + 0.5 * len;
+    double eps = 10.0 * 2.220446049250313e-16;
+    if (fabs(position) > 1.0) eps *= fabs(position);
+    if (shifted <= 0)
+      shifted = eps;
+    else if (shifted >= len)
+      shifted = len - eps;
+    return shifted + mappos - 0.5 * len;
+  };
+  auto ok = [](double x, double len, double mappos, double res, int n) {  // one axis of getIndexFromPosition
+    const double t = -((x - mappos) - 0.5 * len);
+    const int idx = (int)(-(((x - 0.5 * len) - mappos) / res));
+    return t >= 0.0 && t < len && idx >= 0 && idx < n;
+  };
+  const double half = 0.5 * (2.5 * g.res);
+  const double x0 = g.ax, x1 = g.ax + g.res * (double)(-(g.rows - 1));
+  const double y0 = g.ay, y1 = g.ay + g.res * (double)(-(g.cols - 1));
+  int m = 0;
+  if (!ok(bound(x0 + half, g.len_x, g.pos_x), g.len_x, g.pos_x, g.res, g.rows)) m |= 1;
+  if (!ok(bound(x1 - half, g.len_x, g.pos_x), g.len_x, g.pos_x, g.res, g.rows)) m |= 2;
+  if (!ok(bound(y0 + half, g.len_y, g.pos_y), g.len_y, g.pos_y, g.res, g.cols)) m |= 4;
+  if (!ok(bound(y1 - half, g.len_y, g.pos_y), g.len_y, g.pos_y, g.res, g.cols)) m |= 8;
+  return m;
+}
+__device__ __forceinline__ bool submap_fails(const Geo& g, int edge_fail, int a, int b) {
+  return ((edge_fail & 1) && a == 0) || ((edge_fail & 2) && a == g.rows - 1) || ((edge_fail & 4) && b == 0) ||
+         ((edge_fail & 8) && b == g.cols - 1);
+}
+
 // A layer seen through the LDS tile of the block (64x32 cells + halo); cells outside the tile are
 // read from global memory (only the rare long Bresenham walks of checkForStep leave the tile).
 constexpr int MX = 64, MY = 32, MBY = 4, MH = 3;  // tile, threads along j, halo (>= reach of both windows + 1)
@@ -129,7 +166,7 @@ __device__ __forceinline__ bool check_step_screen(const Disc& d, const float* __
 
 // checkForStep :794-865
 __device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, const TileView& step, int ci, int cj,
-                           double crit_step, double max_gap) {
+                           double crit_step, double max_gap, int edge_fail) {
   const double cx = cell_x(g, ci), cy = cell_y(g, cj);
   double height = (double)elev.at(ci, cj);
   int cand[32];
@@ -143,11 +180,13 @@ __device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, co
     const int ii = cand[c] >> 16, ij = cand[c] & 0xffff;
     const double sl = 2.5 * g.res;                         // subMapLength :813
     // GridMap::getSubmap -> getSubmapInformation (grid_map_core) for a 2.5*res square around a cell centre:
-    // the corners lie 1.25 cells from the centre, i.e. 0.25 cells inside the neighbouring cells (or are
-    // clamped into the border cell by boundPositionToRange), so the submap is exactly the 3x3 block
-    // clipped to the map and the lookup cannot fail (:818-822); rounding (1e-13 cells) cannot move a
-    // corner across a cell boundary a quarter cell away.
+    // the corners lie 1.25 cells from the centre, i.e. 0.25 cells inside the neighbouring cells, or are
+    // clamped into the border cell by boundPositionToRange: the submap is exactly the 3x3 block clipped to
+    // the map (rounding of 1e-13 cells cannot move a corner across a cell boundary a quarter cell away) --
+    // unless the clamped corner rounds onto the map border and the lookup fails (:818-822), which
+    // submap_edge_failures() decides per border side with the reference's own arithmetic.
     (void)sl;
+    if (submap_fails(g, edge_fail, ii, ij)) return false;
     const int ti = ii > 0 ? ii - 1 : 0, tj = ij > 0 ? ij - 1 : 0;
     const int bi = ii < g.rows - 1 ? ii + 1 : g.rows - 1, bj = ij < g.cols - 1 ? ij + 1 : g.cols - 1;
     const int sr = bi - ti + 1, sc = bj - tj + 1;
@@ -220,6 +259,7 @@ struct MaskArgs {
   Disc step_disc;   // circle(2.5*res)
   int ncrit_slope, ncrit_rough, check_rough, write_memo;
   double crit_step, max_gap;
+  int edge_fail;  // submap_edge_failures(): border sides on which the 2.5*res submap lookup fails
   int combine;  // also write traversability = w_scale*((w_slope*slope + w_step*step) + w_rough*roughness) (float32)
   float w_scale, w_slope, w_step, w_rough;
 };
@@ -372,7 +412,10 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     if (ok && c_step == 0.0f) {  // checkForStep
       const bool screen_ok = q5 ? ((screen_mask >> c) & 1u) != 0
                                 : check_step_screen(a.step_disc, t_elev, t_key, t_kl, ctr, a.crit_step);
-      ok = screen_ok || check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap);
+      // (the screen knows nothing about failing submap lookups: next to such a border the full function decides)
+      const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
+                                                  ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
+      ok = (screen_ok && !near_bad_edge) || check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap, a.edge_fail);
       m_step = ok ? 1.0f : 0.0f;
     }
     if (ok && a.check_rough && c_rough == 0.0f) {  // checkForRoughness
@@ -584,6 +627,17 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     if (j >= jend) break;
     double St = S;
     int nt = nt_next;
+    if (g.rows < 2 * R + 1 || g.cols < 2 * R + 1) {
+      // map narrower than the disc: both borders can clip it at once, which the one-sided clip codes of the
+      // table cannot express -- count the cells of the clipped tie-free runs directly (tiny maps only)
+      nt = 0;
+      for (int dj = -R; dj <= R; ++dj) {
+        const int hw = a.h[dj < 0 ? -dj : dj];
+        if (hw < 0 || j + dj < 0 || j + dj >= g.cols) continue;
+        const int lo = i - hw > 0 ? i - hw : 0, hi = i + hw < g.rows - 1 ? i + hw : g.rows - 1;
+        nt += hi >= lo ? hi - lo + 1 : 0;
+      }
+    }
     {  // cell count of the clipped tie-free disc for the next row (only changes near the map border)
       const int jn = j + 1 < g.cols ? j + 1 : j;
       const int kyn = (jn < R) ? (R - jn) : ((g.cols - 1 - jn < R) ? -(R - (g.cols - 1 - jn)) : 0);
@@ -671,6 +725,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.crit_step = p.crit_step;
   m.max_gap = p.max_gap;
   m.combine = combine ? 1 : 0;
+  m.edge_fail = submap_edge_failures(g);
   m.w_scale = combine ? combine->w_scale : 0.0f;
   m.w_slope = combine ? combine->w_slope : 0.0f;
   m.w_step = combine ? combine->w_step : 0.0f;
