@@ -74,3 +74,53 @@ def test_random_case(capi, oracle, seed):
     check_fp(got, want, op, f"random case seed {seed}: {rows}x{cols} res {res} {over}")
     for k in OUT_LAYERS:
         assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), (seed, k)
+
+
+_rfirst, _rcount = (int(v) for v in os.environ.get("TE_RANDOM_REGION_CASES", "700:12").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_rfirst, _rfirst + _rcount))
+def test_random_batch_and_dirty_regions(capi, oracle, seed):
+    """A small batch of maps, a sequence of random dirty rectangles on random maps of the batch (te_upload_tile +
+    te_run_chain_region): after every update the incrementally maintained layers of every map equal the oracle's
+    from-scratch result on the current elevation."""
+    from traversability_estimation_amd import synth
+    from tests.helpers import assert_layers_match, to_te_params
+    rng = np.random.default_rng(seed)
+    rows, cols, batch = int(rng.integers(40, 300)), int(rng.integers(40, 300)), int(rng.integers(1, 4))
+    res = 0.05
+
+    def radius():
+        c = float(rng.uniform(0.6, 9.4))
+        return round(c) * res if rng.random() < 0.2 else c * res
+
+    rn = radius()
+    op = oracle.default_params(normals_radius=rn, rough_radius=rn if rng.random() < 0.7 else radius(),
+                               step_radius1=radius(), step_radius2=radius())
+    maps = [synth.perlin_elevation(rows, cols, seed=seed * 10 + b, amplitude=0.3) for b in range(batch)]
+    if rng.random() < 0.5:
+        maps[0] = synth.with_holes(maps[0], 0.01, seed=seed)
+    g = oracle.geom(rows, cols, res)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, batch, res)
+        ctx.upload_elevation(np.stack(maps))
+        ctx.run_chain()
+        for tick in range(3):
+            b = int(rng.integers(0, batch))
+            h, w = int(rng.integers(1, min(rows, 90) + 1)), int(rng.integers(1, min(cols, 90) + 1))
+            r0, c0 = int(rng.integers(0, rows - h + 1)), int(rng.integers(0, cols - w + 1))
+            if tick == 1:  # glued to a corner
+                r0, c0 = rows - h, 0
+            patch = synth.perlin_elevation(h, w, seed=seed * 100 + tick, amplitude=0.4)
+            if rng.random() < 0.3:
+                patch[rng.random(patch.shape) < 0.05] = np.nan
+            maps[b] = maps[b].copy()
+            maps[b][c0:c0 + w, r0:r0 + h] = patch
+            ctx.upload_tile(patch, b, r0, c0)
+            ctx.run_chain_region(b, r0, c0, h, w)
+        ctx.sync()
+        for b in range(batch):
+            got = {k: ctx.download(k, b, 1) for k in OUT_LAYERS}
+            want = oracle.chain(g, op, maps[b])
+            assert_layers_match(got, want, ctx=f"seed {seed} map {b}")
