@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the oracle with OpenMP on all host cores")
+    ap.add_argument("--holes", type=float, default=0.0, help="fraction of invalid (NaN) cells: speckle if < 0.5, else "
+                    "solid unobserved regions covering about (value - 0.5) of the map (not the BASELINE workload)")
     ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
     ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
     return ap.parse_args()
@@ -116,6 +118,18 @@ def main():
     B = args.maps_per_gpu
     # shard of the batch owned by this rank: maps rank*B .. rank*B+B-1 (seed = 1235 + global map index)
     elevs = [synth.perlin_elevation(n, n, seed=1235 + rank * B + b) for b in range(B)]
+    if args.holes > 0.0:
+        rng = np.random.default_rng(99)
+        for b in range(B):
+            if args.holes < 0.5:
+                elevs[b] = synth.with_holes(elevs[b], args.holes, seed=99 + b)
+            else:  # rectangles of 100..400 cells a side until the requested area is covered
+                area, target = 0, (args.holes - 0.5) * n * n
+                while area < target:
+                    h, w = (int(v) for v in rng.integers(100, 400, size=2))
+                    r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+                    elevs[b][c0:c0 + w, r0:r0 + h] = np.nan
+                    area += h * w
     ctx = capi.Context(local_rank)
     ctx.set_params(p)
     ctx.set_geometry(n, n, B, args.res)
@@ -199,7 +213,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)",
+            "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)" + (f", holes {args.holes}" if args.holes else ""),
             "config": {"workload": f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
                                    f" (normals/roughness/step), slope+roughness+step+normals+combine"
                                    f"{' + traversability_footprint pass' if with_fp else ''}",
@@ -214,7 +228,7 @@ def main():
         # WRITE_SIZE do not fit one pass), so the number is taken from the committed profile of this exact
         # workload (profiles/r01_hbm_traffic.json), never measured inside the timed run
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0:
+        if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
             out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes"]
             out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
         out["host_path"] = host_path

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtravgpu.so")
+LIB_PATH = os.environ.get("TRAVGPU_LIB") or os.path.join(_HERE, "libtravgpu.so")
 
 TE_OK = 0
 TE_ERR_INVALID_ARG, TE_ERR_BAD_PARAM, TE_ERR_NOT_READY, TE_ERR_HIP, TE_ERR_NO_DEVICE, TE_ERR_UNSUPPORTED = \
