@@ -83,6 +83,11 @@ struct Layers {
   hipEvent_t ev_fork, ev_join;
 };
 
+// k_normals_fixup: every workgroup owns kFixTiles tiles that are fix_groups() apart (flagged tiles come in runs
+// and must spread over many workgroups) and whose flags are adjacent in memory (one coalesced load).
+constexpr int kFixTiles = 8;
+inline int fix_groups(int ntiles) { return (ntiles + kFixTiles - 1) / kFixTiles; }
+
 struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
   int ntx, nty, nbz;
 };

@@ -280,8 +280,6 @@ __global__ __launch_bounds__(TX* BY) void k_normals(Geo g, NormalsArgs a, const 
 // degenerate covariance) and raises the flag of its block.  Here a 64x16 tile whose block(s) are
 // flagged collects those cells into a dense list and recomputes them with the general path, so that
 // a thin frame of border cells costs only its own cells.
-constexpr int kFixTiles = 8;  // tiles per workgroup of k_normals_fixup
-
 __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, const float* __restrict__ elev,
                                                           const float* __restrict__ step, float* __restrict__ slope,
                                                           float* __restrict__ rough, float* __restrict__ trav,
@@ -294,14 +292,16 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
   __shared__ unsigned long long pending;
   // A workgroup looks at kFixTiles tiles of the region (one flag per lane) and works through the flagged
   // ones; it clears the flags it consumes, so they are all zero again when the kernel ends and the slide
-  // kernel needs no memset.  A clean map costs one flag load per kFixTiles tiles, a map full of holes still
-  // spreads over ntiles / kFixTiles workgroups.
+  // kernel needs no memset.  A clean map costs one flag load per kFixTiles tiles.  The tiles of a workgroup
+  // are gridDim.x apart (flagged tiles come in runs -- along a hole boundary, the map frame -- and a run must
+  // spread over many workgroups instead of queueing up in one), their flags are adjacent (te_internal.h).
   const int ntiles = fg.ntx * fg.nty * fg.nbz;
   const int tid0 = threadIdx.y * TX + threadIdx.x;
   if (tid0 < 64) {
-    const int t = blockIdx.x * kFixTiles + tid0;
-    const bool f = tid0 < kFixTiles && t < ntiles && flags[t] != 0;
-    if (f) flags[t] = 0;
+    const int t = blockIdx.x + tid0 * (int)gridDim.x;
+    const int slot = blockIdx.x * kFixTiles + tid0;
+    const bool f = tid0 < kFixTiles && t < ntiles && flags[slot] != 0;
+    if (f) flags[slot] = 0;
     const unsigned long long m = __ballot(f);
     if (tid0 == 0) pending = m;
   }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
   while (todo_tiles) {  // uniform
   const int bit = __ffsll((long long)todo_tiles) - 1;
   todo_tiles &= todo_tiles - 1;
-  const int t = blockIdx.x * kFixTiles + bit;
+  const int t = blockIdx.x + bit * (int)gridDim.x;
   const int tx = t % fg.ntx, ty = (t / fg.ntx) % fg.nty, mapz = t / (fg.ntx * fg.nty);
   const int map = rg.map >= 0 ? rg.map : mapz;
   const size_t mo = (size_t)map * g.rows * g.cols;
@@ -493,7 +493,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   FastGrid fg;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream)) {
-    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)((fg.ntx * fg.nty * fg.nbz + kFixTiles - 1) / kFixTiles)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
+    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {
     hipLaunchKernelGGL(k_normals, tile_grid(g, rn), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,

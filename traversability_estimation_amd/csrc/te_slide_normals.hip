@@ -47,6 +47,7 @@ struct SlideArgs {
   int combine;
   const int* gtab;  // [(2R+1)^2][6] x/y moments {n, si, sj, sii, sij, sjj} of the disc clipped by the map border
   int fi0, fj0, ntx, nty;  // fix-up flag grid: 64x16 tiles from (fi0, fj0), ntx x nty per map
+  int fix_groups;          // workgroups of the fix-up pass: the flag of tile t lives at (t % groups) * kFixTiles + t / groups
   // One launch covers up to five rectangles (top, bottom, left, right frame with short strips and the
   // clipped-disc tail, then the interior): blocks [first, first+nbx*nby) belong to rectangle k.
   struct Sub {
@@ -330,7 +331,7 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
   const float slope_critf = (float)a.slope_crit, inv_slope_critf = (float)a.inv_slope_crit;
   const float rough_critf = (float)a.rough_crit, inv_rough_critf = (float)a.inv_rough_crit;
   // fix-up flags: one per 64x16 tile of the whole region the chain runs on (origin a.fi0, a.fj0)
-  int* const flag_col = tile_flags + (size_t)(rg.map >= 0 ? 0 : blockIdx.z) * a.ntx * a.nty + ((i0 - a.fi0) >> 6);
+  const int tile_col = (rg.map >= 0 ? 0 : (int)blockIdx.z) * a.ntx * a.nty + ((i0 - a.fi0) >> 6);  // + tile row * ntx
 
   // ring offsets (in doubles) of the leading / trailing row of disc column |di| = d, advanced every step
   int lead[R + 1], trail[R + 1];
@@ -544,7 +545,10 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
         v_nz[o] = nz;
       }
     }
-    if (__any(emit && !done) && lane == 0) flag_col[(size_t)((j - a.fj0) >> 4) * a.ntx] = 1;
+    if (__any(emit && !done) && lane == 0) {
+      const int t = tile_col + ((j - a.fj0) >> 4) * a.ntx;
+      tile_flags[(t % a.fix_groups) * kFixTiles + t / a.fix_groups] = 1;
+    }
   }
   }
 }
@@ -651,6 +655,7 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.fj0 = r.j0;
   a.ntx = fg->ntx;
   a.nty = fg->nty;
+  a.fix_groups = fix_groups(fg->ntx * fg->nty * fg->nbz);
   a.slope_crit = p.slope_crit;
   a.inv_slope_crit = 1.0 / p.slope_crit;
   a.rough_crit = p.rough_crit;
