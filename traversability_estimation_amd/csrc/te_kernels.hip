@@ -170,10 +170,36 @@ __global__ __launch_bounds__(TX* BY) void k_step_score(Geo g, Disc d, double cri
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void accumulate_disc(Mom& m, const Geo& g, const Disc& d, const float* ctr, int tw, int i,
                                                 int j, double z0) {
+  // One run (row of the disc) at a time: dj is constant along it, so only the moments in di are gathered per
+  // cell (3 integer + 3 double updates) and the dj factors are applied once per run.
   for (int dj = -d.R; dj <= d.R; ++dj) {
     const int hw = d.hw[dj < 0 ? -dj : dj];
     const float* row = ctr + dj * tw;
-    for (int di = -hw; di <= hw; ++di) mom_add(m, di, dj, row[di], z0);
+    int rn = 0, rsi = 0, rsii = 0;
+    double rsz = 0.0, rsiz = 0.0, rszz = 0.0;
+    for (int di = -hw; di <= hw; ++di) {
+      const float z = row[di];
+      const bool v = (z == z);
+      const double dz = v ? (double)z - z0 : 0.0;
+      const int w = v ? 1 : 0;
+      const int wdi = v ? di : 0;
+      rn += w;
+      rsi += wdi;
+      rsii += wdi * di;
+      rsz += dz;
+      rsiz = fma((double)di, dz, rsiz);
+      rszz = fma(dz, dz, rszz);
+    }
+    m.n += rn;
+    m.si += rsi;
+    m.sj += dj * rn;
+    m.sii += rsii;
+    m.sij += dj * rsi;
+    m.sjj += dj * dj * rn;
+    m.sz += rsz;
+    m.siz += rsiz;
+    m.sjz = fma((double)dj, rsz, m.sjz);
+    m.szz += rszz;
   }
   for (int t = 0; t < d.n_ties; ++t) {
     const int di = d.tie_di[t], dj = d.tie_dj[t];
