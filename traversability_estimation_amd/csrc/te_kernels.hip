@@ -15,6 +15,7 @@
 //                   + RoughnessFilter::update          RoughnessFilter.cpp:73-132
 //   k_combine       MathExpressionFilter fixed form    traversability_estimation/config/robot_filter_parameter.yaml:29-33
 #include "te_cell.h"
+#include "te_eig.h"
 #include "te_internal.h"
 
 #include <math.h>
@@ -177,6 +178,7 @@ __device__ __forceinline__ void accumulate_disc(Mom& m, const Geo& g, const Disc
     const float* row = ctr + dj * tw;
     int rn = 0, rsi = 0, rsii = 0;
     double rsz = 0.0, rsiz = 0.0, rszz = 0.0;
+#pragma unroll 4
     for (int di = -hw; di <= hw; ++di) {
       const float z = row[di];
       const bool v = (z == z);
@@ -360,7 +362,13 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
         const float s = slope[mo + (size_t)j * g.rows + i];
         need = (z0 == z0) && !(s == s);
       }
-      if (need) todo[atomicAdd(&ntodo, 1)] = (unsigned short)(lj * TX + threadIdx.x);
+      // order-preserving compaction (one LDS atomic per wave): neighbouring lanes keep neighbouring cells, so
+      // the tile reads of the gather stay (nearly) bank-conflict free
+      const unsigned long long mask = __ballot(need);
+      int base = 0;
+      if (threadIdx.x == 0 && mask) base = atomicAdd(&ntodo, __popcll(mask));
+      base = __shfl(base, 0);
+      if (need) todo[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)(lj * TX + threadIdx.x);
     }
     __syncthreads();
     const int n = ntodo;
@@ -368,8 +376,40 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       const int c = todo[k];
       const int lj = c / TX, li = c - lj * TX;
       const int i = i0 + li, j = j0 + lj;
-      normals_cell(g, a, tile + (lj + K) * tw + (li + K), tw, i, j, mo + (size_t)j * g.rows + i, step, slope, rough,
-                   trav, onx, ony, onz);
+      const float* ctr = tile + (lj + K) * tw + (li + K);
+      const size_t o = mo + (size_t)j * g.rows + i;
+      // the cells listed here have a valid centre; same general tail as the clipped discs of the slide kernel
+      // (moments -> one Jacobi rotation + secular equation), the cyclic Jacobi of normals_cell only for the
+      // configurations it does not resolve
+      bool fast_done = false;
+      if (a.same_disc && a.axis == 2 && !a.given_normals) {
+        Mom m;
+        mom_zero(m);
+        accumulate_disc(m, g, a.dn, ctr, tw, i, j, (double)*ctr);
+        float nx, ny, nz;
+        double q = 0.0;
+        fast_done = fast::border_tail(g.res, m.n, m.si, m.sj, m.sii, m.sij, m.sjj, m.sz, m.siz, m.sjz, m.szz, nx, ny, nz, q);
+        if (fast_done) {
+          const double sl = fast::acos_poly((double)nz);
+          const float o_slope = sl < a.slope_crit ? (float)(1.0 - sl / a.slope_crit) : 0.0f;
+          const double rgh = m.n > 1 ? fast::sqrt_nr(q * ((double)m.n / (double)(m.n - 1))) : 1e300;
+          const float o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh / a.rough_crit) : 0.0f;
+          slope[o] = o_slope;
+          rough[o] = o_rough;
+          if (a.combine) {
+            const float ta = a.w_slope * o_slope, tb = a.w_step * step[o], tc = a.w_rough * o_rough;
+            const float tab = ta + tb;
+            const float tabc = tab + tc;
+            trav[o] = a.w_scale * tabc;
+          }
+          if (onx) {
+            onx[o] = nx;
+            ony[o] = ny;
+            onz[o] = nz;
+          }
+        }
+      }
+      if (!fast_done) normals_cell(g, a, ctr, tw, i, j, o, step, slope, rough, trav, onx, ony, onz);
     }
   }
   }
