@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-footprint", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive measurement (for profiler runs: "
+                    "its kernels wait for a pageable H2D copy and would skew the per-kernel averages)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the oracle with OpenMP on all host cores")
     ap.add_argument("--holes", type=float, default=0.0, help="fraction of invalid (NaN) cells: speckle if < 0.5, else "
                     "solid unobserved regions covering about (value - 0.5) of the map (not the BASELINE workload)")
@@ -156,7 +158,7 @@ def main():
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_path:
         stack = np.stack(elevs)
         names = ["traversability_slope", "traversability_step", "traversability_roughness", "traversability"]
         if with_fp:
@@ -231,7 +233,8 @@ def main():
         if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
             out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes"]
             out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
-        out["host_path"] = host_path
+        if host_path is not None:
+            out["host_path"] = host_path
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
             if args.cpu_all_cores:  # extra, not part of the contract: the same oracle on every host core

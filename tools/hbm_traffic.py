@@ -2,8 +2,8 @@
 """Summarise the HBM traffic of one te_run_chain launch from two rocprofv3 PMC passes.
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE -d out/fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE -d out/write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc FETCH_SIZE -d out/fetch -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path
+    rocprofv3 --pmc WRITE_SIZE -d out/write -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path
     python tools/hbm_traffic.py out/fetch out/write > profiles/rNN_hbm_traffic.json
 
 FETCH_SIZE / WRITE_SIZE count KB.  The value per kernel is the average over its dispatches.
@@ -37,7 +37,7 @@ def main():
     wb = sum(v["WRITE_SIZE_bytes"] for v in kernels.values())
     cells = 4096 * 4096
     print(json.dumps({
-        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path "
                    "(two separate passes), summarised by tools/hbm_traffic.py",
         "config": "1 x 4096x4096, radius 9 cells, footprint pass",
         "unit": "bytes per te_run_chain launch",
