@@ -306,6 +306,22 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
   }
   __syncthreads();
+  // The three scores of this thread's MY/MBY cells: issued here so that they are in flight during the two LDS
+  // passes below (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
+  constexpr int NC = MY / MBY;
+  const int i = i0 + threadIdx.x;
+  const int ic = i < g.rows ? i : g.rows - 1;
+  const int jb = threadIdx.y * NC;  // first tile row of this thread
+  float s_slope[NC], s_step[NC], s_rough[NC];
+  fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+    int j = j0 + jb + c;
+    j = j < g.cols ? j : g.cols - 1;
+    const size_t o = mo + (size_t)j * g.rows + ic;
+    s_slope[c] = slope[o];
+    s_step[c] = step[o];
+    s_rough[c] = (a.check_rough || a.combine) ? rough[o] : 1.0f;
+  });
   {
     // t_kl for the tile cells the windows can reach (rows 1..MTH-2, columns 1..MTW-2): the 3x3 minimum of
     // t_key slides down a column (row minimum of 3 cells, then the minimum of 3 consecutive rows).
@@ -345,24 +361,12 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __syncthreads();
   const TileView ve = {t_elev, elev + mo, i0, j0, g.rows}, vs = {nullptr, step + mo, i0, j0, g.rows},
                  vl = {nullptr, slope + mo, i0, j0, g.rows}, vr = {nullptr, rough + mo, i0, j0, g.rows};
-  const int i = i0 + threadIdx.x;
   if (i >= g.rows) return;
   // Every thread walks MY/MBY consecutive rows of its column.  For the 21-cell window of circle(2.5*res)
   // (di^2+dj^2 <= 5: rows dj=0,+-1 span |di|<=2, rows dj=+-2 span |di|<=1) the two window maxima slide:
   // each tile row is reduced once along i (H1 = max over |di|<=1, H2 = max over |di|<=2: 5 LDS reads and
   // 2 v_max3 per array) and an output combines the run values of its 5 rows with 2 more v_max3.
-  constexpr int NC = MY / MBY;
   const bool q5 = a.step_disc.Q == 5 && a.step_disc.n_ties == 0;
-  const int jb = threadIdx.y * NC;  // first tile row of this thread
-  // the scores of my cells are fetched one cell ahead (clamped addresses)
-  auto fetch = [&](int c, float& fs, float& ft, float& fr) {
-    int j = j0 + jb + c;
-    j = j < g.cols ? j : g.cols - 1;
-    const size_t o = mo + (size_t)j * g.rows + i;
-    fs = slope[o];
-    ft = step[o];
-    fr = (a.check_rough || a.combine) ? rough[o] : 1.0f;
-  };
   float h1k[5], h2k[5], h1l[5], h2l[5];  // run maxima of the last 5 tile rows (slot = row mod 5)
   auto reduce_row = [&](int row, int slot) {  // tile row jb + row (window rows start 2 above the outputs)
     const int base = (jb + row + MH) * MTW + (threadIdx.x + MH);
@@ -393,15 +397,42 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       screen_mask |= hit ? 0u : (1u << c);
     });
   }
-  float n_slope, n_step, n_rough;
-  fetch(0, n_slope, n_step, n_rough);
-#pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
+  // Straight-line pass over my cells: almost every cell is decided by its scores and the screening bit alone
+  // (traversable; combined layer written); the few that need a window count or the full checkForStep are
+  // collected in a bit mask and handled by the rolled loop below.
+  unsigned slow_mask = 0;
+  fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
     const int j = j0 + jb + c;
-    if (j >= g.cols) break;
+    const float c_slope = s_slope[c], c_step = s_step[c], c_rough = s_rough[c];
+    const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
+                                                ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
+    const bool step_fast = !(c_step == 0.0f) || (q5 && ((screen_mask >> c) & 1u) != 0 && !near_bad_edge);
+    const bool slow = (c_slope == 0.0f) || !step_fast || (a.check_rough && c_rough == 0.0f);
+    slow_mask |= (slow && j < g.cols) ? (1u << c) : 0u;
+    if (j < g.cols) {
+      const size_t o = mo + (size_t)j * g.rows + i;
+      if (!slow) untrav[o] = 0;
+      if (a.combine) {  // MathExpressionFilter, fixed form, float32, left to right
+        const float ta = a.w_slope * c_slope, tb = a.w_step * c_step, tc = a.w_rough * c_rough;
+        const float tab = ta + tb;
+        const float tabc = tab + tc;
+        trav[o] = a.w_scale * tabc;
+      }
+      if (a.write_memo && !slow) {  // a step check that the screen clears is memoised as passed (:857)
+        slope_fp[o] = qnanf();
+        step_fp[o] = (c_step == 0.0f) ? 1.0f : qnanf();
+        rough_fp[o] = qnanf();
+      }
+    }
+  });
+#pragma unroll 1
+  while (slow_mask) {
+    const int c = __ffs((int)slow_mask) - 1;
+    slow_mask &= slow_mask - 1;
+    const int j = j0 + jb + c;
     const size_t o = mo + (size_t)j * g.rows + i;
-    const float c_slope = n_slope, c_step = n_step, c_rough = n_rough;
-    fetch(c + 1, n_slope, n_step, n_rough);
+    const float c_slope = slope[o], c_step = step[o], c_rough = (a.check_rough || a.combine) ? rough[o] : 1.0f;
     float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
     bool ok = true;
     const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
@@ -423,12 +454,6 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       m_rough = ok ? 1.0f : 0.0f;
     }
     untrav[o] = ok ? 0 : 1;
-    if (a.combine) {  // MathExpressionFilter, fixed form, float32, left to right
-      const float ta = a.w_slope * c_slope, tb = a.w_step * c_step, tc = a.w_rough * c_rough;
-      const float tab = ta + tb;
-      const float tabc = tab + tc;
-      trav[o] = a.w_scale * tabc;
-    }
     if (a.write_memo) {
       slope_fp[o] = m_slope;
       step_fp[o] = m_step;
