@@ -276,6 +276,22 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
   const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
+  // The three scores of this thread's MY/MBY cells: issued together with the tile loads, so that they
+  // are in flight during the staging and the two LDS passes (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
+  constexpr int NC = MY / MBY;
+  const int i = i0 + threadIdx.x;
+  const int ic = i < g.rows ? i : g.rows - 1;
+  const int jb = threadIdx.y * NC;  // first tile row of this thread
+  float s_slope[NC], s_step[NC], s_rough[NC];
+  fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+    int j = j0 + jb + c;
+    j = j < g.cols ? j : g.cols - 1;
+    const size_t o = mo + (size_t)j * g.rows + ic;
+    s_slope[c] = slope[o];
+    s_step[c] = step[o];
+    s_rough[c] = (a.check_rough || a.combine) ? rough[o] : 1.0f;
+  });
   {
     // all loads of the tile in flight at once (clamped addresses), then the LDS writes
     constexpr int NT = MX * MBY, NL = (MTW * MTH + NT - 1) / NT;
@@ -306,22 +322,6 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
   }
   __syncthreads();
-  // The three scores of this thread's MY/MBY cells: issued here so that they are in flight during the two LDS
-  // passes below (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
-  constexpr int NC = MY / MBY;
-  const int i = i0 + threadIdx.x;
-  const int ic = i < g.rows ? i : g.rows - 1;
-  const int jb = threadIdx.y * NC;  // first tile row of this thread
-  float s_slope[NC], s_step[NC], s_rough[NC];
-  fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
-    constexpr int c = decltype(cc)::value;
-    int j = j0 + jb + c;
-    j = j < g.cols ? j : g.cols - 1;
-    const size_t o = mo + (size_t)j * g.rows + ic;
-    s_slope[c] = slope[o];
-    s_step[c] = step[o];
-    s_rough[c] = (a.check_rough || a.combine) ? rough[o] : 1.0f;
-  });
   {
     // t_kl for the tile cells the windows can reach (rows 1..MTH-2, columns 1..MTW-2): the 3x3 minimum of
     // t_key slides down a column (row minimum of 3 cells, then the minimum of 3 consecutive rows).
