@@ -16,7 +16,7 @@ namespace {
 
 // waves per SIMD the kernels are compiled for (register budget 512 / waves); the launchers size the
 // strips so that the whole grid is resident at this occupancy
-constexpr int kHeightWaves = 3, kScoreWaves = 3;
+constexpr int kHeightWaves = 3, kScoreWaves = 2;
 
 template <int Q>
 __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g, const float* __restrict__ elev,
@@ -160,18 +160,22 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
     loader.store(rowbuf, stage, lane, [&](float v) { return make_float2(v, __int_as_float(v > crit_lo ? 1 : 0)); });
     __syncthreads();
     if (per + 1 < periods) loader.load(stage, shl + mo, g, rbase + P, i0 - R, lane);
-    auto horiz = [&](int p, float (&mx)[R + 1], int (&cn)[R + 1]) __attribute__((always_inline)) {
+    // One row = 2R+1 staged cells {value, flag}; the reads of the NEXT row are issued before the current row is
+    // reduced (two row buffers alternate), so the LDS latency is covered by the reduction and the scatter.
+    auto read_row = [&](int p, float2 (&raw)[2 * R + 1]) __attribute__((always_inline)) {
       const float2* row = rowbuf + p * W + lane + R;
-      {
-        const float2 c = row[0];
-        mx[0] = c.x;
-        cn[0] = __float_as_int(c.y);
-      }
+      static_for<2 * R + 1>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        raw[k] = row[k - R];
+      });
+    };
+    auto horiz = [&](const float2 (&raw)[2 * R + 1], float (&mx)[R + 1], int (&cn)[R + 1]) __attribute__((always_inline)) {
+      mx[0] = raw[R].x;
+      cn[0] = __float_as_int(raw[R].y);
       static_for<R>([&](auto dc) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value + 1;
-        if constexpr (R >= 6 && d == R / 2 + 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
-        const float2 a = row[-d], b = row[d];
-        vmax3_add3(mx[d], cn[d], mx[d - 1], a.x, b.x, cn[d - 1], __float_as_int(a.y), __float_as_int(b.y));
+        vmax3_add3(mx[d], cn[d], mx[d - 1], raw[R - d].x, raw[R + d].x, cn[d - 1], __float_as_int(raw[R - d].y),
+                   __float_as_int(raw[R + d].y));
       });
     };
     auto emit = [&](int p, float m, int count) __attribute__((always_inline)) {
@@ -191,15 +195,17 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
         out[mo + (size_t)j * g.rows + i] = o;
       }
     };
+    float2 rawa[2 * R + 1], rawb[2 * R + 1];
+    read_row(0, rawa);
     static_for<(P + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
-      constexpr int p = 2 * decltype(pc)::value;
-      __builtin_amdgcn_sched_barrier(0);  // see k_step_height_fast
+      constexpr int p = 2 * decltype(pc)::value;  // row p is in rawa
       if constexpr (p + 1 < P) {  // two rows per pass
         float mx1[R + 1], mx2[R + 1];
         int cn1[R + 1], cn2[R + 1];
-        horiz(p, mx1, cn1);
-        __builtin_amdgcn_sched_barrier(0);  // float2 rows: do not hold both rows' LDS reads at once
-        horiz(p + 1, mx2, cn2);
+        read_row(p + 1, rawb);
+        horiz(rawa, mx1, cn1);
+        if constexpr (p + 2 < P) read_row(p + 2, rawa);
+        horiz(rawb, mx2, cn2);
         static_for<P>([&](auto sc) __attribute__((always_inline)) {
           constexpr int sl = decltype(sc)::value;
           constexpr int e0 = ((sl - p) % P + P) % P;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
       } else {
         float mx[R + 1];
         int cn[R + 1];
-        horiz(p, mx, cn);
+        horiz(rawa, mx, cn);
         static_for<P>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value - R;
           constexpr int slot = (p + e + P) % P;
