@@ -164,6 +164,17 @@ int te_run_chain(te_ctx* ctx, unsigned flags);
  * `map` changed (the rectangle dilated by the chain's reach). */
 int te_run_chain_region(te_ctx* ctx, unsigned flags, int map, int row0, int col0, int h, int w);
 int te_run_footprint(te_ctx* ctx);
+/* Batched TraversabilityMap::checkFootprintPath for circular footprints (TraversabilityMap.cpp:320-342 ->
+ * checkCircularFootprintPath :344-462) on the resident traversability_footprint layer of map `map`, which must be
+ * complete (te_run_chain with TE_RUN_FOOTPRINT or te_run_footprint, with fp_radius = the paths' radius and
+ * fp_offset = 0.15 like :348): isTraversable() then takes its memo branch (:672-677) for every centre.
+ * Path k has the poses pose_xy[2*pose_offset[k] .. 2*pose_offset[k+1]) (x, y in the map frame; pose_offset[0] == 0).
+ * Outputs per path: is_safe and traversability (TraversabilityResult, :352-355), status 0 ok / 1 a pose of a
+ * multi-pose path lies outside the map (the reference ignores getIndex()'s failure there: undefined) / 2 no poses
+ * (:330-334).  Reference options not covered (their defaults): publishPolygons, compute_untraversable_polygon,
+ * footprint/check_robot_inclination.  Host buffers; synchronous. */
+int te_check_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* pose_xy,
+                             unsigned char* is_safe, double* traversability, int* status);
 int te_sync(te_ctx* ctx);
 
 int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);

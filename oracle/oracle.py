@@ -60,6 +60,8 @@ def lib():
         L.teo_chain.argtypes = [gp, pp, fp, fp, fp, fp, fp, fp, fp, fp]
         L.teo_footprint.argtypes = [gp, pp, fp, fp, fp, fp, fp, fp, fp, fp, fp]
         L.teo_circle_count.argtypes = [gp, C.c_int, C.c_int, C.c_double]
+        L.teo_check_circular_paths.argtypes = [gp, fp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         ip = C.POINTER(C.c_int)
         L.teo_spiral_offsets.argtypes = [gp, C.c_int, C.c_int, C.c_double, ip, ip, ip, C.c_int]
         _LIB = L
@@ -144,6 +146,28 @@ def footprint(g, p, elev, layers, want_memo=False):
     if want_memo:
         return fp, dict(slope_footprint=memo[0], step_footprint=memo[1], roughness_footprint=memo[2])
     return fp
+
+
+def check_circular_paths(g, footprint, fp_default, paths):
+    """TraversabilityMap::checkFootprintPath (circular footprints) for a list of (n_i, 2) pose arrays."""
+    n = g.rows * g.cols
+    fp = _flat(footprint, n)
+    paths = [np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in paths]
+    k = len(paths)
+    off = np.zeros(k + 1, np.int32)
+    if k:
+        off[1:] = np.cumsum([len(p) for p in paths])
+    xy = np.ascontiguousarray(np.concatenate(paths) if k and off[-1] else np.zeros((1, 2)), dtype=np.float64)
+    safe = np.zeros(max(k, 1), np.uint8)
+    trav = np.zeros(max(k, 1), np.float64)
+    st = np.zeros(max(k, 1), np.int32)
+    rc = lib().teo_check_circular_paths(C.byref(g), _f(fp), C.c_double(fp_default), k,
+                                        off.ctypes.data_as(C.POINTER(C.c_int)), xy.ctypes.data_as(C.POINTER(C.c_double)),
+                                        safe.ctypes.data_as(C.POINTER(C.c_ubyte)), trav.ctypes.data_as(C.POINTER(C.c_double)),
+                                        st.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc:
+        raise RuntimeError(f"teo_check_circular_paths failed: {rc}")
+    return safe[:k].astype(bool), trav[:k], st[:k]
 
 
 def circle_count(g, i, j, radius):

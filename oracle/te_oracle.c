@@ -779,3 +779,95 @@ int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, con
   free(untrav);
   return err ? -2 : 0;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* N2  checkCircularFootprintPath :344-462 for a batch of paths, with publishPolygons == false,   */
+/*     compute_untraversable_polygon == false and footprint/check_robot_inclination == false     */
+/*     (robot_footprint_parameter.yaml:10), on a map whose traversability_footprint layer is     */
+/*     complete: isTraversable(center, ...) then takes its memo branch (:672-677) for every      */
+/*     centre -- value = layer, traversable = value != 0.                                         */
+/*     Poses outside the map: the reference calls getIndex() and ignores its result (undefined   */
+/*     start/end index); here such a path gets status 1 and is reported unsafe.                   */
+/*     A single pose outside the map uses traversabilityDefault_ (:663-665).                      */
+/* ------------------------------------------------------------------------------------------- */
+int teo_check_circular_paths(const teo_geom* g, const float* footprint, double fp_default, int n_paths,
+                             const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                             double* traversability, int* status) {
+  for (int k = 0; k < n_paths; ++k) {
+    const int n = pose_offset[k + 1] - pose_offset[k];
+    const double* xy = pose_xy + 2 * (size_t)pose_offset[k];
+    is_safe[k] = 0;
+    traversability[k] = 0.0;
+    status[k] = 0;
+    if (n <= 0) { /* :330-334 "This path has no poses to check" */
+      status[k] = 2;
+      continue;
+    }
+    double res_trav = 0.0, length_path = 0.0;
+    double ex = 0.0, ey = 0.0, sx, sy;
+    int ok = 1;
+    for (int i = 0; i < n && ok; ++i) {
+      sx = ex;
+      sy = ey;
+      ex = xy[2 * i];
+      ey = xy[2 * i + 1];
+      if (n == 1) { /* :365-385 */
+        double t;
+        int trav;
+        int ci, cj;
+        if (!pos_inside(g, ex, ey)) {
+          t = fp_default;
+          trav = fp_default != 0.0;
+        } else {
+          pos_to_index(g, ex, ey, &ci, &cj);
+          t = (double)footprint[IDX(g, ci, cj)];
+          trav = t != 0.0;
+        }
+        if (!trav) {
+          ok = 0;
+          break;
+        }
+        res_trav = t;
+      }
+      if (n > 1 && i > 0) { /* :388-456 */
+        int si, sj, ei, ej;
+        if (!pos_to_index(g, sx, sy, &si, &sj) || !pos_to_index(g, ex, ey, &ei, &ej)) {
+          status[k] = 1;
+          ok = 0;
+          break;
+        }
+        double sum = 0.0;
+        int nline = 0;
+        line_it L;
+        for (line_init(&L, ei, ej, si, sj); L.icell < L.ncells; line_next(&L)) { /* from the end index to the start index */
+          const double t = (double)footprint[IDX(g, L.i, L.j)];
+          if (!(t != 0.0)) {
+            ok = 0;
+            break;
+          }
+          sum += t;
+          nline++;
+          for (int s = 0; s < 3; ++s) /* nSkip :396 */
+            if (L.icell < L.ncells) line_next(&L);
+        }
+        if (!ok) break;
+        const double t = sum / (double)nline;
+        const double dx = ex - sx, dy = ey - sy;
+        const double length_segment = sqrt(dx * dx + dy * dy);
+        if (i > 1) { /* :443-447 (lengthPath keeps its value between iterations) */
+          const double length_previous = length_path;
+          length_path += length_segment;
+          res_trav = (length_segment * t + length_previous * res_trav) / length_path;
+        } else {
+          length_path = length_segment;
+          res_trav = t;
+        }
+      }
+    }
+    if (ok) {
+      is_safe[k] = 1;
+      traversability[k] = res_trav;
+    }
+  }
+  return 0;
+}

@@ -98,6 +98,13 @@ int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, con
 int teo_circle_count(const teo_geom* g, int i, int j, double radius);
 int teo_spiral_offsets(const teo_geom* g, int ci, int cj, double radius, int* di, int* dj, int* ring, int cap);
 
+/* N2: checkCircularFootprintPath (TraversabilityMap.cpp:344-462) for n_paths paths on a complete traversability_footprint
+ * layer; path k has the poses pose_xy[2*pose_offset[k] .. 2*pose_offset[k+1]) (x, y pairs).  status: 0 ok, 1 a pose of a
+ * multi-pose path lies outside the map (undefined in the reference), 2 no poses. */
+int teo_check_circular_paths(const teo_geom* g, const float* footprint, double fp_default, int n_paths,
+                             const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                             double* traversability, int* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,45 @@ def main():
             "tick_ms_median": float(np.median(lat)), "tick_ms_p95": float(np.percentile(lat, 95)),
             "ticks_per_s": 1e3 / float(np.median(lat)),
             "what": "host-timed: H2D of the tile + re-filter of the dilated region + sync (outputs stay resident)"}
+    # ---- N2: batched circular checkFootprintPath on the resident footprint layer -----------------------------
+    from oracle import oracle as O
+    n = 4096
+    rng = np.random.default_rng(5)
+    with capi.Context(0) as c:
+        p = params(capi, synth, 9.0, res)
+        c.set_params(p)
+        c.set_geometry(n, n, 1, res)
+        c.upload_elevation(synth.perlin_elevation(n, n, seed=1235))
+        c.run_chain(capi.RUN_FOOTPRINT)
+        c.sync()
+        fp = c.download("traversability_footprint")
+        half = 0.5 * n * res
+        paths = []
+        for _ in range(200000):  # MPC-style candidates: 2..6 poses, segments up to 2 m
+            k = int(rng.integers(2, 7))
+            start = rng.uniform(-half + 3.0, half - 3.0, size=2)
+            steps = rng.uniform(-2.0, 2.0, size=(k - 1, 2))
+            paths.append(np.clip(np.vstack([start, start + np.cumsum(steps, axis=0)]), -half + 0.01, half - 0.01))
+        off, xy = capi.pack_paths(paths)
+        c.check_footprint_paths(paths[:1000])  # warm-up
+        best = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            safe, trav, st = c.check_footprint_paths_packed(off, xy)
+            d = time.perf_counter() - t0
+            best = d if best is None or d < best else best
+        dt = best
+        g = O.geom(n, n, res)
+        m = 20000
+        t0 = time.perf_counter()
+        ws, wt, wst = O.check_circular_paths(g, fp, 0.3, paths[:m])
+        dt_cpu = time.perf_counter() - t0
+        assert np.array_equal(ws, safe[:m]) and np.array_equal(wt, trav[:m]) and np.array_equal(wst, st[:m])
+        out["N2 checkFootprintPath (circular), 200000 paths of 2-6 poses on 4096x4096"] = {
+            "gpu_paths_per_s": len(paths) / dt, "gpu_ms": dt * 1e3, "safe_fraction": float(safe.mean()),
+            "cpu_oracle_paths_per_s": m / dt_cpu,
+            "what": "te_check_footprint_paths on packed host arrays, H2D of the poses and D2H of the results included; the oracle "
+                    "(1 thread, same layer) on the first 20000 paths, results bit-identical"}
     print(json.dumps(out, indent=1))
 
 

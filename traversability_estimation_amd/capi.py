@@ -28,8 +28,20 @@ RUN_SEQUENTIAL = 0x10
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
-           "te_device_ptr", "te_upload_layer", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_sync",
+           "te_device_ptr", "te_upload_layer", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
+           "te_sync",
            "te_download_layer", "te_time_chain", "te_last_error", "te_version"]
+
+
+def pack_paths(paths):
+    """List of (n_i, 2) pose arrays -> (offsets int32[n+1], xy float64[total, 2])."""
+    paths = [np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in paths]
+    n = len(paths)
+    off = np.zeros(n + 1, np.int32)
+    if n:
+        off[1:] = np.cumsum([len(p) for p in paths])
+    xy = np.ascontiguousarray(np.concatenate(paths) if n and off[-1] else np.zeros((1, 2)), dtype=np.float64)
+    return off, xy
 
 
 class TeParams(C.Structure):
@@ -80,6 +92,8 @@ def load():
         L.te_run_chain.argtypes = [vp, C.c_uint]
         L.te_run_chain_region.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_run_footprint.argtypes = [vp]
+        L.te_check_footprint_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -195,6 +209,27 @@ class Context:
 
     def run_footprint(self):
         _check(load().te_run_footprint(self._h))
+
+    def check_footprint_paths(self, paths, map_index=0):
+        """paths: sequence of (n_i, 2) arrays of (x, y) poses.  Returns (is_safe[bool], traversability[float64], status[int32])
+        like TraversabilityMap::checkFootprintPath for circular footprints, on the resident footprint layer."""
+        off, xy = pack_paths(paths)
+        return self.check_footprint_paths_packed(off, xy, map_index)
+
+    def check_footprint_paths_packed(self, off, xy, map_index=0):
+        """The same with the poses already packed: off int32[n+1] (off[0] == 0), xy float64[off[-1], 2]."""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        n = len(off) - 1
+        safe = np.zeros(max(n, 1), np.uint8)
+        trav = np.zeros(max(n, 1), np.float64)
+        st = np.zeros(max(n, 1), np.int32)
+        _check(load().te_check_footprint_paths(self._h, int(map_index), n, off.ctypes.data_as(C.POINTER(C.c_int)),
+                                               xy.ctypes.data_as(C.POINTER(C.c_double)),
+                                               safe.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                               trav.ctypes.data_as(C.POINTER(C.c_double)),
+                                               st.ctypes.data_as(C.POINTER(C.c_int))))
+        return safe[:n].astype(bool), trav[:n], st[:n]
 
     def sync(self):
         _check(load().te_sync(self._h))

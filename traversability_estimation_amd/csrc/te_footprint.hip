@@ -16,6 +16,7 @@
 //             lane walks the host-built spiral table (SpiralIterator order) over the rows already staged
 //             in LDS until the first untraversable cell, exactly like isTraversable().
 #include "te_internal.h"
+#include "te_geom.h"
 #include "te_march.h"
 
 namespace te {
@@ -25,23 +26,6 @@ namespace {
 constexpr int kLanes = 64;
 
 __device__ __forceinline__ float qnanf() { return __builtin_nanf(""); }
-__device__ __forceinline__ double cell_x(const Geo& g, int i) { return g.ax + g.res * (double)(-i); }
-__device__ __forceinline__ double cell_y(const Geo& g, int j) { return g.ay + g.res * (double)(-j); }
-
-// checkIfPositionWithinMap (grid_map_core)
-__device__ __forceinline__ bool pos_inside(const Geo& g, double x, double y) {
-  const double tx = -((x - g.pos_x) - 0.5 * g.len_x);
-  const double ty = -((y - g.pos_y) - 0.5 * g.len_y);
-  return tx >= 0.0 && ty >= 0.0 && tx < g.len_x && ty < g.len_y;
-}
-// getIndexFromPosition (grid_map_core)
-__device__ __forceinline__ bool pos_to_index(const Geo& g, double x, double y, int& i, int& j) {
-  const double vx = ((x - 0.5 * g.len_x) - g.pos_x) / g.res;
-  const double vy = ((y - 0.5 * g.len_y) - g.pos_y) / g.res;
-  i = (int)(-vx);
-  j = (int)(-vy);
-  return pos_inside(g, x, y) && i >= 0 && j >= 0 && i < g.rows && j < g.cols;
-}
 // GridMap::getSubmap of the 2.5*res window around a candidate on a map border: the window corner beyond the
 // border is clamped by boundPositionToRange to `length - eps` (eps = 10 ulp(1), scaled by |position| only
 // above 1 m) and looked up again; depending on the map position that value can round onto the border itself,

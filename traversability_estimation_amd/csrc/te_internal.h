@@ -101,6 +101,10 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
                             const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
+// te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map
+hipError_t launch_check_circular_paths(const Geo& g, const float* footprint, double fp_default, int n_paths,
+                                       const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                                       double* traversability, int* status, hipStream_t stream);
 
 // shape-specialised kernels (te_fast_*.hip); return false when the shape Q is not instantiated
 namespace fast {

@@ -112,7 +112,7 @@ struct te_ctx {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   te_params params;
-  bool have_params = false, have_geo = false, have_elev = false, chain_done = false;
+  bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
   Geo geo;
   ChainParams cp;
   FootprintParams fp;
@@ -290,6 +290,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.ev_join = c->ev_join;
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
+  c->footprint_done = false;  // the layers the footprint pass reads have changed
   return TE_OK;
 }
 
@@ -300,6 +301,7 @@ int run_footprint_locked(te_ctx* c, unsigned flags) {
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
                            c->combine_deferred ? &c->cp : nullptr, c->stream));
   c->combine_deferred = false;
+  c->footprint_done = true;
   return TE_OK;
 }
 
@@ -622,6 +624,46 @@ int te_run_footprint(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_footprint: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);
   return run_footprint_locked(c, TE_RUN_FOOTPRINT_MEMO);
+}
+
+int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_offset, const double* pose_xy,
+                             unsigned char* is_safe, double* traversability, int* status) {
+  if (!c || n_paths < 0 || (n_paths > 0 && (!pose_offset || !pose_xy || !is_safe || !traversability || !status)))
+    return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: NULL argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: run the chain with the footprint pass first");
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: map %d of %d", map, c->geo.batch);
+  if (n_paths == 0) return TE_OK;
+  const int n_poses = pose_offset[n_paths];
+  if (pose_offset[0] != 0 || n_poses < 0) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: bad pose offsets");
+  for (int k = 0; k < n_paths; ++k)
+    if (pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: bad pose offsets");
+  HIP_TRY(hipSetDevice(c->device));
+  // staging buffers for this call (paths are small: a few KB .. MB)
+  const size_t b_off = (size_t)(n_paths + 1) * sizeof(int), b_xy = (size_t)2 * (n_poses > 0 ? n_poses : 1) * sizeof(double);
+  const size_t b_safe = (size_t)n_paths, b_trav = (size_t)n_paths * sizeof(double), b_st = (size_t)n_paths * sizeof(int);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, up(b_off) + up(b_xy) + up(b_trav) + up(b_st) + up(b_safe)));
+  int* d_off = (int*)d;
+  double* d_xy = (double*)(d + up(b_off));
+  double* d_trav = (double*)(d + up(b_off) + up(b_xy));
+  int* d_st = (int*)(d + up(b_off) + up(b_xy) + up(b_trav));
+  unsigned char* d_safe = (unsigned char*)(d + up(b_off) + up(b_xy) + up(b_trav) + up(b_st));
+  hipError_t e = hipMemcpyAsync(d_off, pose_offset, b_off, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_poses > 0) e = hipMemcpyAsync(d_xy, pose_xy, (size_t)2 * n_poses * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  if (e == hipSuccess)
+    e = launch_check_circular_paths(c->geo, c->L.footprint + per * map, c->params.fp_default, n_paths, d_off, d_xy, d_safe,
+                                    d_trav, d_st, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(is_safe, d_safe, b_safe, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, b_st, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_check_footprint_paths: %s", hipGetErrorString(e));
+  return TE_OK;
 }
 
 int te_sync(te_ctx* c) {
