@@ -126,16 +126,20 @@ struct te_ctx {
   bool combine_deferred = false;
   bool tables_ready = false;
   // the launch sequence of a whole-map run, captured once per (flags, parameters, geometry) and replayed
-  hipGraphExec_t graph_exec = nullptr;
-  unsigned graph_flags = 0;
+  static constexpr int kGraphs = 4;  // one per flag combination in use
+  hipGraphExec_t graph_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned graph_flags[kGraphs] = {0, 0, 0, 0};
+  int graph_next = 0;
   bool graph_ok = true;  // cleared after a failed capture: direct launches from then on
 };
 
 namespace {
 
 void drop_graph(te_ctx* c) {
-  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
-  c->graph_exec = nullptr;
+  for (int k = 0; k < te_ctx::kGraphs; ++k) {
+    if (c->graph_exec[k]) (void)hipGraphExecDestroy(c->graph_exec[k]);
+    c->graph_exec[k] = nullptr;
+  }
 }
 
 int rebuild_tables(te_ctx* c) {
@@ -331,8 +335,14 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
       if (rc) return rc;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (!(c->graph_exec && c->graph_flags == flags)) {
-      drop_graph(c);
+    int slot = -1;
+    for (int k = 0; k < te_ctx::kGraphs; ++k)
+      if (c->graph_exec[k] && c->graph_flags[k] == flags) slot = k;
+    if (slot < 0) {
+      slot = c->graph_next;
+      c->graph_next = (c->graph_next + 1) % te_ctx::kGraphs;
+      if (c->graph_exec[slot]) (void)hipGraphExecDestroy(c->graph_exec[slot]);
+      c->graph_exec[slot] = nullptr;
       hipGraph_t graph = nullptr;
       int rc = TE_OK;
       hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
@@ -341,18 +351,19 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
         if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags);
         e = hipStreamEndCapture(c->stream, &graph);
       }
-      if (e == hipSuccess && rc == TE_OK && graph) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+      if (e == hipSuccess && rc == TE_OK && graph) e = hipGraphInstantiate(&c->graph_exec[slot], graph, nullptr, nullptr, 0);
       if (graph) (void)hipGraphDestroy(graph);
-      if (e != hipSuccess || rc != TE_OK || !c->graph_exec) {
+      if (e != hipSuccess || rc != TE_OK || !c->graph_exec[slot]) {
         (void)hipGetLastError();
         drop_graph(c);
         c->graph_ok = false;
+        slot = -1;
       } else {
-        c->graph_flags = flags;
+        c->graph_flags[slot] = flags;
       }
     }
-    if (c->graph_exec) {
-      HIP_TRY(hipGraphLaunch(c->graph_exec, c->stream));
+    if (slot >= 0) {
+      HIP_TRY(hipGraphLaunch(c->graph_exec[slot], c->stream));
       c->chain_done = true;
       c->footprint_done = (flags & TE_RUN_FOOTPRINT) != 0;
       c->combine_deferred = false;
