@@ -59,3 +59,14 @@ def test_no_cpu_fallback_without_device(capi):
     with pytest.raises(capi.TeError) as e:
         capi.Context(0)
     assert e.value.code == capi.TE_ERR_NO_DEVICE
+
+
+def test_null_arguments_are_rejected_without_a_device(capi):
+    """Entry points validate their pointers before they touch the device (status code + te_last_error)."""
+    L = capi.load()
+    one = (C.c_int * 2)(0, 1)
+    xy = (C.c_double * 2)(0.0, 0.0)
+    assert L.te_check_footprint_paths(None, 0, 1, one, xy, None, None, None) == capi.TE_ERR_INVALID_ARG
+    assert b"te_check_footprint_paths" in L.te_last_error()
+    assert L.te_run_chain(None, 0) == capi.TE_ERR_INVALID_ARG
+    assert L.te_sync(None) == capi.TE_ERR_INVALID_ARG
