@@ -70,3 +70,16 @@ def test_null_arguments_are_rejected_without_a_device(capi):
     assert b"te_check_footprint_paths" in L.te_last_error()
     assert L.te_run_chain(None, 0) == capi.TE_ERR_INVALID_ARG
     assert L.te_sync(None) == capi.TE_ERR_INVALID_ARG
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/travgpu.h is the drop-in boundary: it has to compile as C99 and as C++11 on its own."""
+    import shutil
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "travgpu.h"\nint main(void) { te_params p; return te_params_default(&p); }\n')
+    inc = os.path.join(ROOT, "include")
+    for cc, std, extra in (("gcc", "-std=c99", []), ("g++", "-std=c++11", ["-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only"] + extra + [str(src)])
