@@ -12,7 +12,8 @@ once over RCCL before the timed region.
 
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the whole chain launch
 sequence: algorithmic bytes (20 B/cell chain, 24 B/cell with the footprint pass) divided
-by the chain's average duration measured with HIP events on the stream the kernels run on.
+by the chain's average duration measured with HIP events on the stream the kernels run on;
+`roofline.dominant_kernel` is the normals/slope/roughness kernel timed alone the same way (12 B/cell).
 `cpu_baseline` times the CPU oracle (our restatement of the reference; kind "port") on one host thread
 over a bounded crop of the same map.
 """
@@ -155,6 +156,8 @@ def main():
 
     # kernel-only duration of the chain: HIP events on the context's own stream
     ms_chain = ctx.time_chain(flags, warmup=1, iters=max(5, min(args.steps, 50)))
+    # the dominant kernel alone (normals/slope/roughness + its fix-up pass), the same way
+    ms_normals = ctx.time_chain(capi.RUN_NORMALS_ONLY, warmup=1, iters=max(5, min(args.steps, 50)))
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
@@ -224,7 +227,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "chain launch sequence (all kernels of one te_run_chain)",
-                         "ms_per_launch": ms_chain, "algorithmic_bytes_per_cell": bytes_per_cell},
+                         "ms_per_launch": ms_chain, "algorithmic_bytes_per_cell": bytes_per_cell,
+                         "dominant_kernel": {"name": "k_normals_slide (+ k_normals_fixup), alone on the GPU",
+                                             "ms": ms_normals, "algorithmic_bytes_per_cell": 12,
+                                             "achieved": B * n * n * 12 / (ms_normals * 1e-3) / 1e9,
+                                             "frac": B * n * n * 12 / (ms_normals * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         # HBM traffic of the same launch sequence: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
         # WRITE_SIZE do not fit one pass), so the number is taken from the committed profile of this exact

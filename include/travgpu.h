@@ -83,6 +83,7 @@ typedef enum te_layer {
 #define TE_RUN_FOOTPRINT    0x2u /* run the circular footprint pass right after the chain */
 #define TE_RUN_FOOTPRINT_MEMO 0x8u /* with the footprint pass: also write slope_/step_/roughness_footprint (0/1/NaN) */
 #define TE_RUN_SEQUENTIAL 0x10u /* one HIP stream only (default: step filter and normals kernel overlap on two streams) */
+#define TE_RUN_NORMALS_ONLY 0x20u /* measurement aid: only the normals/slope/roughness kernel (+ its fix-up pass) */
 #define TE_RUN_GENERIC_KERNELS 0x4u /* use only the shape-generic kernels (also the path for tie radii); for A/B tests */
 
 /* The reference's plugins one at a time (te_run_filter): what the drop-in adapters of

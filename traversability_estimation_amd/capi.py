@@ -24,6 +24,7 @@ RUN_FOOTPRINT = 0x2
 RUN_GENERIC_KERNELS = 0x4
 RUN_FOOTPRINT_MEMO = 0x8
 RUN_SEQUENTIAL = 0x10
+RUN_NORMALS_ONLY = 0x20
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",

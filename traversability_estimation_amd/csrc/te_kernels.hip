@@ -522,18 +522,21 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   // The step filter and the normals/slope/roughness kernel are independent until the combine: on whole
   // maps they run concurrently on two HIP streams (each alone leaves the VALUs half idle), joined by an
   // event before the combine.
-  const bool overlap = whole && L.aux_stream != nullptr;
+  const bool normals_only = (flags & TE_RUN_NORMALS_ONLY) != 0;  // measurement aid: the dominant kernel alone
+  const bool overlap = whole && L.aux_stream != nullptr && !normals_only;
   hipStream_t ss = overlap ? L.aux_stream : stream;
   if (overlap) {
     (void)hipEventRecord(L.ev_fork, stream);
     (void)hipStreamWaitEvent(ss, L.ev_fork, 0);
   }
-  if (!(use_fast && fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r1, ss)))
-    hipLaunchKernelGGL(k_step_height, tile_grid(g, r1), blk, tile_bytes(p.step1.reach), ss, g, p.step1, L.elev,
-                       L.step_height, r1);
-  if (!(use_fast && fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r2, ss)))
-    hipLaunchKernelGGL(k_step_score, tile_grid(g, r2), blk, tile_bytes(p.step2.reach), ss, g, p.step2, p.step_crit,
-                       p.step_ncrit, L.step_height, L.step, r2);
+  if (!normals_only) {
+    if (!(use_fast && fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r1, ss)))
+      hipLaunchKernelGGL(k_step_height, tile_grid(g, r1), blk, tile_bytes(p.step1.reach), ss, g, p.step1, L.elev,
+                         L.step_height, r1);
+    if (!(use_fast && fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r2, ss)))
+      hipLaunchKernelGGL(k_step_score, tile_grid(g, r2), blk, tile_bytes(p.step2.reach), ss, g, p.step2, p.step_crit,
+                         p.step_ncrit, L.step_height, L.step, r2);
+  }
   if (overlap) (void)hipEventRecord(L.ev_join, ss);
   const bool keep = (flags & TE_RUN_KEEP_NORMALS) != 0;
   const int Kn = p.normals.reach > p.rough.reach ? p.normals.reach : p.rough.reach;
@@ -551,11 +554,11 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   na.given_normals = 0;
   // the combine is fused into the normals kernel only when the step layer is complete before it starts;
   // region runs: the step reach may exceed the normals reach, combine separately
-  na.combine = (whole && !overlap) ? 1 : 0;
+  na.combine = (whole && !overlap && !normals_only) ? 1 : 0;
   float* const knx = keep ? L.nx : nullptr;
   float* const kny = keep ? L.ny : nullptr;
   float* const knz = keep ? L.nz : nullptr;
-  const bool fused_combine = whole && !overlap;
+  const bool fused_combine = whole && !overlap && !normals_only;
   FastGrid fg;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream)) {
@@ -567,7 +570,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   }
   if (overlap) (void)hipStreamWaitEvent(stream, L.ev_join, 0);
   // with the footprint pass right behind, its mask kernel (which reads the three scores anyway) combines
-  if (!fused_combine && !(overlap && (flags & kDeferCombine))) {
+  if (!fused_combine && !normals_only && !(overlap && (flags & kDeferCombine))) {
     const dim3 cgrid((unsigned)((rc.i1 - rc.i0 + 255) / 256), (unsigned)(rc.j1 - rc.j0),
                      (unsigned)(rc.map >= 0 ? 1 : g.batch));
     hipLaunchKernelGGL(k_combine, cgrid, dim3(256), 0, stream, g, p.w_scale, p.w_slope, p.w_step, p.w_rough, L.slope,

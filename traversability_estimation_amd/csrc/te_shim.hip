@@ -300,6 +300,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   HIP_TRY(hipSetDevice(c->device));
   c->L.aux_stream = (flags & TE_RUN_SEQUENTIAL) ? nullptr : c->aux_stream;
   // whole-map run with the footprint pass right behind: the mask kernel writes the combined layer
+  if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
   c->combine_deferred = (r.map < 0) && c->L.aux_stream && (flags & TE_RUN_FOOTPRINT);
   if (c->combine_deferred) flags |= kDeferCombine;
   c->L.ev_fork = c->ev_fork;
@@ -329,7 +330,8 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   static const bool no_graph = getenv("TE_NO_GRAPH") != nullptr;
   const bool large = (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23);
-  if (!no_graph && large && c->graph_ok && c->have_params && c->have_geo && c->have_elev) {
+  if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
+  if (!no_graph && large && !(flags & TE_RUN_NORMALS_ONLY) && c->graph_ok && c->have_params && c->have_geo && c->have_elev) {
     if (!c->tables_ready) {
       int rc = rebuild_tables(c);
       if (rc) return rc;
