@@ -158,6 +158,12 @@ int te_device_ptr(te_ctx* ctx, int layer, void** dptr, size_t* bytes);
 
 /* Host -> device copy of any layer (e.g. surface_normal_z for TE_FILTER_SLOPE); elevation marks the context ready. */
 int te_upload_layer(te_ctx* ctx, int layer, const float* host, int map0, int nmaps);
+/* The same for a layer in GridMap's circular-buffer order: logical cell (i, j) is stored at ((i + start_row) % rows,
+ * (j + start_col) % cols) (grid_map_core getBufferIndexFromIndex; start index = GridMap::getStartIndex(), non-zero after
+ * GridMap::move).  The reference's filters see maps in this form: their iterators (StepFilter.cpp:112,124) hide the
+ * start index.  The device layers are always in logical order. */
+int te_upload_layer_circular(te_ctx* ctx, int layer, const float* host, int map, int start_row, int start_col);
+int te_download_layer_circular(te_ctx* ctx, int layer, float* host, int map, int start_row, int start_col);
 /* Run ONE of the reference's plugins on the resident layers (see te_filter). */
 int te_run_filter(te_ctx* ctx, int filter, unsigned flags);
 int te_run_chain(te_ctx* ctx, unsigned flags);

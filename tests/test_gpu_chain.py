@@ -265,3 +265,33 @@ def test_single_plugin_entry_points(capi, oracle):
     assert_layers_match(got, want, ctx="single plugins")
     # with the reference's float32 normals as input the slope is the same double acos of the same float
     assert (got["traversability_step"].view(np.uint32) == want["traversability_step"].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("start", [(0, 0), (5, 0), (0, 7), (37, 101), (89, 129)])
+def test_circular_buffer_layers(capi, start):
+    """A GridMap that has been move()d stores logical cell (i, j) at ((i+si) % rows, (j+sj) % cols)
+    (grid_map_core getBufferIndexFromIndex); the reference's iterators hide that.  Upload in buffer order,
+    run, download in buffer order == roll of the plain run, bit for bit."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 90, 130, 0.04
+    elev = np.array(synth.perlin_elevation(rows, cols, seed=11), dtype=np.float32).reshape(cols, rows)
+    elev[20:23, 40] = np.nan
+    si, sj = start
+    buf = np.roll(elev, (sj, si), axis=(0, 1))  # buf[(j+sj)%cols, (i+si)%rows] = elev[j, i]
+    p = capi.default_params()
+    plain = run_gpu(capi, elev, rows, cols, res, p)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(rows, cols, 1, res, (0.0, 0.0))
+        ctx.upload_layer_circular("elevation", buf, start)
+        ctx.run_chain(0)
+        ctx.sync()
+        assert np.array_equal(ctx.download("elevation").view(np.uint32), elev.reshape(-1).view(np.uint32))
+        for k in OUT_LAYERS:
+            got = ctx.download_layer_circular(k, start)
+            want = np.roll(plain[k].reshape(cols, rows), (sj, si), axis=(0, 1))
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, start)
+        with pytest.raises(capi.TeError):
+            ctx.upload_layer_circular("elevation", buf, (rows, 0))
+        with pytest.raises(capi.TeError):
+            ctx.download_layer_circular("traversability", (0, -1))

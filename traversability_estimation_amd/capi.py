@@ -29,7 +29,7 @@ RUN_NORMALS_ONLY = 0x20
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
-           "te_device_ptr", "te_upload_layer", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
+           "te_device_ptr", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
            "te_download_layer", "te_time_chain", "te_last_error", "te_version"]
 
@@ -89,6 +89,8 @@ def load():
         L.te_upload_tile.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
+        L.te_upload_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+        L.te_download_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         L.te_run_filter.argtypes = [vp, C.c_int, C.c_uint]
         L.te_run_chain.argtypes = [vp, C.c_uint]
         L.te_run_chain_region.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -198,6 +200,22 @@ class Context:
         assert a.size % per == 0, (a.size, per)
         _check(load().te_upload_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
                                       a.ctypes.data_as(C.POINTER(C.c_float)), int(map0), a.size // per))
+
+    def upload_layer_circular(self, layer, data, start_index, map_index=0):
+        """Upload ONE map's layer given in GridMap buffer order (start_index = GridMap::getStartIndex())."""
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        assert a.size == self.rows * self.cols, (a.size, self.rows, self.cols)
+        _check(load().te_upload_layer_circular(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
+                                               a.ctypes.data_as(C.POINTER(C.c_float)), int(map_index),
+                                               int(start_index[0]), int(start_index[1])))
+
+    def download_layer_circular(self, layer, start_index, map_index=0):
+        """Download ONE map's layer into GridMap buffer order; returns a (cols, rows) array (row index fastest)."""
+        out = np.empty((self.cols, self.rows), dtype=np.float32)
+        _check(load().te_download_layer_circular(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
+                                                 out.ctypes.data_as(C.POINTER(C.c_float)), int(map_index),
+                                                 int(start_index[0]), int(start_index[1])))
+        return out
 
     def run_filter(self, which, flags=0):
         _check(load().te_run_filter(self._h, FILTERS[which] if isinstance(which, str) else int(which), int(flags)))

@@ -653,6 +653,62 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
   return TE_OK;
 }
 
+namespace {
+// GridMap layers are circular buffers: logical cell (i, j) is stored at ((i + si) % rows, (j + sj) % cols)
+// (grid_map_core getBufferIndexFromIndex, (si, sj) = GridMap::getStartIndex()).  The device layers are in
+// logical order, so a layer in buffer order moves as (up to) four rectangles.
+hipError_t copy_circular(te_ctx* c, float* dev, float* host, int si, int sj, bool to_device) {
+  const int rows = c->geo.rows, cols = c->geo.cols;
+  const size_t pitch = (size_t)rows * sizeof(float);
+  const int i_split[3] = {0, rows - si, rows}, j_split[3] = {0, cols - sj, cols};
+  for (int bj = 0; bj < 2; ++bj)
+    for (int bi = 0; bi < 2; ++bi) {
+      const int li = i_split[bi], lj = j_split[bj];                  // logical origin of the rectangle
+      const int h = i_split[bi + 1] - li, w = j_split[bj + 1] - lj;  // rows x cols
+      if (h <= 0 || w <= 0) continue;
+      const int ri = (li + si) % rows, rj = (lj + sj) % cols;        // its origin in the buffer
+      float* d = dev + (size_t)lj * rows + li;
+      float* b = host + (size_t)rj * rows + ri;
+      const hipError_t e = to_device ? hipMemcpy2DAsync(d, pitch, b, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream)
+                                     : hipMemcpy2DAsync(b, pitch, d, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyDeviceToHost, c->stream);
+      if (e != hipSuccess) return e;
+    }
+  return hipStreamSynchronize(c->stream);
+}
+}  // namespace
+
+int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col) {
+  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer_circular: geometry not set");
+  float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: bad layer %d", layer);
+  if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
+    return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: map %d, start index (%d,%d) of a %dx%d map", map, start_row,
+                start_col, c->geo.rows, c->geo.cols);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(copy_circular(c, p + (size_t)map * c->geo.rows * c->geo.cols, const_cast<float*>(host), start_row, start_col, true));
+  if (layer == TE_LAYER_ELEVATION) {
+    c->have_elev = true;
+    c->chain_done = false;
+  }
+  return TE_OK;
+}
+
+int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int start_row, int start_col) {
+  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer_circular: geometry not set");
+  float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: bad layer %d", layer);
+  if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
+    return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: map %d, start index (%d,%d) of a %dx%d map", map, start_row,
+                start_col, c->geo.rows, c->geo.cols);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(copy_circular(c, p + (size_t)map * c->geo.rows * c->geo.cols, host, start_row, start_col, false));
+  return TE_OK;
+}
+
 int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_filter: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);

@@ -21,7 +21,7 @@ class DeviceMap {
   static DeviceMap& instance();
   std::mutex& mutex() { return mutex_; }
   // All calls below expect the caller to hold mutex().  They return false and fill error() on failure.
-  bool prepare(const grid_map::GridMap& map);                       // (re)sets the geometry if it changed
+  bool prepare(const grid_map::GridMap& map);                       // (re)sets the geometry if it changed, notes the start index
   bool params(te_params& p);                                        // current parameter set (to edit and pass back)
   bool setParams(const te_params& p);
   bool upload(const grid_map::GridMap& map, const std::string& layer, int te_layer);
@@ -37,6 +37,7 @@ class DeviceMap {
   std::mutex mutex_;
   te_ctx* ctx_;
   int rows_, cols_;
+  int start_row_, start_col_;  // GridMap::getStartIndex() of the map last passed to prepare()
   double res_, px_, py_;
   std::string error_;
 };

@@ -7,7 +7,7 @@ DeviceMap& DeviceMap::instance() {
   return d;
 }
 
-DeviceMap::DeviceMap() : ctx_(nullptr), rows_(0), cols_(0), res_(0), px_(0), py_(0) {}
+DeviceMap::DeviceMap() : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0) {}
 
 DeviceMap::~DeviceMap() {
   if (ctx_) te_destroy(ctx_);
@@ -21,10 +21,9 @@ bool DeviceMap::check(int rc) {
 
 bool DeviceMap::prepare(const grid_map::GridMap& map) {
   if (!ctx_ && !check(te_create(0, &ctx_))) return false;
-  if (!map.isDefaultStartIndex()) {
-    error_ = "grid map has a non-default start index; call convertToDefaultStartIndex() first";
-    return false;
-  }
+  // a moved map is a circular buffer; the copies to and from the device undo / redo the rotation
+  start_row_ = map.getStartIndex()(0);
+  start_col_ = map.getStartIndex()(1);
   const int rows = map.getSize()(0), cols = map.getSize()(1);
   const double res = map.getResolution(), px = map.getPosition().x(), py = map.getPosition().y();
   if (rows != rows_ || cols != cols_ || res != res_ || px != px_ || py != py_) {
@@ -49,6 +48,7 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
     error_ = "input layer '" + layer + "' is missing";
     return false;
   }
+  if (start_row_ || start_col_) return check(te_upload_layer_circular(ctx_, te_layer, map.get(layer).data(), 0, start_row_, start_col_));
   return check(te_upload_layer(ctx_, te_layer, map.get(layer).data(), 0, 1));
 }
 
@@ -56,6 +56,7 @@ bool DeviceMap::runFilter(int filter) { return check(te_run_filter(ctx_, filter,
 bool DeviceMap::runChain(unsigned flags) { return check(te_run_chain(ctx_, flags)); }
 
 bool DeviceMap::download(grid_map::GridMap& map, const std::string& layer, int te_layer) {
+  if (start_row_ || start_col_) return check(te_download_layer_circular(ctx_, te_layer, map.get(layer).data(), 0, start_row_, start_col_));
   return check(te_download_layer(ctx_, te_layer, map.get(layer).data(), 0, 1));
 }
 

@@ -68,6 +68,7 @@ class GridMap {
   const Vec2d& getPosition() const { return pos_; }
   const Arr2i& getStartIndex() const { return start_; }
   bool isDefaultStartIndex() const { return start_(0) == 0 && start_(1) == 0; }
+  void setStartIndex(const Arr2i& start) { start_ = start; }  // the layers are circular buffers (GridMap::move)
   void convertToDefaultStartIndex() {}
   std::vector<std::string> getLayers() const {
     std::vector<std::string> v;

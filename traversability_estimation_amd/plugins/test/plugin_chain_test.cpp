@@ -168,6 +168,51 @@ static void test_device() {
   CHECK(!fout.exists("surface_normal_x"));                             // DeletionFilter
 }
 
+// the same map as a circular buffer: logical (i, j) stored at ((i + si) % rows, (j + sj) % cols)
+static grid_map::GridMap rolled(const grid_map::GridMap& src, int si, int sj) {
+  const int rows = src.getSize()(0), cols = src.getSize()(1);
+  grid_map::GridMap m;
+  m.setGeometry(src.getLength(), src.getResolution(), src.getPosition());
+  m.setStartIndex(grid_map::Arr2i{{si, sj}});
+  for (const std::string& name : src.getLayers()) {
+    m.add(name);
+    for (int j = 0; j < cols; ++j)
+      for (int i = 0; i < rows; ++i) m[name]((i + si) % rows, (j + sj) % cols) = src.get(name)(i, j);
+  }
+  return m;
+}
+
+static void test_device_circular() {
+  // a map that has been move()d: the reference's iterators hide the start index (StepFilter.cpp:112,124)
+  const int rows = 150, cols = 120, si = 37, sj = 101;
+  const double res = 0.04;
+  grid_map::GridMap flat = make_map(rows, cols, res);
+  auto f = make(kFused);
+  CHECK(f->configure("fused", ParamMap{{"normals_radius", 0.09}, {"estimation_radius", 0.13},
+                                       {"first_window_radius", 0.1}, {"second_window_radius", 0.07}}));
+  grid_map::GridMap want, got, in = rolled(flat, si, sj);
+  CHECK(f->update(flat, want));
+  CHECK(f->update(in, got));
+  CHECK(got.getStartIndex()(0) == si && got.getStartIndex()(1) == sj);
+  std::printf("FusedChainFilter on a circular-buffer map (start index %d,%d):\n", si, sj);
+  grid_map::GridMap expect = rolled(want, si, sj);
+  const size_t n = (size_t)rows * cols;
+  for (const char* name : {"traversability_slope", "traversability_step", "traversability_roughness", "traversability"}) {
+    std::vector<float> w(expect[name].data(), expect[name].data() + n);
+    CHECK(compare(name, got[name], w) == 0);
+  }
+  // the single plugins take the same route
+  auto t = make(kStep);
+  CHECK(t->configure("stepFilter", ParamMap{{"critical_value", 0.12}, {"first_window_radius", 0.1}, {"second_window_radius", 0.07},
+                                            {"critical_cell_number", 4}, {"map_type", "traversability_step"}}));
+  grid_map::GridMap tw, tg;
+  CHECK(t->update(flat, tw));
+  CHECK(t->update(in, tg));
+  grid_map::GridMap te = rolled(tw, si, sj);
+  std::vector<float> w(te["traversability_step"].data(), te["traversability_step"].data() + n);
+  CHECK(compare("traversability_step (plugin)", tg["traversability_step"], w) == 0);
+}
+
 static void test_no_device() {
   auto t = make(kStep);
   CHECK(t->configure("stepFilter", ParamMap{{"critical_value", 0.12}, {"first_window_radius", 0.04},
@@ -180,10 +225,12 @@ static void test_no_device() {
 int main(int argc, char** argv) {
   const bool device = argc > 1 && std::strcmp(argv[1], "--device") == 0;
   test_configure();
-  if (device)
+  if (device) {
     test_device();
-  else
+    test_device_circular();
+  } else {
     test_no_device();
+  }
   std::printf("%s (%d failures)\n", g_fail ? "FAILED" : "OK", g_fail);
   return g_fail ? 1 : 0;
 }
