@@ -190,6 +190,49 @@ int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);
  * (after `warmup` untimed ones); inputs and outputs stay resident in HBM. */
 int te_time_chain(te_ctx* ctx, unsigned flags, int warmup, int iters, float* ms_per_iter);
 
+/* ---- wire formats either side of the chain: grid_map_msgs/GridMap (ROS1 serialisation) and rosbag V2.0 ----
+ * The reference node gets its elevation map as such a message (TraversabilityEstimation.cpp:248-270 requestElevationMap ->
+ * GridMapRosConverter::fromMessage), loads / saves maps from / to bags (:125-152 loadFromBag, :318-329 saveToBag) and
+ * publishes its result with toMessage.  A layer's float32 payload in the message IS the layer's Eigen matrix
+ * (column-major, circular start index = outer/inner_start_index), so it moves between the message buffer and the device
+ * with te_upload_layer_circular's rectangle copies: no host-side GridMap, no reshuffling. */
+#define TE_MSG_MAX_NAME 64
+typedef struct te_msg_info {
+  uint32_t seq, stamp_sec, stamp_nsec; /* info.header */
+  char frame_id[TE_MSG_MAX_NAME];      /* NUL-terminated */
+  double resolution, length_x, length_y;
+  double pose[7];                /* position x y z, orientation x y z w; GridMap uses position x, y only */
+  int32_t rows, cols;            /* size of every layer: dim[1].size, dim[0].size */
+  int32_t start_row, start_col;  /* outer_start_index, inner_start_index = GridMap::getStartIndex()(0), (1) */
+  int32_t n_layers, n_basic_layers;
+} te_msg_info;
+
+/* Validate a serialised message and describe it.  Rejected (TE_ERR_INVALID_ARG + message): truncation, layers/data count
+ * mismatch (fromMessage's own check), storage order other than (column_index, row_index), layer sizes that disagree with
+ * each other or with round(length / resolution), start index outside the map. */
+int te_msg_parse(const void* msg, size_t len, te_msg_info* info);
+/* Name of layer k (NUL-terminated into name[TE_MSG_MAX_NAME]) and byte offset of its rows*cols float32 payload. */
+int te_msg_layer(const void* msg, size_t len, int k, char* name, size_t* data_offset);
+/* toMessage for host layers: layer_data[k] = rows*cols float32 in the GridMap's own (column-major, circular) storage order;
+ * every field of `info` is used.  *written = bytes needed even when `cap` is too small (out = NULL, cap = 0 sizes). */
+int te_msg_write(const te_msg_info* info, int n_layers, const char* const* names, const float* const* layer_data, int n_basic,
+                 const char* const* basic_names, void* out, size_t cap, size_t* written);
+/* fromMessage + upload in one step: (re)sets the context's geometry from the message (batch 1: rows, cols, resolution,
+ * position) when it differs, then copies layer `layer_name` into device layer `layer` (te_layer), undoing the circular
+ * start index.  `info` (may be NULL) receives the parsed description. */
+int te_upload_msg(te_ctx* ctx, const void* msg, size_t len, const char* layer_name, int layer, te_msg_info* info);
+/* toMessage: serialise n_layers device layers (te_layer ids `layers`, message names `names`) of map 0 into `out`.
+ * Geometry comes from the context; seq, stamp, frame_id, pose z / orientation and the start index from `info` (its
+ * rows / cols / lengths / resolution are ignored).  *written = bytes needed even when TE_ERR_INVALID_ARG reports that
+ * `cap` is too small (call with out = NULL, cap = 0 to size the buffer). */
+int te_download_msg(te_ctx* ctx, const te_msg_info* info, int n_layers, const int* layers, const char* const* names, int n_basic,
+                    const char* const* basic_names, void* out, size_t cap, size_t* written);
+/* loadFromBag: the last grid_map_msgs/GridMap message stored under `topic` in an (uncompressed-chunk) rosbag V2.0 image. */
+int te_bag_find_message(const void* bag, size_t len, const char* topic, size_t* msg_offset, size_t* msg_len);
+/* saveToBag: a one-message bag (stamp 0.0 is written as ros::TIME_MIN like the reference).  Sizing call as above. */
+int te_bag_write(const void* msg, size_t msg_len, const char* topic, uint32_t stamp_sec, uint32_t stamp_nsec, void* out,
+                 size_t cap, size_t* written);
+
 const char* te_last_error(void);
 const char* te_version(void);
 

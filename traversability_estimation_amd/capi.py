@@ -31,7 +31,10 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
            "te_device_ptr", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
-           "te_download_layer", "te_time_chain", "te_last_error", "te_version"]
+           "te_download_layer", "te_time_chain", "te_last_error", "te_version",
+           "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
+           "te_bag_write"]
+MSG_MAX_NAME = 64
 
 
 def pack_paths(paths):
@@ -43,6 +46,16 @@ def pack_paths(paths):
         off[1:] = np.cumsum([len(p) for p in paths])
     xy = np.ascontiguousarray(np.concatenate(paths) if n and off[-1] else np.zeros((1, 2)), dtype=np.float64)
     return off, xy
+
+
+class TeMsgInfo(C.Structure):
+    """te_msg_info: the non-layer part of a grid_map_msgs/GridMap message."""
+    _fields_ = [("seq", C.c_uint32), ("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32),
+                ("frame_id", C.c_char * MSG_MAX_NAME),
+                ("resolution", C.c_double), ("length_x", C.c_double), ("length_y", C.c_double),
+                ("pose", C.c_double * 7),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("start_row", C.c_int32), ("start_col", C.c_int32),
+                ("n_layers", C.c_int32), ("n_basic_layers", C.c_int32)]
 
 
 class TeParams(C.Structure):
@@ -100,6 +113,15 @@ def load():
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        szp, cpp = C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)
+        L.te_msg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TeMsgInfo)]
+        L.te_msg_layer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, szp]
+        L.te_msg_write.argtypes = [C.POINTER(TeMsgInfo), C.c_int, cpp, C.POINTER(fp), C.c_int, cpp, vp, C.c_size_t, szp]
+        L.te_upload_msg.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.POINTER(TeMsgInfo)]
+        L.te_download_msg.argtypes = [vp, C.POINTER(TeMsgInfo), C.c_int, C.POINTER(C.c_int), cpp, C.c_int, cpp, vp,
+                                      C.c_size_t, szp]
+        L.te_bag_find_message.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, szp, szp]
+        L.te_bag_write.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_size_t, szp]
         L.te_last_error.restype = C.c_char_p
         L.te_version.restype = C.c_char_p
         _lib = L
@@ -130,6 +152,64 @@ def params_from_bytes(b):
     assert len(b) == C.sizeof(p)
     C.memmove(C.byref(p), b, len(b))
     return p
+
+
+def _names(names):
+    arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+    return arr
+
+
+def msg_parse(msg):
+    """Validate a serialised grid_map_msgs/GridMap; returns (TeMsgInfo, {layer name: byte offset of its payload})."""
+    info = TeMsgInfo()
+    _check(load().te_msg_parse(msg, len(msg), C.byref(info)))
+    layers = {}
+    name = C.create_string_buffer(MSG_MAX_NAME)
+    off = C.c_size_t()
+    for k in range(info.n_layers):
+        _check(load().te_msg_layer(msg, len(msg), k, name, C.byref(off)))
+        layers[name.value.decode()] = off.value
+    return info, layers
+
+
+def msg_layer(msg, info, offset):
+    """The payload at `offset` as a (cols, rows) float32 array in the message's own (circular) storage order."""
+    return np.frombuffer(msg, dtype="<f4", count=info.rows * info.cols, offset=offset).reshape(info.cols, info.rows)
+
+
+def msg_write(info, layers, basic_layers=()):
+    """GridMapRosConverter::toMessage for host layers: {name: rows*cols float32 in storage order} -> bytes."""
+    names = list(layers)
+    arrs = [np.ascontiguousarray(layers[n], dtype=np.float32).reshape(-1) for n in names]
+    for a in arrs:
+        assert a.size == info.rows * info.cols, (a.size, info.rows, info.cols)
+    fpp = C.POINTER(C.c_float)
+    data = (fpp * max(len(arrs), 1))(*[a.ctypes.data_as(fpp) for a in arrs])
+    need = C.c_size_t()
+    L = load()
+    L.te_msg_write(C.byref(info), len(names), _names(names), data, len(basic_layers), _names(list(basic_layers)), None, 0,
+                   C.byref(need))
+    out = C.create_string_buffer(max(need.value, 1))
+    _check(L.te_msg_write(C.byref(info), len(names), _names(names), data, len(basic_layers), _names(list(basic_layers)), out,
+                          need.value, C.byref(need)))
+    return out.raw[:need.value]
+
+
+def bag_find_message(bag, topic):
+    """GridMapRosConverter::loadFromBag's pick: the last grid_map_msgs/GridMap message under `topic`."""
+    off, n = C.c_size_t(), C.c_size_t()
+    _check(load().te_bag_find_message(bag, len(bag), topic.encode(), C.byref(off), C.byref(n)))
+    return bag[off.value:off.value + n.value]
+
+
+def bag_write(msg, topic, stamp=(0, 0)):
+    """GridMapRosConverter::saveToBag: a one-message rosbag V2.0 image."""
+    need = C.c_size_t()
+    L = load()
+    L.te_bag_write(msg, len(msg), topic.encode(), int(stamp[0]), int(stamp[1]), None, 0, C.byref(need))
+    out = C.create_string_buffer(max(need.value, 1))
+    _check(L.te_bag_write(msg, len(msg), topic.encode(), int(stamp[0]), int(stamp[1]), out, need.value, C.byref(need)))
+    return out.raw[:need.value]
 
 
 def device_count():
@@ -249,6 +329,26 @@ class Context:
                                                trav.ctypes.data_as(C.POINTER(C.c_double)),
                                                st.ctypes.data_as(C.POINTER(C.c_int))))
         return safe[:n].astype(bool), trav[:n], st[:n]
+
+    def upload_msg(self, msg, layer_name="elevation", layer="elevation"):
+        """fromMessage + upload: geometry from the message, layer `layer_name` into device layer `layer`."""
+        info = TeMsgInfo()
+        _check(load().te_upload_msg(self._h, msg, len(msg), layer_name.encode(),
+                                    LAYERS[layer] if isinstance(layer, str) else int(layer), C.byref(info)))
+        self.rows, self.cols, self.batch = info.rows, info.cols, 1
+        return info
+
+    def download_msg(self, info, layers, basic_layers=()):
+        """toMessage: {message layer name: device layer} of map 0 -> serialised grid_map_msgs/GridMap bytes."""
+        names = list(layers)
+        ids = (C.c_int * max(len(names), 1))(*[LAYERS[v] if isinstance(v, str) else int(v) for v in layers.values()])
+        need = C.c_size_t()
+        L = load()
+        args = (self._h, C.byref(info), len(names), ids, _names(names), len(basic_layers), _names(list(basic_layers)))
+        L.te_download_msg(*args, None, 0, C.byref(need))
+        out = C.create_string_buffer(max(need.value, 1))
+        _check(L.te_download_msg(*args, out, need.value, C.byref(need)))
+        return out.raw[:need.value]
 
     def sync(self):
         _check(load().te_sync(self._h))

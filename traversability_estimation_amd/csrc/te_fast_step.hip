@@ -249,8 +249,8 @@ long wave_slots(int waves) {
   static long simds = 0;
   if (!simds) {
     int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     simds = 4L * cus;
   }
   return simds * waves;

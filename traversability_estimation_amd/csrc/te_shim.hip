@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include "te_internal.h"
+#include "te_msg.h"
 
 using namespace te;
 
@@ -657,7 +658,8 @@ namespace {
 // GridMap layers are circular buffers: logical cell (i, j) is stored at ((i + si) % rows, (j + sj) % cols)
 // (grid_map_core getBufferIndexFromIndex, (si, sj) = GridMap::getStartIndex()).  The device layers are in
 // logical order, so a layer in buffer order moves as (up to) four rectangles.
-hipError_t copy_circular(te_ctx* c, float* dev, float* host, int si, int sj, bool to_device) {
+// `host` may be unaligned (a payload inside a serialised message).
+hipError_t copy_circular(te_ctx* c, float* dev, void* host, int si, int sj, bool to_device) {
   const int rows = c->geo.rows, cols = c->geo.cols;
   const size_t pitch = (size_t)rows * sizeof(float);
   const int i_split[3] = {0, rows - si, rows}, j_split[3] = {0, cols - sj, cols};
@@ -668,7 +670,7 @@ hipError_t copy_circular(te_ctx* c, float* dev, float* host, int si, int sj, boo
       if (h <= 0 || w <= 0) continue;
       const int ri = (li + si) % rows, rj = (lj + sj) % cols;        // its origin in the buffer
       float* d = dev + (size_t)lj * rows + li;
-      float* b = host + (size_t)rj * rows + ri;
+      char* b = (char*)host + ((size_t)rj * rows + ri) * sizeof(float);
       const hipError_t e = to_device ? hipMemcpy2DAsync(d, pitch, b, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream)
                                      : hipMemcpy2DAsync(b, pitch, d, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyDeviceToHost, c->stream);
       if (e != hipSuccess) return e;
@@ -706,6 +708,114 @@ int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int s
                 start_col, c->geo.rows, c->geo.cols);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(copy_circular(c, p + (size_t)map * c->geo.rows * c->geo.cols, host, start_row, start_col, false));
+  return TE_OK;
+}
+
+int te_msg_parse(const void* m, size_t len, te_msg_info* info) {
+  if (!m || !info) return fail(TE_ERR_INVALID_ARG, "te_msg_parse: NULL");
+  msg::View v;
+  std::string err;
+  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_parse: %s", err.c_str());
+  *info = v.info;
+  return TE_OK;
+}
+
+int te_msg_layer(const void* m, size_t len, int k, char* name, size_t* data_offset) {
+  if (!m || !name || !data_offset) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: NULL");
+  msg::View v;
+  std::string err;
+  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: %s", err.c_str());
+  if (k < 0 || k >= (int)v.layers.size()) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: layer %d of %zu", k, v.layers.size());
+  const msg::LayerView& l = v.layers[k];
+  if (l.name_len >= TE_MSG_MAX_NAME) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: layer name longer than %d", TE_MSG_MAX_NAME - 1);
+  memcpy(name, l.name, l.name_len);
+  name[l.name_len] = 0;
+  *data_offset = l.data_off;
+  return TE_OK;
+}
+
+int te_msg_write(const te_msg_info* info, int n_layers, const char* const* names, const float* const* layer_data, int n_basic,
+                 const char* const* basic_names, void* out, size_t cap, size_t* written) {
+  if (!info || !written || (n_layers > 0 && (!names || !layer_data))) return fail(TE_ERR_INVALID_ARG, "te_msg_write: NULL");
+  const msg::Names ln = {n_layers, names}, bn = {n_basic, basic_names};
+  *written = msg::message_size(*info, ln, bn);
+  std::vector<size_t> off;
+  std::string err;
+  if (!msg::write_skeleton(*info, ln, bn, (uint8_t*)out, out ? cap : 0, off, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_write: %s", err.c_str());
+  for (int k = 0; k < n_layers; ++k) {
+    if (!layer_data[k]) return fail(TE_ERR_INVALID_ARG, "te_msg_write: NULL layer data");
+    memcpy((uint8_t*)out + off[k], layer_data[k], (size_t)info->rows * info->cols * sizeof(float));
+  }
+  return TE_OK;
+}
+
+int te_upload_msg(te_ctx* c, const void* m, size_t len, const char* layer_name, int layer, te_msg_info* info) {
+  if (!c || !m || !layer_name) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: NULL");
+  msg::View v;
+  std::string err;
+  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: %s", err.c_str());
+  const msg::LayerView* l = nullptr;
+  for (const msg::LayerView& k : v.layers)
+    if (k.name_len == strlen(layer_name) && memcmp(k.name, layer_name, k.name_len) == 0) l = &k;
+  // setElevationMap refuses a message without the elevation layers (TraversabilityMap.cpp:135-154)
+  if (!l) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: the message has no layer '%s'", layer_name);
+  const te_msg_info& mi = v.info;
+  bool same;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    same = c->have_geo && c->geo.rows == mi.rows && c->geo.cols == mi.cols && c->geo.batch == 1 && c->geo.res == mi.resolution &&
+           c->geo.pos_x == mi.pose[0] && c->geo.pos_y == mi.pose[1];
+  }
+  if (!same) {
+    const int rc = te_set_geometry(c, mi.rows, mi.cols, 1, mi.resolution, mi.pose[0], mi.pose[1]);
+    if (rc != TE_OK) return rc;
+  }
+  if (info) *info = mi;
+  // the payload may be unaligned: it is only ever handed to the copy engine
+  return te_upload_layer_circular(c, layer, reinterpret_cast<const float*>((const uint8_t*)m + l->data_off), 0, mi.start_row,
+                                  mi.start_col);
+}
+
+int te_download_msg(te_ctx* c, const te_msg_info* info, int n_layers, const int* layers, const char* const* names, int n_basic,
+                    const char* const* basic_names, void* out, size_t cap, size_t* written) {
+  if (!c || !info || !written || (n_layers > 0 && (!layers || !names))) return fail(TE_ERR_INVALID_ARG, "te_download_msg: NULL");
+  te_msg_info mi = *info;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_msg: geometry not set");
+    mi.rows = c->geo.rows;
+    mi.cols = c->geo.cols;
+    mi.resolution = c->geo.res;
+    mi.length_x = c->geo.len_x;
+    mi.length_y = c->geo.len_y;
+    mi.pose[0] = c->geo.pos_x;
+    mi.pose[1] = c->geo.pos_y;
+  }
+  const msg::Names ln = {n_layers, names}, bn = {n_basic, basic_names};
+  *written = msg::message_size(mi, ln, bn);
+  std::vector<size_t> off;
+  std::string err;
+  if (!msg::write_skeleton(mi, ln, bn, (uint8_t*)out, out ? cap : 0, off, err)) return fail(TE_ERR_INVALID_ARG, "te_download_msg: %s", err.c_str());
+  for (int k = 0; k < n_layers; ++k) {
+    const int rc = te_download_layer_circular(c, layers[k], reinterpret_cast<float*>((uint8_t*)out + off[k]), 0, mi.start_row, mi.start_col);
+    if (rc != TE_OK) return rc;
+  }
+  return TE_OK;
+}
+
+int te_bag_find_message(const void* bag, size_t len, const char* topic, size_t* msg_offset, size_t* msg_len) {
+  if (!bag || !topic || !msg_offset || !msg_len) return fail(TE_ERR_INVALID_ARG, "te_bag_find_message: NULL");
+  std::string err;
+  if (!msg::bag_find((const uint8_t*)bag, len, topic, *msg_offset, *msg_len, err)) return fail(TE_ERR_INVALID_ARG, "te_bag_find_message: %s", err.c_str());
+  return TE_OK;
+}
+
+int te_bag_write(const void* m, size_t msg_len, const char* topic, uint32_t stamp_sec, uint32_t stamp_nsec, void* out, size_t cap,
+                 size_t* written) {
+  if (!m || !topic || !written) return fail(TE_ERR_INVALID_ARG, "te_bag_write: NULL");
+  std::string err;
+  if (!msg::bag_write((const uint8_t*)m, msg_len, topic, stamp_sec, stamp_nsec, (uint8_t*)out, out ? cap : 0, *written, err))
+    return fail(TE_ERR_INVALID_ARG, "te_bag_write: %s", err.c_str());
   return TE_OK;
 }
 
