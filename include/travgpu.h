@@ -75,7 +75,9 @@ typedef enum te_layer {
   TE_LAYER_SLOPE_FOOTPRINT = 9,   /* memo layers of checkForSlope/Step/Roughness (0/1/NaN) */
   TE_LAYER_STEP_FOOTPRINT = 10,
   TE_LAYER_ROUGHNESS_FOOTPRINT = 11,
-  TE_LAYER_COUNT = 12
+  TE_LAYER_TRAVERSABILITY_X = 12,   /* traversability_x / traversability_rot: exist after te_run_polygon_footprint */
+  TE_LAYER_TRAVERSABILITY_ROT = 13,
+  TE_LAYER_COUNT = 14
 } te_layer;
 
 /* te_run_chain flags */
@@ -182,6 +184,22 @@ int te_run_footprint(te_ctx* ctx);
  * footprint/check_robot_inclination.  Host buffers; synchronous. */
 int te_check_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* pose_xy,
                              unsigned char* is_safe, double* traversability, int* status);
+/* TraversabilityMap::traversabilityFootprint(footprintYaw) (TraversabilityMap.cpp:239-305): for every cell of every map the
+ * footprint polygon (n_points vertices points_xy = x0 y0 x1 y1 .. in the footprint frame, footprint/footprint_polygon
+ * :91-103) centred on the cell, as given -> layer traversability_x, and turned by `yaw` about z -> traversability_rot;
+ * each cell gets isTraversable(polygon)'s mean (:586-645) or 0 when the polygon touches an untraversable cell.  Needs the
+ * untraversable-cell mask the circular footprint pass leaves behind (te_run_chain with TE_RUN_FOOTPRINT or
+ * te_run_footprint first).  At most TE_MAX_POLYGON_VERTICES points.  Asynchronous like te_run_chain; read the layers
+ * with te_download_layer(TE_LAYER_TRAVERSABILITY_X / _ROT). */
+#define TE_MAX_POLYGON_VERTICES 32
+int te_run_polygon_footprint(te_ctx* ctx, int n_points, const double* points_xy, double yaw);
+/* Batched TraversabilityMap::isTraversable(polygon, traversability) (:586-645) on map `map`: polygon k has the vertices
+ * vertex_xy[2*vertex_offset[k] .. 2*vertex_offset[k+1]) in the map frame (at least one each; vertex_offset[0] == 0).
+ * traversability[k] = mean over the polygon's cells, traversabilityDefault_ when it covers no cell centre, 0 when
+ * is_traversable[k] == 0.  The per-segment polygons of checkPolygonalFootprintPath (:464-584) go through this.  Same
+ * precondition as above.  Host buffers; synchronous. */
+int te_polygons_traversable(te_ctx* ctx, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
+                            unsigned char* is_traversable, double* traversability);
 int te_sync(te_ctx* ctx);
 
 int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);

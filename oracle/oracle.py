@@ -63,6 +63,12 @@ def lib():
         L.teo_check_circular_paths.argtypes = [gp, fp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         ip = C.POINTER(C.c_int)
+        dp_ = C.POINTER(C.c_double)
+        L.teo_polygons_traversable.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int), dp_,
+                                               C.POINTER(C.c_ubyte), dp_]
+        L.teo_rotate_footprint.argtypes = [C.c_int, dp_, C.c_double, dp_]
+        L.teo_rotate_footprint.restype = None
+        L.teo_polygon_footprint.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, dp_, C.c_double, fp, fp]
         L.teo_spiral_offsets.argtypes = [gp, C.c_int, C.c_int, C.c_double, ip, ip, ip, C.c_int]
         _LIB = L
     return _LIB
@@ -168,6 +174,47 @@ def check_circular_paths(g, footprint, fp_default, paths):
     if rc:
         raise RuntimeError(f"teo_check_circular_paths failed: {rc}")
     return safe[:k].astype(bool), trav[:k], st[:k]
+
+
+def polygons_traversable(g, p, elev, slope, step, rough, trav, polygons):
+    """Batched TraversabilityMap::isTraversable(polygon) for a list of (n_i, 2) vertex arrays."""
+    n = g.rows * g.cols
+    polys = [np.asarray(q, dtype=np.float64).reshape(-1, 2) for q in polygons]
+    k = len(polys)
+    off = np.zeros(k + 1, np.int32)
+    off[1:] = np.cumsum([len(q) for q in polys])
+    xy = np.ascontiguousarray(np.concatenate(polys), dtype=np.float64)
+    ok = np.zeros(k, np.uint8)
+    out = np.zeros(k, np.float64)
+    rc = lib().teo_polygons_traversable(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
+                                        _f(_flat(rough, n)), _f(_flat(trav, n)), k, off.ctypes.data_as(C.POINTER(C.c_int)),
+                                        xy.ctypes.data_as(C.POINTER(C.c_double)), ok.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                        out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc:
+        raise RuntimeError(f"teo_polygons_traversable failed: {rc}")
+    return ok.astype(bool), out
+
+
+def rotate_footprint(points_xy, yaw):
+    pts = np.ascontiguousarray(points_xy, dtype=np.float64).reshape(-1, 2)
+    out = np.empty_like(pts)
+    lib().teo_rotate_footprint(len(pts), pts.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(yaw),
+                               out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def polygon_footprint(g, p, elev, slope, step, rough, trav, points_xy, yaw):
+    """traversabilityFootprint(footprintYaw): returns (traversability_x, traversability_rot)."""
+    n = g.rows * g.cols
+    pts = np.ascontiguousarray(points_xy, dtype=np.float64).reshape(-1, 2)
+    tx = np.empty(n, np.float32)
+    tr = np.empty(n, np.float32)
+    rc = lib().teo_polygon_footprint(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
+                                     _f(_flat(rough, n)), _f(_flat(trav, n)), len(pts),
+                                     pts.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(yaw), _f(tx), _f(tr))
+    if rc:
+        raise RuntimeError(f"teo_polygon_footprint failed: {rc}")
+    return tx, tr
 
 
 def circle_count(g, i, j, radius):

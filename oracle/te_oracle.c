@@ -709,6 +709,27 @@ static int check_step(const teo_geom* g, const float* elev, const float* step, i
   return 1;
 }
 
+/* isTraversableForFilters :774-792 for every cell, starting from all-NaN memo layers (slope_fp / step_fp /
+ * rough_fp may be NULL): untrav[cell] = 1 where it returns false. */
+static void untraversable_cells(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                                const float* rough, unsigned char* untrav, float* slope_fp, float* step_fp, float* rough_fp) {
+  const size_t N = (size_t)g->rows * g->cols;
+  for (size_t k = 0; k < N; ++k) {
+    if (slope_fp) slope_fp[k] = NAN;
+    if (step_fp) step_fp[k] = NAN;
+    if (rough_fp) rough_fp[k] = NAN;
+  }
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
+  for (int j = 0; j < g->cols; ++j) {
+    for (int i = 0; i < g->rows; ++i) {
+      int ok = check_count_zero(g, slope, i, j, 2.0, p->fp_max_gap, slope_fp);
+      if (ok) ok = check_step(g, elev, step, i, j, p->fp_critical_step, p->fp_max_gap, step_fp);
+      if (ok && p->fp_check_roughness) ok = check_count_zero(g, rough, i, j, 1.5, p->fp_max_gap, rough_fp);
+      untrav[IDX(g, i, j)] = (unsigned char)!ok;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* a13  traversabilityFootprint(radius, offset) :307-318 -> isTraversable :654-746               */
 /* ------------------------------------------------------------------------------------------- */
@@ -719,22 +740,8 @@ int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, con
   const double rmin = p->fp_radius, rmax = p->fp_radius + p->fp_offset;
   unsigned char* untrav = (unsigned char*)malloc(N);
   if (!untrav) return -2;
-  for (size_t k = 0; k < N; ++k) {
-    footprint[k] = NAN;
-    if (slope_fp) slope_fp[k] = NAN;
-    if (step_fp) step_fp[k] = NAN;
-    if (rough_fp) rough_fp[k] = NAN;
-  }
-  /* isTraversableForFilters :774-792 for every cell (each is visited at least as a spiral centre) */
-#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
-  for (int j = 0; j < g->cols; ++j) {
-    for (int i = 0; i < g->rows; ++i) {
-      int ok = check_count_zero(g, slope, i, j, 2.0, p->fp_max_gap, slope_fp);
-      if (ok) ok = check_step(g, elev, step, i, j, p->fp_critical_step, p->fp_max_gap, step_fp);
-      if (ok && p->fp_check_roughness) ok = check_count_zero(g, rough, i, j, 1.5, p->fp_max_gap, rough_fp);
-      untrav[IDX(g, i, j)] = (unsigned char)!ok;
-    }
-  }
+  for (size_t k = 0; k < N; ++k) footprint[k] = NAN;
+  untraversable_cells(g, p, elev, slope, step, rough, untrav, slope_fp, step_fp, rough_fp);
   const int rc = ring_capacity(g, rmax);
   int err = 0;
 #pragma omp parallel num_threads(g_threads)
@@ -869,5 +876,133 @@ int teo_check_circular_paths(const teo_geom* g, const float* footprint, double f
       traversability[k] = res_trav;
     }
   }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* N3  polygon footprints.  grid_map_core is not vendored by the reference: Polygon::isInside,    */
+/*     PolygonIterator (findSubmapParameters + SubmapIterator) are restated from the published   */
+/*     grid_map 1.6 sources; parity unpinned (the reference has no fixture for this path).       */
+/* ------------------------------------------------------------------------------------------- */
+/* grid_map::Polygon::isInside: crossing-number test, edge (i, j = i-1) */
+static int polygon_inside(int n, const double* v, double px, double py) {
+  int cross = 0;
+  for (int i = 0, j = n - 1; i < n; j = i++) {
+    const double xi = v[2 * i], yi = v[2 * i + 1], xj = v[2 * j], yj = v[2 * j + 1];
+    if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) cross++;
+  }
+  return cross % 2;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* isTraversable(polygon, traversability) :586-645 with computeUntraversablePolygon == false; *value = 0 when the
+ * polygon is not traversable (every caller discards the partial sum).  PolygonIterator: bounding box of the vertices,
+ * both corners bound to the map (boundPositionToRange), converted to indices (a corner that lands exactly on the map
+ * border would give an index one past the end in the reference: clamped here), SubmapIterator order (row index outer). */
+static int polygon_traversable(const teo_geom* g, const unsigned char* untrav, const float* trav, double def, int n,
+                               const double* v, double* value) {
+  double tlx = v[0], tly = v[1], brx = v[0], bry = v[1];
+  for (int k = 1; k < n; ++k) {
+    tlx = tlx < v[2 * k] ? v[2 * k] : tlx;
+    tly = tly < v[2 * k + 1] ? v[2 * k + 1] : tly;
+    brx = v[2 * k] < brx ? v[2 * k] : brx;
+    bry = v[2 * k + 1] < bry ? v[2 * k + 1] : bry;
+  }
+  tlx = bound_axis(tlx, g->len_x, g->pos_x);
+  tly = bound_axis(tly, g->len_y, g->pos_y);
+  brx = bound_axis(brx, g->len_x, g->pos_x);
+  bry = bound_axis(bry, g->len_y, g->pos_y);
+  int ti, tj, bi, bj;
+  pos_to_index(g, tlx, tly, &ti, &tj);
+  pos_to_index(g, brx, bry, &bi, &bj);
+  ti = clampi(ti, 0, g->rows - 1);
+  bi = clampi(bi, 0, g->rows - 1);
+  tj = clampi(tj, 0, g->cols - 1);
+  bj = clampi(bj, 0, g->cols - 1);
+  unsigned ncells = 0;
+  double t = 0.0;
+  for (int a = ti; a <= bi; ++a) {
+    const double px = cell_x(g, a);
+    for (int b = tj; b <= bj; ++b) {
+      if (!polygon_inside(n, v, px, cell_y(g, b))) continue;
+      const size_t o = IDX(g, a, b);
+      if (untrav[o]) { /* :603-611 */
+        *value = 0.0;
+        return 0;
+      }
+      ncells++;
+      t += finitef(trav[o]) ? (double)trav[o] : def; /* :613-618 */
+    }
+  }
+  if (ncells == 0) { /* :626-629 */
+    *value = def;
+    return def != 0.0;
+  }
+  *value = t / ncells;
+  return 1;
+}
+
+int teo_polygons_traversable(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                             const float* rough, const float* trav, int n_polygons, const int* vertex_offset,
+                             const double* vertex_xy, unsigned char* is_traversable, double* traversability) {
+  unsigned char* untrav = (unsigned char*)malloc((size_t)g->rows * g->cols);
+  if (!untrav) return -2;
+  untraversable_cells(g, p, elev, slope, step, rough, untrav, NULL, NULL, NULL);
+  for (int k = 0; k < n_polygons; ++k) {
+    const int n = vertex_offset[k + 1] - vertex_offset[k];
+    if (n < 1) {
+      free(untrav);
+      return -1;
+    }
+    is_traversable[k] = (unsigned char)polygon_traversable(g, untrav, trav, p->fp_default, n,
+                                                           vertex_xy + 2 * (size_t)vertex_offset[k], &traversability[k]);
+  }
+  free(untrav);
+  return 0;
+}
+
+/* The rotation part of  toPosition * orientation * positionToVertex  (:270-283) for a yaw-only orientation:
+ * kindr AngleAxis(yaw, 0, 0, 1) * identity -> quaternion (w, 0, 0, z) = (cos(yaw/2), 0, 0, sin(yaw/2)); Eigen's
+ * Quaternion::toRotationMatrix; linear * v.  The translation is added per cell. */
+void teo_rotate_footprint(int n_points, const double* points_xy, double yaw, double* out_xy) {
+  const double w = cos(yaw / 2.0), z = sin(yaw / 2.0);
+  const double tz = 2.0 * z, twz = tz * w, tzz = tz * z;
+  const double r00 = 1.0 - (0.0 + tzz), r01 = 0.0 - twz, r10 = 0.0 + twz, r11 = 1.0 - (0.0 + tzz);
+  for (int k = 0; k < n_points; ++k) {
+    const double px = points_xy[2 * k], py = points_xy[2 * k + 1];
+    out_xy[2 * k] = r00 * px + r01 * py;
+    out_xy[2 * k + 1] = r10 * px + r11 * py;
+  }
+}
+
+/* traversabilityFootprint(footprintYaw) :239-305: layers traversability_x (footprint as given) and traversability_rot
+ * (footprint turned by yaw) -- for every cell the footprint polygon centred on it. */
+int teo_polygon_footprint(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                          const float* rough, const float* trav, int n_points, const double* points_xy, double yaw,
+                          float* trav_x, float* trav_rot) {
+  if (n_points < 1 || n_points > 64) return -1;
+  unsigned char* untrav = (unsigned char*)malloc((size_t)g->rows * g->cols);
+  if (!untrav) return -2;
+  untraversable_cells(g, p, elev, slope, step, rough, untrav, NULL, NULL, NULL);
+  double off[2][128];
+  teo_rotate_footprint(n_points, points_xy, 0.0, off[0]);
+  teo_rotate_footprint(n_points, points_xy, yaw, off[1]);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
+  for (int j = 0; j < g->cols; ++j) {
+    for (int i = 0; i < g->rows; ++i) {
+      const double cx = cell_x(g, i), cy = cell_y(g, j);
+      for (int which = 0; which < 2; ++which) {
+        double v[128], t;
+        for (int k = 0; k < n_points; ++k) {
+          v[2 * k] = off[which][2 * k] + cx;
+          v[2 * k + 1] = off[which][2 * k + 1] + cy;
+        }
+        const int ok = polygon_traversable(g, untrav, trav, p->fp_default, n_points, v, &t);
+        (which ? trav_rot : trav_x)[IDX(g, i, j)] = ok ? (float)t : 0.0f; /* :293-300 */
+      }
+    }
+  }
+  free(untrav);
   return 0;
 }

@@ -105,6 +105,19 @@ int teo_check_circular_paths(const teo_geom* g, const float* footprint, double f
                              const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
                              double* traversability, int* status);
 
+
+/* N3: batched TraversabilityMap::isTraversable(polygon, traversability) (:586-645); polygon k has the vertices
+ * vertex_xy[2*vertex_offset[k] .. 2*vertex_offset[k+1]).  Returns -1 for a polygon without vertices. */
+int teo_polygons_traversable(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                             const float* rough, const float* trav, int n_polygons, const int* vertex_offset,
+                             const double* vertex_xy, unsigned char* is_traversable, double* traversability);
+/* the footprint points turned by yaw about z exactly as :250-283 does it (kindr angle-axis -> Eigen quaternion -> matrix) */
+void teo_rotate_footprint(int n_points, const double* points_xy, double yaw, double* out_xy);
+/* traversabilityFootprint(footprintYaw) (:239-305): layers traversability_x / traversability_rot */
+int teo_polygon_footprint(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                          const float* rough, const float* trav, int n_points, const double* points_xy, double yaw,
+                          float* trav_x, float* trav_rot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ TE_ERR_INVALID_ARG, TE_ERR_BAD_PARAM, TE_ERR_NOT_READY, TE_ERR_HIP, TE_ERR_NO_DE
 
 LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traversability_roughness=3,
               traversability=4, traversability_footprint=5, surface_normal_x=6, surface_normal_y=7,
-              surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11)
+              surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11,
+              traversability_x=12, traversability_rot=13)
 FILTERS = dict(slope=1, step=2, roughness=3, combine=4)
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
@@ -33,7 +34,7 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_sync",
            "te_download_layer", "te_time_chain", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
-           "te_bag_write"]
+           "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable"]
 MSG_MAX_NAME = 64
 
 
@@ -110,6 +111,9 @@ def load():
         L.te_run_footprint.argtypes = [vp]
         L.te_check_footprint_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.te_run_polygon_footprint.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_double]
+        L.te_polygons_traversable.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_ubyte), C.POINTER(C.c_double)]
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -349,6 +353,23 @@ class Context:
         out = C.create_string_buffer(max(need.value, 1))
         _check(L.te_download_msg(*args, out, need.value, C.byref(need)))
         return out.raw[:need.value]
+
+    def run_polygon_footprint(self, points_xy, yaw):
+        """traversabilityFootprint(footprintYaw): fills the layers traversability_x / traversability_rot."""
+        pts = np.ascontiguousarray(points_xy, dtype=np.float64).reshape(-1, 2)
+        _check(load().te_run_polygon_footprint(self._h, len(pts), pts.ctypes.data_as(C.POINTER(C.c_double)), float(yaw)))
+
+    def polygons_traversable(self, polygons, map_index=0):
+        """Batched isTraversable(polygon): list of (n_i, 2) vertex arrays -> (traversable bool[n], traversability float64[n])."""
+        off, xy = pack_paths(polygons)
+        n = len(off) - 1
+        ok = np.zeros(max(n, 1), np.uint8)
+        trav = np.zeros(max(n, 1), np.float64)
+        _check(load().te_polygons_traversable(self._h, int(map_index), n, off.ctypes.data_as(C.POINTER(C.c_int)),
+                                              xy.ctypes.data_as(C.POINTER(C.c_double)),
+                                              ok.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                              trav.ctypes.data_as(C.POINTER(C.c_double))))
+        return ok[:n].astype(bool), trav[:n]
 
     def sync(self):
         _check(load().te_sync(self._h))

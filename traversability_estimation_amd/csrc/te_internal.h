@@ -83,6 +83,19 @@ struct Layers {
   hipEvent_t ev_fork, ev_join;
 };
 
+// polygon footprints (te_polygon.hip)
+struct PolygonArgs {
+  int n;
+  double def;                                       // traversabilityDefault_
+  double off[2][2 * TE_MAX_POLYGON_VERTICES];       // vertex offsets from the centre cell: [0] as given, [1] turned by yaw
+};
+void rotate_footprint(int n_points, const double* points_xy, double yaw, double* out_xy);
+hipError_t launch_polygon_footprint(const Geo& g, const PolygonArgs& a, const float* trav, const uint8_t* untrav, float* out_x,
+                                    float* out_rot, hipStream_t stream);
+hipError_t launch_polygons_traversable(const Geo& g, double def, int n_polygons, const int* vertex_offset, const double* vertex_xy,
+                                       const float* trav, const uint8_t* untrav, unsigned char* is_traversable,
+                                       double* traversability, hipStream_t stream);
+
 // k_normals_fixup: every workgroup owns kFixTiles tiles that are fix_groups() apart (flagged tiles come in runs
 // and must spread over many workgroups) and whose flags are adjacent in memory (one coalesced load).
 constexpr int kFixTiles = 8;

@@ -115,6 +115,8 @@ struct te_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   te_params params;
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
+  float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
+  float* poly_rot = nullptr;
   Geo geo;
   ChainParams cp;
   FootprintParams fp;
@@ -267,10 +269,13 @@ void free_layers(te_ctx* c) {
   drop_graph(c);
   if (c->slab) (void)hipFree(c->slab);
   c->slab = nullptr;
+  if (c->poly_x) (void)hipFree(c->poly_x);
+  c->poly_x = c->poly_rot = nullptr;
   memset(&c->L, 0, sizeof(c->L));
   c->layer_elems = 0;
   c->have_elev = false;
   c->chain_done = false;
+  c->footprint_done = false;
 }
 
 float* layer_ptr(te_ctx* c, int layer) {
@@ -287,6 +292,8 @@ float* layer_ptr(te_ctx* c, int layer) {
     case TE_LAYER_SLOPE_FOOTPRINT: return c->L.slope_fp;
     case TE_LAYER_STEP_FOOTPRINT: return c->L.step_fp;
     case TE_LAYER_ROUGHNESS_FOOTPRINT: return c->L.rough_fp;
+    case TE_LAYER_TRAVERSABILITY_X: return c->poly_x;
+    case TE_LAYER_TRAVERSABILITY_ROT: return c->poly_rot;
     default: return nullptr;
   }
 }
@@ -529,7 +536,10 @@ int te_set_params(te_ctx* c, const te_params* p) {
     (void)rebuild_tables(c);
     return rc;
   }
-  c->chain_done = false;
+  // the filter layers stay valid when only the footprint part (fp_*, the tail of the struct) changed:
+  // traversabilityFootprint(radius, offset) is called with a new radius on an unchanged map
+  if (memcmp(&old, p, offsetof(te_params, fp_radius)) != 0) c->chain_done = false;
+  c->footprint_done = false;
   return TE_OK;
 }
 
@@ -587,6 +597,7 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
   c->geo.ay = pos_y + (0.5 * c->geo.len_y - 0.5 * res);
   c->have_geo = true;
   c->chain_done = false;
+  c->footprint_done = false;
   return rebuild_tables(c);
 }
 
@@ -602,6 +613,7 @@ int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer may be reused as soon as we return
   c->have_elev = true;
   c->chain_done = false;
+  c->footprint_done = false;
   return TE_OK;
 }
 
@@ -634,6 +646,7 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   if (layer == TE_LAYER_ELEVATION) {  // caller fills the elevation in place (zero-copy producer)
     c->have_elev = true;
     c->chain_done = false;
+    c->footprint_done = false;
   }
   return TE_OK;
 }
@@ -693,6 +706,7 @@ int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, i
   if (layer == TE_LAYER_ELEVATION) {
     c->have_elev = true;
     c->chain_done = false;
+    c->footprint_done = false;
   }
   return TE_OK;
 }
@@ -897,6 +911,76 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(TE_ERR_HIP, "te_check_footprint_paths: %s", hipGetErrorString(e));
+  return TE_OK;
+}
+
+int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, double yaw) {
+  if (!c || !points_xy) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: NULL");
+  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
+    return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
+  if (!isfinite(yaw)) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: yaw is not finite");
+  for (int k = 0; k < 2 * n_points; ++k)
+    if (!isfinite(points_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: footprint point %d is not finite", k / 2);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_run_polygon_footprint: run the chain with the footprint pass first (it marks the untraversable cells)");
+  if (c->geo.cols > 65535) return fail(TE_ERR_UNSUPPORTED, "te_run_polygon_footprint: more than 65535 columns");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->poly_x) {
+    const size_t lb = (c->layer_elems * sizeof(float) + 255) & ~(size_t)255;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 2 * lb);
+    if (e != hipSuccess) return fail(TE_ERR_HIP, "te_run_polygon_footprint: hipMalloc(%zu bytes): %s", 2 * lb, hipGetErrorString(e));
+    c->poly_x = (float*)p;
+    c->poly_rot = (float*)((char*)p + lb);
+  }
+  PolygonArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = n_points;
+  a.def = c->params.fp_default;
+  rotate_footprint(n_points, points_xy, 0.0, a.off[0]);
+  rotate_footprint(n_points, points_xy, yaw, a.off[1]);
+  HIP_TRY(launch_polygon_footprint(c->geo, a, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot, c->stream));
+  return TE_OK;
+}
+
+int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
+                            unsigned char* is_traversable, double* traversability) {
+  if (!c || n_polygons < 0 || (n_polygons > 0 && (!vertex_offset || !vertex_xy || !is_traversable || !traversability)))
+    return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: NULL argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_polygons_traversable: run the chain with the footprint pass first (it marks the untraversable cells)");
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: map %d of %d", map, c->geo.batch);
+  if (n_polygons == 0) return TE_OK;
+  if (vertex_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: bad vertex offsets");
+  for (int k = 0; k < n_polygons; ++k)
+    if (vertex_offset[k + 1] <= vertex_offset[k])
+      return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: polygon %d has no vertices (or the offsets decrease)", k);
+  const int n_vert = vertex_offset[n_polygons];
+  for (long k = 0; k < 2L * n_vert; ++k)
+    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: vertex %ld is not finite", k / 2);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t b_off = (size_t)(n_polygons + 1) * sizeof(int), b_xy = (size_t)2 * n_vert * sizeof(double);
+  const size_t b_ok = (size_t)n_polygons, b_trav = (size_t)n_polygons * sizeof(double);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, up(b_off) + up(b_xy) + up(b_trav) + up(b_ok)));
+  int* d_off = (int*)d;
+  double* d_xy = (double*)(d + up(b_off));
+  double* d_trav = (double*)(d + up(b_off) + up(b_xy));
+  unsigned char* d_ok = (unsigned char*)(d + up(b_off) + up(b_xy) + up(b_trav));
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  hipError_t e = hipMemcpyAsync(d_off, vertex_offset, b_off, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_xy, vertex_xy, b_xy, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = launch_polygons_traversable(c->geo, c->params.fp_default, n_polygons, d_off, d_xy, c->L.trav + per * map,
+                                    c->L.untrav + per * map, d_ok, d_trav, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(is_traversable, d_ok, b_ok, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_polygons_traversable: %s", hipGetErrorString(e));
   return TE_OK;
 }
 
