@@ -200,6 +200,18 @@ int te_run_polygon_footprint(te_ctx* ctx, int n_points, const double* points_xy,
  * precondition as above.  Host buffers; synchronous. */
 int te_polygons_traversable(te_ctx* ctx, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
                             unsigned char* is_traversable, double* traversability);
+/* Batched TraversabilityMap::checkFootprintPath for polygonal footprints (checkPolygonalFootprintPath, :464-584).
+ * Path k has the poses poses[7*pose_offset[k] .. 7*pose_offset[k+1]) -- position x y z, orientation x y z w, as in
+ * geometry_msgs/Pose; the footprint is n_points points x y z (path.footprint.polygon.points) in the footprint frame;
+ * conservative[k] = path.conservative (NULL: all false).  The pose polygons (toPosition * orientation * point), their
+ * conservative extensions, the convex hull of consecutive ones (grid_map::Polygon::convexHull) and the areas are computed
+ * on the host, every polygon's isTraversable on the device in one launch.  Outputs per path = TraversabilityResult:
+ * is_safe, traversability, area (a path that fails keeps the values of the segments before, as the reference's result
+ * does).  status: 0 ok, 2 no poses (:330-334), 3 the conservative vertex lists outgrew 1024 vertices.  Not covered (their
+ * defaults): publishPolygons, compute_untraversable_polygon, check_robot_inclination.  Host buffers; synchronous. */
+int te_check_polygon_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
+                                     const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                                     double* traversability, double* area, int* status);
 int te_sync(te_ctx* ctx);
 
 int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);

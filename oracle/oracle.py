@@ -69,6 +69,8 @@ def lib():
         L.teo_rotate_footprint.argtypes = [C.c_int, dp_, C.c_double, dp_]
         L.teo_rotate_footprint.restype = None
         L.teo_polygon_footprint.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, dp_, C.c_double, fp, fp]
+        L.teo_check_polygon_paths.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int), dp_, C.c_int, dp_,
+                                              C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), dp_, dp_, C.POINTER(C.c_int)]
         L.teo_spiral_offsets.argtypes = [gp, C.c_int, C.c_int, C.c_double, ip, ip, ip, C.c_int]
         _LIB = L
     return _LIB
@@ -215,6 +217,33 @@ def polygon_footprint(g, p, elev, slope, step, rough, trav, points_xy, yaw):
     if rc:
         raise RuntimeError(f"teo_polygon_footprint failed: {rc}")
     return tx, tr
+
+
+def check_polygon_paths(g, p, elev, slope, step, rough, trav, paths, points_xyz, conservative=None):
+    """checkPolygonalFootprintPath for a list of (n_i, 7) pose arrays (position xyz, orientation xyzw)."""
+    n = g.rows * g.cols
+    paths = [np.asarray(q, dtype=np.float64).reshape(-1, 7) for q in paths]
+    k = len(paths)
+    off = np.zeros(k + 1, np.int32)
+    if k:
+        off[1:] = np.cumsum([len(q) for q in paths])
+    poses = np.ascontiguousarray(np.concatenate(paths) if k and off[-1] else np.zeros((1, 7)), dtype=np.float64)
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
+    cons = None if conservative is None else np.ascontiguousarray(conservative, dtype=np.uint8)
+    safe = np.zeros(max(k, 1), np.uint8)
+    out = np.zeros(max(k, 1), np.float64)
+    area = np.zeros(max(k, 1), np.float64)
+    st = np.zeros(max(k, 1), np.int32)
+    dp_ = C.POINTER(C.c_double)
+    rc = lib().teo_check_polygon_paths(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
+                                       _f(_flat(rough, n)), _f(_flat(trav, n)), k, off.ctypes.data_as(C.POINTER(C.c_int)),
+                                       poses.ctypes.data_as(dp_), len(pts), pts.ctypes.data_as(dp_),
+                                       None if cons is None else cons.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                       safe.ctypes.data_as(C.POINTER(C.c_ubyte)), out.ctypes.data_as(dp_),
+                                       area.ctypes.data_as(dp_), st.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc:
+        raise RuntimeError(f"teo_check_polygon_paths failed: {rc}")
+    return safe[:k].astype(bool), out[:k], area[:k], st[:k]
 
 
 def circle_count(g, i, j, radius):

@@ -1006,3 +1006,155 @@ int teo_polygon_footprint(const teo_geom* g, const teo_params* p, const float* e
   free(untrav);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* N2 (polygon half)  checkPolygonalFootprintPath :464-584 with publishPolygons == false,         */
+/*     compute_untraversable_polygon == false, check_robot_inclination == false.                 */
+/*     grid_map::Polygon::convexHull / monotoneChainConvexHullOfPoints / getArea and Eigen's     */
+/*     Translation * Quaternion * Vector3 are restated from the published sources (unpinned).    */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct pt2 {
+  double x, y;
+} pt2;
+
+static int pt_less(const void* a, const void* b) { /* sortVertices: x, then y */
+  const pt2 *p = (const pt2*)a, *q = (const pt2*)b;
+  if (p->x < q->x || (p->x == q->x && p->y < q->y)) return -1;
+  if (q->x < p->x || (q->x == p->x && q->y < p->y)) return 1;
+  return 0;
+}
+
+/* vectorsMakeClockwiseTurn(pivot, v1, v2): cross(v1 - pivot, v2 - pivot) <= 0 */
+static int clockwise(pt2 o, pt2 a, pt2 b) {
+  const double ax = a.x - o.x, ay = a.y - o.y, bx = b.x - o.x, by = b.y - o.y;
+  return ax * by - bx * ay <= 0.0;
+}
+
+/* monotoneChainConvexHullOfPoints; hull must hold 2*n points; returns the number of hull vertices */
+static int convex_hull(int n, const pt2* pts, pt2* sorted, pt2* hull) {
+  if (n <= 3) {
+    memcpy(hull, pts, sizeof(pt2) * (size_t)n);
+    return n;
+  }
+  memcpy(sorted, pts, sizeof(pt2) * (size_t)n);
+  qsort(sorted, (size_t)n, sizeof(pt2), pt_less);
+  int k = 0;
+  for (int i = 0; i < n; ++i) { /* lower hull */
+    while (k >= 2 && clockwise(hull[k - 2], hull[k - 1], sorted[i])) k--;
+    hull[k++] = sorted[i];
+  }
+  for (int i = n - 2, t = k + 1; i >= 0; i--) { /* upper hull */
+    while (k >= t && clockwise(hull[k - 2], hull[k - 1], sorted[i])) k--;
+    hull[k++] = sorted[i];
+  }
+  return k - 1;
+}
+
+static double polygon_area(int n, const pt2* v) { /* Polygon::getArea */
+  double area = 0.0;
+  int j = n - 1;
+  for (int i = 0; i < n; i++) {
+    area += (v[j].x + v[i].x) * (v[j].y - v[i].y);
+    j = i;
+  }
+  return fabs(area / 2.0);
+}
+
+#define TEO_MAX_PATH_VERTS 1024 /* vertices of one (conservative) pose polygon */
+
+int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                            const float* rough, const float* trav, int n_paths, const int* pose_offset, const double* poses,
+                            int n_points, const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                            double* traversability, double* area, int* status) {
+  if (n_points < 1 || n_points > 32) return -1;
+  unsigned char* untrav = (unsigned char*)malloc((size_t)g->rows * g->cols);
+  if (!untrav) return -2;
+  untraversable_cells(g, p, elev, slope, step, rough, untrav, NULL, NULL, NULL);
+  for (int k = 0; k < n_paths; ++k) {
+    const int n = pose_offset[k + 1] - pose_offset[k];
+    is_safe[k] = 0;
+    traversability[k] = 0.0;
+    area[k] = 0.0;
+    status[k] = 0;
+    if (n <= 0) { /* :330-334 */
+      status[k] = 2;
+      continue;
+    }
+    pt2 poly1[TEO_MAX_PATH_VERTS], poly2[TEO_MAX_PATH_VERTS], all[2 * TEO_MAX_PATH_VERTS], sorted[2 * TEO_MAX_PATH_VERTS],
+        hull[4 * TEO_MAX_PATH_VERTS];
+    int n1 = 0, n2 = 0, ok = 1;
+    double sx, sy, ex = 0.0, ey = 0.0, t = 0.0;
+    for (int i = 0; i < n && ok; ++i) {
+      const double* q = poses + 7 * (size_t)(pose_offset[k] + i);
+      memcpy(poly1, poly2, sizeof(pt2) * (size_t)n2); /* polygon1 = polygon2 */
+      n1 = n2;
+      sx = ex;
+      sy = ey;
+      ex = q[0];
+      ey = q[1];
+      { /* toPosition * orientation * positionToVertex: Quaternion::toRotationMatrix, linear * v + translation */
+        const double x = q[3], y = q[4], z = q[5], w = q[6];
+        const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+        const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                     tyz = tz * y, tzz = tz * z;
+        const double r00 = 1.0 - (tyy + tzz), r01 = txy - twz, r02 = txz + twy;
+        const double r10 = txy + twz, r11 = 1.0 - (txx + tzz), r12 = tyz - twx;
+        for (int m = 0; m < n_points; ++m) {
+          const double px = points_xyz[3 * m], py = points_xyz[3 * m + 1], pz = points_xyz[3 * m + 2];
+          poly2[m].x = ((r00 * px + r01 * py) + r02 * pz) + q[0];
+          poly2[m].y = ((r10 * px + r11 * py) + r12 * pz) + q[1];
+        }
+        n2 = n_points;
+      }
+      if (conservative && conservative[k] && i > 0) { /* :512-522 */
+        const double dx = ex - sx, dy = ey - sy;
+        const int m1 = n1, m2 = n2;
+        for (int m = 0; m < m1; ++m) {
+          poly2[n2].x = poly1[m].x + dx;
+          poly2[n2].y = poly1[m].y + dy;
+          n2++;
+        }
+        for (int m = 0; m < m2; ++m) {
+          poly1[n1].x = poly2[m].x - dx;
+          poly1[n1].y = poly2[m].y - dy;
+          n1++;
+        }
+      }
+      if (n == 1) { /* :524-546 */
+        if (!polygon_traversable(g, untrav, trav, p->fp_default, n2, (const double*)poly2, &t)) {
+          ok = 0;
+          break;
+        }
+        traversability[k] = t;
+        area[k] = polygon_area(n2, poly2);
+      }
+      if (n > 1 && i > 0) { /* :548-579 */
+        memcpy(all, poly1, sizeof(pt2) * (size_t)n1);
+        memcpy(all + n1, poly2, sizeof(pt2) * (size_t)n2);
+        const int nh = convex_hull(n1 + n2, all, sorted, hull);
+        if (!polygon_traversable(g, untrav, trav, p->fp_default, nh, (const double*)hull, &t)) {
+          ok = 0;
+          break;
+        }
+        if (i > 1) {
+          const double area_previous = area[k];
+          const double area_polygon = polygon_area(nh, hull) - polygon_area(n1, poly1);
+          area[k] += area_polygon;
+          traversability[k] = (area_polygon * t + area_previous * traversability[k]) / area[k];
+        } else {
+          area[k] = polygon_area(nh, hull);
+          traversability[k] = t;
+        }
+      }
+      /* the conservative vertex lists grow by n_points with every pose; the reference grows without bound, here the
+       * path is refused once the next pose would not fit */
+      if (conservative && conservative[k] && n2 + n_points > TEO_MAX_PATH_VERTS && i + 1 < n) {
+        status[k] = 3;
+        ok = 0;
+      }
+    }
+    if (ok) is_safe[k] = 1; /* on failure the partial traversability / area stay, like result in the reference */
+  }
+  free(untrav);
+  return 0;
+}

@@ -118,6 +118,15 @@ int teo_polygon_footprint(const teo_geom* g, const teo_params* p, const float* e
                           const float* rough, const float* trav, int n_points, const double* points_xy, double yaw,
                           float* trav_x, float* trav_rot);
 
+/* N2 (polygon footprints): checkPolygonalFootprintPath (:464-584) for n_paths paths.  poses: 7 doubles per pose (position
+ * x y z, orientation x y z w), footprint points_xyz: 3 doubles per point (<= 32 points), conservative: per path flag or
+ * NULL.  Outputs per path like TraversabilityResult: is_safe, traversability, area (partial values stay when a segment
+ * fails, as in the reference).  status: 0 ok, 2 no poses, 3 conservative vertex lists outgrew the buffer. */
+int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                            const float* rough, const float* trav, int n_paths, const int* pose_offset, const double* poses,
+                            int n_points, const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                            double* traversability, double* area, int* status);
+
 #ifdef __cplusplus
 }
 #endif

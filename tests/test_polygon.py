@@ -237,3 +237,136 @@ def test_polygon_calls_need_the_mask(capi, oracle):
         ctx.run_polygon_footprint(FOOTPRINT, 0.0)
         ctx.sync()
         assert np.isfinite(ctx.download("traversability_x")).all()
+
+
+# ---------------------------------------------------------------- polygonal footprint paths (:464-584)
+POINTS_XYZ = [[0.45, 0.30, 0.0], [0.45, -0.30, 0.0], [-0.45, -0.30, 0.0], [-0.45, 0.30, 0.0]]
+
+
+def random_pose_paths(g, rng, count, scale=1.0):
+    """MPC-style candidates: 1..5 poses, mostly yaw-only orientations, a few tilted, some starting outside the map."""
+    paths, cons = [], []
+    for k in range(count):
+        n = int(rng.integers(1, 6))
+        start = np.array([g.pos_x, g.pos_y]) + (rng.random(2) - 0.5) * np.array([g.len_x, g.len_y]) * (1.25 if k % 9 == 0 else 0.9)
+        xy = np.vstack([start, start + np.cumsum(rng.uniform(-0.6, 0.6, size=(n - 1, 2)) * scale, axis=0)]) if n > 1 else start[None]
+        yaw = rng.uniform(-math.pi, math.pi, n)
+        q = np.stack([np.zeros(n), np.zeros(n), np.sin(yaw / 2), np.cos(yaw / 2)], axis=1)
+        if k % 5 == 0:  # roll / pitch as well; not normalised on purpose (Eigen does not normalise either)
+            q = q + rng.normal(0, 0.05, size=q.shape)
+        paths.append(np.hstack([xy, rng.uniform(-0.2, 0.2, (n, 1)), q]))
+        cons.append(k % 3 == 0)
+    return paths, np.array(cons, np.uint8)
+
+
+def py_hull(points):
+    pts = [tuple(p) for p in points]
+    if len(pts) <= 3:
+        return pts
+    s = sorted(pts)
+    cw = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (b[0] - o[0]) * (a[1] - o[1]) <= 0.0  # noqa: E731
+    h = []
+    for p in s:
+        while len(h) >= 2 and cw(h[-2], h[-1], p):
+            h.pop()
+        h.append(p)
+    t = len(h) + 1
+    for p in reversed(s[:-1]):
+        while len(h) >= t and cw(h[-2], h[-1], p):
+            h.pop()
+        h.append(p)
+    return h[:-1]
+
+
+def py_area(v):
+    area, j = 0.0, len(v) - 1
+    for i in range(len(v)):
+        area += (v[j][0] + v[i][0]) * (v[j][1] - v[i][1])
+        j = i
+    return abs(area / 2.0)
+
+
+def py_check_polygon_path(g, untrav, trav, default, poses, points, conservative):
+    n = len(poses)
+    if n == 0:
+        return False, 0.0, 0.0, 2
+    res_t, res_a = 0.0, 0.0
+    poly2, ex, ey = [], 0.0, 0.0
+    for i in range(n):
+        q = [float(v) for v in poses[i]]
+        poly1 = list(poly2)
+        sx, sy, ex, ey = ex, ey, q[0], q[1]
+        x, y, z, w = q[3:7]
+        tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+        twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+        r00, r01, r02 = 1.0 - (tyy + tzz), txy - twz, txz + twy
+        r10, r11, r12 = txy + twz, 1.0 - (txx + tzz), tyz - twx
+        poly2 = [(((r00 * px + r01 * py) + r02 * pz) + q[0], ((r10 * px + r11 * py) + r12 * pz) + q[1]) for px, py, pz in points]
+        if conservative and i > 0:
+            dx, dy = ex - sx, ey - sy
+            v1, v2 = list(poly1), list(poly2)
+            poly2 += [(vx + dx, vy + dy) for vx, vy in v1]
+            poly1 += [(vx - dx, vy - dy) for vx, vy in v2]
+        if n == 1:
+            ok, t = py_polygon(g, untrav, trav, default, poly2)
+            if not ok:
+                return False, res_t, res_a, 0
+            res_t, res_a = t, py_area(poly2)
+        if n > 1 and i > 0:
+            hull = py_hull(poly1 + poly2)
+            ok, t = py_polygon(g, untrav, trav, default, hull)
+            if not ok:
+                return False, res_t, res_a, 0
+            if i > 1:
+                prev, ap = res_a, py_area(hull) - py_area(poly1)
+                res_a += ap
+                res_t = (ap * t + prev * res_t) / res_a
+            else:
+                res_a, res_t = py_area(hull), t
+    return True, res_t, res_a, 0
+
+
+def test_oracle_polygon_paths_match_python_restatement(oracle):
+    rows, cols, res = 60, 45, 0.05
+    g = oracle.geom(rows, cols, res, (0.3, -1.1))
+    p = oracle.default_params(fp_default=0.3)
+    elev = terrain(rows, cols, seed=15, boxes=12)
+    layers = chain_layers(oracle, g, p, elev)
+    untrav = untraversable_mask(oracle, g, p, elev, layers)
+    pts = np.array(POINTS_XYZ) * 0.5
+    paths, cons = random_pose_paths(g, np.random.default_rng(21), 80, scale=0.5)
+    paths.append(np.zeros((0, 7)))
+    cons = np.append(cons, 0).astype(np.uint8)
+    safe, val, area, st = oracle.check_polygon_paths(g, p, elev, layers["traversability_slope"], layers["traversability_step"],
+                                                     layers["traversability_roughness"], layers["traversability"], paths, pts,
+                                                     cons)
+    for k, path in enumerate(paths):
+        want = py_check_polygon_path(g, untrav, layers["traversability"], 0.3, path, [tuple(v) for v in pts], bool(cons[k]))
+        assert (bool(safe[k]), val[k], area[k], int(st[k])) == want, (k, want)
+    assert 10 < safe.sum() < len(paths) - 10 and st[-1] == 2
+
+
+@pytest.mark.gpu
+def test_polygon_paths_on_the_device(capi, oracle):
+    rows, cols, res = 160, 140, 0.05
+    elev = terrain(rows, cols, seed=31, boxes=12)
+    ctx, g, op, layers = gpu_setup(capi, oracle, rows, cols, res, (2.0, -3.0), elev, fp_default=0.3)
+    paths, cons = random_pose_paths(g, np.random.default_rng(4), 600)
+    paths.append(np.zeros((0, 7)))
+    cons = np.append(cons, 1).astype(np.uint8)
+    with ctx:
+        got = ctx.check_polygon_footprint_paths(paths, POINTS_XYZ, cons)
+        got_nc = ctx.check_polygon_footprint_paths(paths, POINTS_XYZ)
+        assert all(len(v) == 0 for v in ctx.check_polygon_footprint_paths([], POINTS_XYZ))
+        with pytest.raises(capi.TeError, match="footprint points"):
+            ctx.check_polygon_footprint_paths(paths[:1], np.zeros((0, 3)))
+        with pytest.raises(capi.TeError, match="not finite"):
+            ctx.check_polygon_footprint_paths([np.full((2, 7), np.nan)], POINTS_XYZ)
+    args = (g, op, elev, layers["traversability_slope"], layers["traversability_step"], layers["traversability_roughness"],
+            layers["traversability"], paths, POINTS_XYZ)
+    for have, want in ((got, oracle.check_polygon_paths(*args, cons)), (got_nc, oracle.check_polygon_paths(*args))):
+        assert np.array_equal(have[0], want[0]) and np.array_equal(have[3], want[3])
+        assert np.array_equal(have[1].view(np.uint64), want[1].view(np.uint64))
+        assert np.array_equal(have[2].view(np.uint64), want[2].view(np.uint64))
+    assert 50 < got[0].sum() < len(paths) - 50
+    assert not np.array_equal(got[0], got_nc[0]) or not np.array_equal(got[2], got_nc[2])  # conservative matters

@@ -4,10 +4,12 @@
   cfg2  one 1024 x 1024 map, radius 5 cells                       (launch-latency regime)
   cfg4  a batch of 512 x 512 maps, radius 5 cells, one launch     (the batch axis, what multi-GPU shards)
   cfg5  8192 x 8192 resident map, 256 x 256 dirty tiles per tick  (te_upload_tile + te_run_chain_region)
+  N2    batched circular checkFootprintPath, N3 polygon footprint layers
 
 Prints one JSON object; the committed copy is profiles/r01_configs.json.  Needs an MI355X.
 """
 import json
+import math
 import os
 import sys
 import time
@@ -24,12 +26,7 @@ def params(capi, synth, cells, res):
                                fp_radius=synth.benchmark_radius(6.0, res), fp_offset=synth.benchmark_radius(3.0, res))
 
 
-def main():
-    from traversability_estimation_amd import capi, synth
-    capi.load()
-    res = 0.05
-    out = {}
-
+def run_cfg2(capi, synth, res, out):
     # ---- cfg2 -----------------------------------------------------------------------------------------------
     n = 1024
     with capi.Context(0) as c:
@@ -40,6 +37,8 @@ def main():
             ms = c.time_chain(flags, warmup=5, iters=100)
             out[f"cfg2 1024x1024 R5 {name}"] = {"ms_per_launch": ms, "cells_per_s": n * n / (ms * 1e-3)}
 
+
+def run_cfg4(capi, synth, res, out):
     # ---- cfg4 -----------------------------------------------------------------------------------------------
     n, B = 512, int(os.environ.get("TE_CFG4_MAPS", "512"))
     base = synth.perlin_elevation(n, n, seed=2000)
@@ -54,6 +53,8 @@ def main():
             out[f"cfg4 {B} x 512x512 R5 {name}"] = {"ms_per_launch": ms, "cells_per_s": B * n * n / (ms * 1e-3)}
     del maps
 
+
+def run_cfg5(capi, synth, res, out):
     # ---- cfg5 -----------------------------------------------------------------------------------------------
     n, tile = 8192, 256
     elev = synth.perlin_elevation(n, n, seed=77)
@@ -78,6 +79,8 @@ def main():
             "tick_ms_median": float(np.median(lat)), "tick_ms_p95": float(np.percentile(lat, 95)),
             "ticks_per_s": 1e3 / float(np.median(lat)),
             "what": "host-timed: H2D of the tile + re-filter of the dilated region + sync (outputs stay resident)"}
+
+def run_n2(capi, synth, res, out):
     # ---- N2: batched circular checkFootprintPath on the resident footprint layer -----------------------------
     from oracle import oracle as O
     n = 4096
@@ -117,6 +120,56 @@ def main():
             "cpu_oracle_paths_per_s": m / dt_cpu,
             "what": "te_check_footprint_paths on packed host arrays, H2D of the poses and D2H of the results included; the oracle "
                     "(1 thread, same layer) on the first 20000 paths, results bit-identical"}
+
+def run_n3(capi, synth, res, out):
+    # ---- N3: traversabilityFootprint(footprintYaw): the polygon footprint layers over the whole map ------------
+    from oracle import oracle as O
+    footprint = [[0.45, 0.30], [0.45, -0.30], [-0.45, -0.30], [-0.45, 0.30]]  # robot_footprint_parameter.yaml:3
+    yaw = math.pi / 2                                                          # footprint_yaw default
+    n = 4096
+    elev = synth.perlin_elevation(n, n, seed=1235)
+    with capi.Context(0) as c:
+        c.set_params(params(capi, synth, 9.0, res))
+        c.set_geometry(n, n, 1, res)
+        c.upload_elevation(elev)
+        c.run_chain(capi.RUN_FOOTPRINT)
+        c.run_polygon_footprint(footprint, yaw)  # warm-up (allocates the two layers)
+        c.sync()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            c.run_polygon_footprint(footprint, yaw)
+            c.sync()
+            d = time.perf_counter() - t0
+            best = d if best is None or d < best else best
+        tx = c.download("traversability_x").reshape(n, n)
+    # the oracle on a 384 x 384 crop (its own chain first; the polygon pass alone is timed)
+    m = 384
+    crop = np.ascontiguousarray(elev.reshape(n, n)[:m, :m])
+    g = O.geom(m, m, res)
+    op = O.default_params(**{k: getattr(params(capi, synth, 9.0, res), k) for k in
+                             ("normals_radius", "rough_radius", "step_radius1", "step_radius2", "fp_radius", "fp_offset")})
+    L = O.chain(g, op, crop)
+    t0 = time.perf_counter()
+    O.polygon_footprint(g, op, crop, L["traversability_slope"], L["traversability_step"], L["traversability_roughness"],
+                        L["traversability"], footprint, yaw)
+    dt_cpu = time.perf_counter() - t0
+    out["N3 traversabilityFootprint(yaw): traversability_x + traversability_rot, 0.9 x 0.6 m footprint on 4096x4096"] = {
+        "gpu_ms": best * 1e3, "gpu_cells_per_s": n * n / best, "untraversable_fraction_x": float((tx == 0).mean()),
+        "cpu_oracle_cells_per_s": m * m / dt_cpu,
+        "what": "host-timed te_run_polygon_footprint + te_sync on resident layers (both polygons for every cell); the "
+                "oracle (1 thread, untraversable mask included) on a 384 x 384 crop"}
+
+
+def main():
+    from traversability_estimation_amd import capi, synth
+    capi.load()
+    res = 0.05
+    out = {}
+    only = [k for k in os.environ.get("TE_CONFIGS", "").split(",") if k]  # e.g. TE_CONFIGS=N3,N3P runs those alone
+    for name, fn in (("cfg2", run_cfg2), ("cfg4", run_cfg4), ("cfg5", run_cfg5), ("N2", run_n2), ("N3", run_n3)):
+        if not only or name in only:
+            fn(capi, synth, res, out)
     print(json.dumps(out, indent=1))
 
 

@@ -34,7 +34,8 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_sync",
            "te_download_layer", "te_time_chain", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
-           "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable"]
+           "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
+           "te_check_polygon_footprint_paths"]
 MSG_MAX_NAME = 64
 
 
@@ -114,6 +115,9 @@ def load():
         L.te_run_polygon_footprint.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_double]
         L.te_polygons_traversable.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                               C.POINTER(C.c_ubyte), C.POINTER(C.c_double)]
+        L.te_check_polygon_footprint_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int,
+                                                       C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
+                                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -370,6 +374,29 @@ class Context:
                                               ok.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                               trav.ctypes.data_as(C.POINTER(C.c_double))))
         return ok[:n].astype(bool), trav[:n]
+
+    def check_polygon_footprint_paths(self, paths, points_xyz, conservative=None, map_index=0):
+        """Batched checkFootprintPath for a polygonal footprint: paths = list of (n_i, 7) pose arrays (position xyz,
+        orientation xyzw); returns (is_safe bool[n], traversability[n], area[n], status[n])."""
+        paths = [np.asarray(p, dtype=np.float64).reshape(-1, 7) for p in paths]
+        n = len(paths)
+        off = np.zeros(n + 1, np.int32)
+        if n:
+            off[1:] = np.cumsum([len(p) for p in paths])
+        poses = np.ascontiguousarray(np.concatenate(paths) if n and off[-1] else np.zeros((1, 7)), dtype=np.float64)
+        pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
+        cons = None if conservative is None else np.ascontiguousarray(conservative, dtype=np.uint8)
+        safe = np.zeros(max(n, 1), np.uint8)
+        trav = np.zeros(max(n, 1), np.float64)
+        area = np.zeros(max(n, 1), np.float64)
+        st = np.zeros(max(n, 1), np.int32)
+        dp = C.POINTER(C.c_double)
+        _check(load().te_check_polygon_footprint_paths(
+            self._h, int(map_index), n, off.ctypes.data_as(C.POINTER(C.c_int)), poses.ctypes.data_as(dp), len(pts),
+            pts.ctypes.data_as(dp), None if cons is None else cons.ctypes.data_as(C.POINTER(C.c_ubyte)),
+            safe.ctypes.data_as(C.POINTER(C.c_ubyte)), trav.ctypes.data_as(dp), area.ctypes.data_as(dp),
+            st.ctypes.data_as(C.POINTER(C.c_int))))
+        return safe[:n].astype(bool), trav[:n], area[:n], st[:n]
 
     def sync(self):
         _check(load().te_sync(self._h))

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "travgpu.h"
 
 namespace te {
@@ -95,6 +97,18 @@ hipError_t launch_polygon_footprint(const Geo& g, const PolygonArgs& a, const fl
 hipError_t launch_polygons_traversable(const Geo& g, double def, int n_polygons, const int* vertex_offset, const double* vertex_xy,
                                        const float* trav, const uint8_t* untrav, unsigned char* is_traversable,
                                        double* traversability, hipStream_t stream);
+
+// the polygons checkPolygonalFootprintPath evaluates for a batch of paths (host side), in path order
+constexpr int kMaxPathPolygonVertices = 1024;
+struct PathPolygons {
+  std::vector<int> vertex_offset;     // polygon p: vertices [vertex_offset[p], vertex_offset[p+1])
+  std::vector<double> vertex_xy;
+  std::vector<double> area;           // polygon.getArea()
+  std::vector<double> area_previous;  // polygon1.getArea() of the same iteration (:574)
+  std::vector<int> first, count, status;  // per path
+};
+void build_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
+                         const unsigned char* conservative, PathPolygons& out);
 
 // k_normals_fixup: every workgroup owns kFixTiles tiles that are fix_groups() apart (flagged tiles come in runs
 // and must spread over many workgroups) and whose flags are adjacent in memory (one coalesced load).

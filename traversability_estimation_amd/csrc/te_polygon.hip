@@ -12,6 +12,8 @@
 // and mask layers coalesce.  Inside / outside is grid_map::Polygon::isInside's crossing-number expression evaluated in
 // the same order in double: footprints whose edges pass through cell centres (0.45 m at 0.05 m resolution) are decided
 // by its rounding, cell by cell.  The division is skipped when the cell is clearly left or right of the whole edge.
+#include <algorithm>
+
 #include "te_geom.h"
 #include "te_internal.h"
 
@@ -160,6 +162,120 @@ void rotate_footprint(int n_points, const double* points_xy, double yaw, double*
     const double px = points_xy[2 * k], py = points_xy[2 * k + 1];
     out_xy[2 * k] = r00 * px + r01 * py;
     out_xy[2 * k + 1] = r10 * px + r11 * py;
+  }
+}
+
+// ---- checkPolygonalFootprintPath (TraversabilityMap.cpp:464-584), host part: the polygons of every path ----------------
+namespace {
+
+struct P2 {
+  double x, y;
+};
+
+// grid_map::Polygon::monotoneChainConvexHullOfPoints (sortVertices: x then y; vectorsMakeClockwiseTurn: cross <= 0)
+void convex_hull(const std::vector<P2>& points, std::vector<P2>& hull) {
+  const size_t n = points.size();
+  if (n <= 3) {
+    hull = points;
+    return;
+  }
+  std::vector<P2> sorted(points);
+  std::sort(sorted.begin(), sorted.end(), [](const P2& a, const P2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+  auto clockwise = [](const P2& o, const P2& a, const P2& b) {
+    const double ax = a.x - o.x, ay = a.y - o.y, bx = b.x - o.x, by = b.y - o.y;
+    return ax * by - bx * ay <= 0.0;
+  };
+  hull.assign(2 * n, P2{0.0, 0.0});
+  int k = 0;
+  for (size_t i = 0; i < n; ++i) {
+    while (k >= 2 && clockwise(hull[k - 2], hull[k - 1], sorted[i])) k--;
+    hull[k++] = sorted[i];
+  }
+  for (int i = (int)n - 2, t = k + 1; i >= 0; i--) {
+    while (k >= t && clockwise(hull[k - 2], hull[k - 1], sorted[i])) k--;
+    hull[k++] = sorted[i];
+  }
+  hull.resize(k - 1);
+}
+
+double polygon_area(const std::vector<P2>& v) {  // Polygon::getArea
+  double area = 0.0;
+  size_t j = v.size() - 1;
+  for (size_t i = 0; i < v.size(); i++) {
+    area += (v[j].x + v[i].x) * (v[j].y - v[i].y);
+    j = i;
+  }
+  return fabs(area / 2.0);
+}
+
+}  // namespace
+
+void build_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
+                         const unsigned char* conservative, PathPolygons& out) {
+  out.vertex_offset.assign(1, 0);
+  out.vertex_xy.clear();
+  out.area.clear();
+  out.area_previous.clear();
+  out.first.assign(n_paths, 0);
+  out.count.assign(n_paths, 0);
+  out.status.assign(n_paths, 0);
+  std::vector<P2> poly1, poly2, all, hull;
+  auto emit = [&](const std::vector<P2>& poly, double area_prev) {
+    for (const P2& v : poly) {
+      out.vertex_xy.push_back(v.x);
+      out.vertex_xy.push_back(v.y);
+    }
+    out.vertex_offset.push_back((int)(out.vertex_xy.size() / 2));
+    out.area.push_back(polygon_area(poly));
+    out.area_previous.push_back(area_prev);
+  };
+  for (int k = 0; k < n_paths; ++k) {
+    const int n = pose_offset[k + 1] - pose_offset[k];
+    out.first[k] = (int)out.area.size();
+    if (n <= 0) {  // :330-334 "This path has no poses to check!"
+      out.status[k] = 2;
+      continue;
+    }
+    const bool cons = conservative && conservative[k];
+    poly2.clear();
+    double ex = 0.0, ey = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double* q = poses + 7 * (size_t)(pose_offset[k] + i);
+      poly1 = poly2;  // :481
+      const double sx = ex, sy = ey;
+      ex = q[0];
+      ey = q[1];
+      // toPosition * orientation * positionToVertex (:497): Eigen Quaternion::toRotationMatrix, linear * v + translation
+      const double x = q[3], y = q[4], z = q[5], w = q[6];
+      const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+                   tzz = tz * z;
+      const double r00 = 1.0 - (tyy + tzz), r01 = txy - twz, r02 = txz + twy;
+      const double r10 = txy + twz, r11 = 1.0 - (txx + tzz), r12 = tyz - twx;
+      poly2.clear();
+      for (int m = 0; m < n_points; ++m) {
+        const double px = points_xyz[3 * m], py = points_xyz[3 * m + 1], pz = points_xyz[3 * m + 2];
+        poly2.push_back(P2{((r00 * px + r01 * py) + r02 * pz) + q[0], ((r10 * px + r11 * py) + r12 * pz) + q[1]});
+      }
+      if (cons && i > 0) {  // :512-522
+        const double dx = ex - sx, dy = ey - sy;
+        const size_t m1 = poly1.size(), m2 = poly2.size();
+        for (size_t m = 0; m < m1; ++m) poly2.push_back(P2{poly1[m].x + dx, poly1[m].y + dy});
+        for (size_t m = 0; m < m2; ++m) poly1.push_back(P2{poly2[m].x - dx, poly2[m].y - dy});
+      }
+      if (n == 1) emit(poly2, 0.0);  // :524-546
+      if (n > 1 && i > 0) {          // :548-579
+        all = poly1;
+        all.insert(all.end(), poly2.begin(), poly2.end());
+        convex_hull(all, hull);
+        emit(hull, polygon_area(poly1));
+      }
+      if (cons && poly2.size() + (size_t)n_points > (size_t)kMaxPathPolygonVertices && i + 1 < n) {
+        out.status[k] = 3;  // the conservative vertex lists grow with every pose: refuse the rest of the path
+        break;
+      }
+    }
+    out.count[k] = (int)out.area.size() - out.first[k];
   }
 }
 

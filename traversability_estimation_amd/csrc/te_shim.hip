@@ -944,22 +944,12 @@ int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, d
   return TE_OK;
 }
 
-int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
-                            unsigned char* is_traversable, double* traversability) {
-  if (!c || n_polygons < 0 || (n_polygons > 0 && (!vertex_offset || !vertex_xy || !is_traversable || !traversability)))
-    return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: NULL argument");
-  std::lock_guard<std::mutex> lk(c->mu);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_polygons_traversable: run the chain with the footprint pass first (it marks the untraversable cells)");
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: map %d of %d", map, c->geo.batch);
+namespace {
+// isTraversable(polygon) for a batch of validated polygons; context locked, mask present
+int polygons_traversable_locked(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
+                                unsigned char* is_traversable, double* traversability, const char* who) {
   if (n_polygons == 0) return TE_OK;
-  if (vertex_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: bad vertex offsets");
-  for (int k = 0; k < n_polygons; ++k)
-    if (vertex_offset[k + 1] <= vertex_offset[k])
-      return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: polygon %d has no vertices (or the offsets decrease)", k);
   const int n_vert = vertex_offset[n_polygons];
-  for (long k = 0; k < 2L * n_vert; ++k)
-    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: vertex %ld is not finite", k / 2);
   HIP_TRY(hipSetDevice(c->device));
   const size_t b_off = (size_t)(n_polygons + 1) * sizeof(int), b_xy = (size_t)2 * n_vert * sizeof(double);
   const size_t b_ok = (size_t)n_polygons, b_trav = (size_t)n_polygons * sizeof(double);
@@ -980,7 +970,87 @@ int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* verte
   if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d);
-  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_polygons_traversable: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+  return TE_OK;
+}
+}  // namespace
+
+int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
+                            unsigned char* is_traversable, double* traversability) {
+  if (!c || n_polygons < 0 || (n_polygons > 0 && (!vertex_offset || !vertex_xy || !is_traversable || !traversability)))
+    return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: NULL argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_polygons_traversable: run the chain with the footprint pass first (it marks the untraversable cells)");
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: map %d of %d", map, c->geo.batch);
+  if (n_polygons == 0) return TE_OK;
+  if (vertex_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: bad vertex offsets");
+  for (int k = 0; k < n_polygons; ++k)
+    if (vertex_offset[k + 1] <= vertex_offset[k])
+      return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: polygon %d has no vertices (or the offsets decrease)", k);
+  const int n_vert = vertex_offset[n_polygons];
+  for (long k = 0; k < 2L * n_vert; ++k)
+    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: vertex %ld is not finite", k / 2);
+  return polygons_traversable_locked(c, map, n_polygons, vertex_offset, vertex_xy, is_traversable, traversability,
+                                     "te_polygons_traversable");
+}
+
+int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
+                                     const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                                     double* traversability, double* area, int* status) {
+  if (!c || n_paths < 0 || !points_xyz ||
+      (n_paths > 0 && (!pose_offset || !poses || !is_safe || !traversability || !area || !status)))
+    return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: NULL argument");
+  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
+    return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
+  for (int k = 0; k < 3 * n_points; ++k)
+    if (!isfinite(points_xyz[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: footprint point %d is not finite", k / 3);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: run the chain with the footprint pass first (it marks the untraversable cells)");
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: map %d of %d", map, c->geo.batch);
+  if (n_paths == 0) return TE_OK;
+  if (pose_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
+  for (int k = 0; k < n_paths; ++k)
+    if (pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
+  for (long k = 0; k < 7L * pose_offset[n_paths]; ++k)
+    if (!isfinite(poses[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: pose %ld is not finite", k / 7);
+  PathPolygons pp;
+  build_path_polygons(n_paths, pose_offset, poses, n_points, points_xyz, conservative, pp);
+  const int n_poly = (int)pp.area.size();
+  std::vector<unsigned char> ok(n_poly > 0 ? n_poly : 1);
+  std::vector<double> val(n_poly > 0 ? n_poly : 1);
+  const int rc = polygons_traversable_locked(c, map, n_poly, pp.vertex_offset.data(), pp.vertex_xy.data(), ok.data(), val.data(),
+                                             "te_check_polygon_footprint_paths");
+  if (rc != TE_OK) return rc;
+  // the loop of :480-580 over the precomputed polygons; a path stops at its first untraversable polygon and keeps
+  // the partial traversability / area, like `result` in the reference
+  for (int k = 0; k < n_paths; ++k) {
+    is_safe[k] = 0;
+    traversability[k] = 0.0;
+    area[k] = 0.0;
+    status[k] = pp.status[k];
+    if (pp.status[k] == 2) continue;
+    const int n = pose_offset[k + 1] - pose_offset[k];
+    bool good = true;
+    for (int s = 0; s < pp.count[k] && good; ++s) {
+      const int q = pp.first[k] + s;
+      if (!ok[q]) {
+        good = false;
+        break;
+      }
+      if (n == 1 || s == 0) {  // :543-544, :576-577
+        area[k] = pp.area[q];
+        traversability[k] = val[q];
+      } else {  // :570-575
+        const double area_previous = area[k];
+        const double area_polygon = pp.area[q] - pp.area_previous[q];
+        area[k] += area_polygon;
+        traversability[k] = (area_polygon * val[q] + area_previous * traversability[k]) / area[k];
+      }
+    }
+    if (good && pp.status[k] == 0) is_safe[k] = 1;
+  }
   return TE_OK;
 }
 
