@@ -175,11 +175,17 @@ def gpu_setup(capi, oracle, rows, cols, res, pos, elev, **over):
     dict(rows=61, cols=90, res=0.04, pts=[[0.3, 0.3], [0.3, -0.3], [0.0, -0.3], [0.0, 0.0], [-0.3, 0.0], [-0.3, 0.3]], yaw=1.0),
     dict(rows=33, cols=20, res=0.1, pts=[[0.01, 0.01], [0.01, -0.01], [-0.01, -0.01]], yaw=0.3),  # covers no cell centre
     dict(rows=5, cols=7, res=0.1, pts=FOOTPRINT, yaw=0.9),  # footprint larger than the map
+    dict(rows=300, cols=40, res=0.05, pts=FOOTPRINT, yaw=math.pi / 2),  # several workgroups along the rows
+    dict(rows=120, cols=60, res=0.02, pts=[[0.72, 0.48], [0.72, -0.48], [-0.72, -0.48], [-0.72, 0.48]], yaw=0.3,
+         over=dict(fp_radius=0.2, fp_offset=0.1)),  # 72 x 48 cells: too large for the offset table
 ])
-def test_polygon_footprint_layers(capi, oracle, case):
+@pytest.mark.parametrize("per_cell", [False, True])
+def test_polygon_footprint_layers(capi, oracle, case, per_cell, monkeypatch):
+    """Both kernels (offset table + LDS tile; every cell of every bounding box) against the oracle, bit for bit."""
     rows, cols, res = case["rows"], case["cols"], case["res"]
     elev = terrain(rows, cols, seed=rows + cols)
-    ctx, g, op, layers = gpu_setup(capi, oracle, rows, cols, res, (0.7, -0.2), elev, fp_default=0.3)
+    ctx, g, op, layers = gpu_setup(capi, oracle, rows, cols, res, (0.7, -0.2), elev, fp_default=0.3, **case.get("over", {}))
+    monkeypatch.setenv("TE_POLYGON_PER_CELL", "1" if per_cell else "0")
     with ctx:
         ctx.run_polygon_footprint(case["pts"], case["yaw"])
         ctx.sync()

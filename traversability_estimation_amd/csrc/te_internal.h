@@ -91,6 +91,22 @@ struct PolygonArgs {
   double def;                                       // traversabilityDefault_
   double off[2][2 * TE_MAX_POLYGON_VERTICES];       // vertex offsets from the centre cell: [0] as given, [1] turned by yaw
 };
+// offset table of one footprint polygon (build_polygon_table): rows of the bounding box that hold cells, each a header
+// word (di index | items << 8) followed by its items (dj index | run length << 8 | "decided per cell" << 31)
+struct PolygonTable {
+  int first;              // index of the first word in the stream
+  int n_rows;
+  int n_uncertain;
+  int di_min, dj_min;     // offset of table index 0
+  int di_span, dj_span;   // extent of the staged tile in offsets
+};
+struct PolygonTables {
+  PolygonTable t[2];
+};
+bool build_polygon_table(const Geo& g, int n, const double* off, std::vector<unsigned>& stream, PolygonTable& tb);
+hipError_t launch_polygon_footprint_table(const Geo& g, const PolygonArgs& a, const PolygonTables& tabs, const unsigned* d_stream,
+                                          const float* trav, const uint8_t* untrav, float* out_x, float* out_rot,
+                                          hipStream_t stream);
 void rotate_footprint(int n_points, const double* points_xy, double yaw, double* out_xy);
 hipError_t launch_polygon_footprint(const Geo& g, const PolygonArgs& a, const float* trav, const uint8_t* untrav, float* out_x,
                                     float* out_rot, hipStream_t stream);

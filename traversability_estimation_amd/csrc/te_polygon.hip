@@ -34,6 +34,16 @@ __device__ __forceinline__ double bound_axis(double position, double len, double
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// one edge (xi, yi) - (xj, yj) of grid_map::Polygon::isInside's crossing-number test
+__device__ __forceinline__ bool edge_crosses(double xi, double yi, double xj, double yj, double px, double py) {
+  if ((yi > py) == (yj > py)) return false;
+  if (xi == xj) return px < xi;  // the expression below is 0 * (..) / (..) + xi == xi exactly (yj != yi here)
+  const double lo = fmin(xi, xj), hi = fmax(xi, xj);
+  const double margin = 1e-9 * (fabs(lo) + fabs(hi) + 1.0);  // >> the rounding error of the expression below
+  if (px < lo - margin) return true;
+  return px <= hi + margin && px < (xj - xi) * (py - yi) / (yj - yi) + xi;
+}
+
 // vert(k, x, y): vertex k of the polygon
 template <class V>
 __device__ __forceinline__ bool polygon_inside(int n, V&& vert, double px, double py) {
@@ -43,24 +53,16 @@ __device__ __forceinline__ bool polygon_inside(int n, V&& vert, double px, doubl
   for (int i = 0; i < n; ++i) {
     double xi, yi;
     vert(i, xi, yi);
-    if ((yi > py) != (yj > py)) {
-      const double lo = fmin(xi, xj), hi = fmax(xi, xj);
-      const double margin = 1e-9 * (fabs(lo) + fabs(hi) + 1.0);  // >> the rounding error of the expression below
-      if (px < lo - margin)
-        ++cross;
-      else if (px <= hi + margin && px < (xj - xi) * (py - yi) / (yj - yi) + xi)
-        ++cross;
-    }
+    cross += edge_crosses(xi, yi, xj, yj, px, py);
     xj = xi;
     yj = yi;
   }
   return (cross & 1) != 0;
 }
 
+// PolygonIterator::findSubmapParameters: the index range [ti, bi] x [tj, bj] the iterator walks
 template <class V>
-__device__ __forceinline__ bool polygon_traversable(const Geo& g, const uint8_t* __restrict__ untrav,
-                                                    const float* __restrict__ trav, double def, int n, V&& vert,
-                                                    double& value) {
+__device__ __forceinline__ void polygon_bbox(const Geo& g, int n, V&& vert, int& ti, int& bi, int& tj, int& bj) {
   double tlx, tly;
   vert(0, tlx, tly);
   double brx = tlx, bry = tly;
@@ -76,13 +78,20 @@ __device__ __forceinline__ bool polygon_traversable(const Geo& g, const uint8_t*
   tly = bound_axis(tly, g.len_y, g.pos_y);
   brx = bound_axis(brx, g.len_x, g.pos_x);
   bry = bound_axis(bry, g.len_y, g.pos_y);
-  int ti, tj, bi, bj;
   pos_to_index(g, tlx, tly, ti, tj);
   pos_to_index(g, brx, bry, bi, bj);
   ti = clampi(ti, 0, g.rows - 1);
   bi = clampi(bi, 0, g.rows - 1);
   tj = clampi(tj, 0, g.cols - 1);
   bj = clampi(bj, 0, g.cols - 1);
+}
+
+template <class V>
+__device__ __forceinline__ bool polygon_traversable(const Geo& g, const uint8_t* __restrict__ untrav,
+                                                    const float* __restrict__ trav, double def, int n, V&& vert,
+                                                    double& value) {
+  int ti, tj, bi, bj;
+  polygon_bbox(g, n, vert, ti, bi, tj, bj);
   unsigned ncells = 0;
   double t = 0.0;
   for (int a = ti; a <= bi; ++a) {
@@ -125,6 +134,91 @@ __global__ __launch_bounds__(256) void k_polygon_footprint(Geo g, PolygonArgs a,
         },
         t);
     (which ? out_rot : out_x)[map + (size_t)j * g.rows + i] = ok ? (float)t : 0.0f;  // :293-300
+  }
+}
+
+// ---- the same layers through an offset table ------------------------------------------------------------------------
+// The footprint polygon of cell c is the footprint translated to c, so whether cell q lies inside depends, up to
+// rounding, only on the index offset q - c.  The host classifies every offset of the bounding box once
+// (build_polygon_table): "inside for every centre cell" (farther than a tolerance from every edge), "outside for every
+// centre cell" (dropped), or "decided by rounding" -- only the last kind is still evaluated per cell with the exact
+// expression.  A workgroup (256 adjacent centre cells of one map column) stages the cells its polygons can touch in LDS
+// as doubles ready to add (0 outside the map, NaN on an untraversable cell, traversabilityDefault_ for an invalid one),
+// then every lane walks the table in the reference's order: one LDS read and one add per inside cell.  Same cells, same
+// order, same values as k_polygon_footprint: the results are identical.
+__device__ __forceinline__ unsigned uniform_u32(const unsigned* p) { return __builtin_amdgcn_readfirstlane(*p); }
+
+__global__ __launch_bounds__(256) void k_polygon_footprint_table(Geo g, PolygonArgs a, PolygonTables tabs,
+                                                                 const unsigned* __restrict__ stream,
+                                                                 const float* __restrict__ trav,
+                                                                 const uint8_t* __restrict__ untrav, float* __restrict__ out_x,
+                                                                 float* __restrict__ out_rot) {
+  extern __shared__ double tile[];
+  const int tid = threadIdx.x, i0 = blockIdx.x * 256, i = i0 + tid, j = blockIdx.y;
+  const size_t map = (size_t)blockIdx.z * g.rows * g.cols;
+  const double cx = cell_x(g, i), cy = cell_y(g, j);
+  const double nan = __builtin_nan("");
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+    const PolygonTable tb = tabs.t[which];
+    const int W = 255 + tb.di_span;
+    __syncthreads();  // the previous polygon's tile is no longer read
+    for (int idx = tid; idx < W * tb.dj_span; idx += 256) {
+      const int c = idx / W, r = idx - c * W;
+      const int aa = i0 + tb.di_min + r, bb = j + tb.dj_min + c;
+      double w = 0.0;
+      if (aa >= 0 && aa < g.rows && bb >= 0 && bb < g.cols) {
+        const size_t o = map + (size_t)bb * g.rows + aa;
+        const float v = trav[o];
+        w = untrav[o] ? nan : ((v == v && fabsf(v) != __builtin_inff()) ? (double)v : a.def);
+      }
+      tile[idx] = w;
+    }
+    __syncthreads();
+    if (i >= g.rows) continue;
+    auto vert = [&](int k, double& x, double& y) {
+      x = a.off[which][2 * k] + cx;
+      y = a.off[which][2 * k + 1] + cy;
+    };
+    int ti = 0, bi = -1, tj = 0, bj = -1;
+    if (tb.n_uncertain) polygon_bbox(g, a.n, vert, ti, bi, tj, bj);
+    const unsigned* p = stream + tb.first;
+    double t = 0.0;
+    int ncells = 0;
+#pragma unroll 1
+    for (int r = 0; r < tb.n_rows; ++r) {
+      const unsigned hdr = uniform_u32(p++);
+      const int di_idx = hdr & 0xff, items = hdr >> 8;
+      const int aa = i + tb.di_min + di_idx;
+      const bool a_in = aa >= 0 && aa < g.rows;
+      const double* col0 = tile + tid + di_idx;
+#pragma unroll 1
+      for (int k = 0; k < items; ++k) {
+        const unsigned item = uniform_u32(p++);
+        const int dj_idx = item & 0xff, len = (item >> 8) & 0xff;
+        const int b0 = j + tb.dj_min + dj_idx;
+        const double* q = col0 + dj_idx * W;
+        if (!(item >> 31)) {
+          // inside for every centre cell; the columns of the run that are on the map (uniform)
+          const int lo = b0 < 0 ? 0 : b0, hi = b0 + len - 1 > g.cols - 1 ? g.cols - 1 : b0 + len - 1;
+          ncells += (a_in && hi >= lo) ? hi - lo + 1 : 0;
+#pragma unroll 4
+          for (int m = 0; m < len; ++m) t += q[m * W];
+        } else if (a_in && b0 >= 0 && b0 < g.cols && aa >= ti && aa <= bi && b0 >= tj && b0 <= bj &&
+                   polygon_inside(a.n, vert, cell_x(g, aa), cell_y(g, b0))) {
+          t += q[0];
+          ++ncells;
+        }
+      }
+    }
+    float res;
+    if (t != t)
+      res = 0.0f;  // touched an untraversable cell (:603-611, :295/:299)
+    else if (ncells == 0)
+      res = a.def != 0.0 ? (float)a.def : 0.0f;  // :626-629
+    else
+      res = (float)(t / (double)ncells);
+    (which ? out_rot : out_x)[map + (size_t)j * g.rows + i] = res;
   }
 }
 
@@ -277,6 +371,107 @@ void build_path_polygons(int n_paths, const int* pose_offset, const double* pose
     }
     out.count[k] = (int)out.area.size() - out.first[k];
   }
+}
+
+// Classify the index offsets (di, dj) of one footprint polygon (vertex offsets `off` from the centre cell).  The cell at
+// offset (di, dj) lies at (-di, -dj) * res from the centre.  Returns false when the polygon does not fit the table
+// format (spans beyond 255 offsets, LDS tile too large): the caller then uses the per-cell kernel.
+bool build_polygon_table(const Geo& g, int n, const double* off, std::vector<unsigned>& stream, PolygonTable& tb) {
+  double xmin = off[0], xmax = off[0], ymin = off[1], ymax = off[1], ext = 0.0;
+  for (int k = 0; k < n; ++k) {
+    xmin = std::min(xmin, off[2 * k]);
+    xmax = std::max(xmax, off[2 * k]);
+    ymin = std::min(ymin, off[2 * k + 1]);
+    ymax = std::max(ymax, off[2 * k + 1]);
+    ext = std::max(ext, std::max(fabs(off[2 * k]), fabs(off[2 * k + 1])));
+  }
+  // rounding of the per-cell evaluation is ~1e-16 of the coordinates involved; anything closer than `tol` to an edge
+  // is left to that evaluation
+  const double scale = fabs(g.pos_x) + fabs(g.pos_y) + g.len_x + g.len_y + ext;
+  const double tol = 1e-7 * g.res + 1e-9 * scale;
+  const int di_lo = (int)floor(-xmax / g.res) - 1, di_hi = (int)ceil(-xmin / g.res) + 1;
+  const int dj_lo = (int)floor(-ymax / g.res) - 1, dj_hi = (int)ceil(-ymin / g.res) + 1;
+  if (di_hi - di_lo + 1 > 255 || dj_hi - dj_lo + 1 > 255) return false;
+  auto classify = [&](int di, int dj) {  // 0 outside, 1 inside, 2 decided by rounding
+    const double px = -(double)di * g.res, py = -(double)dj * g.res;
+    int cross = 0;
+    double dmin = 1e300;
+    for (int i = 0, j = n - 1; i < n; j = i++) {
+      const double xi = off[2 * i], yi = off[2 * i + 1], xj = off[2 * j], yj = off[2 * j + 1];
+      if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) cross++;
+      const double ex = xj - xi, ey = yj - yi, l2 = ex * ex + ey * ey;
+      double u = l2 > 0.0 ? ((px - xi) * ex + (py - yi) * ey) / l2 : 0.0;
+      u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+      const double qx = xi + u * ex - px, qy = yi + u * ey - py;
+      dmin = std::min(dmin, sqrt(qx * qx + qy * qy));
+    }
+    if (!(dmin > tol)) return 2;
+    return cross & 1;
+  };
+  // the used part of the box
+  int a0 = di_hi + 1, a1 = di_lo - 1, b0 = dj_hi + 1, b1 = dj_lo - 1;
+  std::vector<signed char> cls((size_t)(di_hi - di_lo + 1) * (dj_hi - dj_lo + 1));
+  for (int di = di_lo; di <= di_hi; ++di)
+    for (int dj = dj_lo; dj <= dj_hi; ++dj) {
+      const int c = classify(di, dj);
+      cls[(size_t)(di - di_lo) * (dj_hi - dj_lo + 1) + (dj - dj_lo)] = (signed char)c;
+      if (c) {
+        a0 = std::min(a0, di);
+        a1 = std::max(a1, di);
+        b0 = std::min(b0, dj);
+        b1 = std::max(b1, dj);
+      }
+    }
+  tb.first = (int)stream.size();
+  tb.n_rows = 0;
+  tb.n_uncertain = 0;
+  if (a1 < a0) {  // covers no cell centre
+    tb.di_min = tb.dj_min = 0;
+    tb.di_span = tb.dj_span = 1;
+    return true;
+  }
+  tb.di_min = a0;
+  tb.dj_min = b0;
+  tb.di_span = a1 - a0 + 1;
+  tb.dj_span = b1 - b0 + 1;
+  if ((size_t)(255 + tb.di_span) * tb.dj_span * sizeof(double) > 64 * 1024) return false;
+  for (int di = a0; di <= a1; ++di) {  // SubmapIterator order: row index outer, column index inner
+    const size_t hdr = stream.size();
+    stream.push_back(0);
+    unsigned items = 0;
+    for (int dj = b0; dj <= b1;) {
+      const int c = cls[(size_t)(di - di_lo) * (dj_hi - dj_lo + 1) + (dj - dj_lo)];
+      if (c == 0) {
+        ++dj;
+        continue;
+      }
+      int len = 1;
+      if (c == 1)
+        while (dj + len <= b1 && len < 255 && cls[(size_t)(di - di_lo) * (dj_hi - dj_lo + 1) + (dj + len - dj_lo)] == 1) ++len;
+      else
+        ++tb.n_uncertain;
+      stream.push_back((unsigned)(dj - b0) | ((unsigned)len << 8) | (c == 2 ? 0x80000000u : 0u));
+      ++items;
+      dj += len;
+    }
+    if (items == 0) {
+      stream.pop_back();
+      continue;
+    }
+    stream[hdr] = (unsigned)(di - a0) | (items << 8);
+    ++tb.n_rows;
+  }
+  return true;
+}
+
+hipError_t launch_polygon_footprint_table(const Geo& g, const PolygonArgs& a, const PolygonTables& tabs, const unsigned* d_stream,
+                                          const float* trav, const uint8_t* untrav, float* out_x, float* out_rot,
+                                          hipStream_t stream) {
+  size_t lds = 0;
+  for (int w = 0; w < 2; ++w) lds = std::max(lds, (size_t)(255 + tabs.t[w].di_span) * tabs.t[w].dj_span * sizeof(double));
+  hipLaunchKernelGGL(k_polygon_footprint_table, dim3((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch),
+                     dim3(256), lds, stream, g, a, tabs, d_stream, trav, untrav, out_x, out_rot);
+  return hipGetLastError();
 }
 
 hipError_t launch_polygon_footprint(const Geo& g, const PolygonArgs& a, const float* trav, const uint8_t* untrav, float* out_x,

@@ -117,6 +117,9 @@ struct te_ctx {
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
   float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
   float* poly_rot = nullptr;
+  unsigned* poly_stream = nullptr;        // offset tables of the two footprint polygons (device copy)
+  size_t poly_stream_cap = 0;             // in words
+  std::vector<unsigned> poly_stream_host;  // stays alive until the asynchronous upload has been consumed
   Geo geo;
   ChainParams cp;
   FootprintParams fp;
@@ -271,6 +274,9 @@ void free_layers(te_ctx* c) {
   c->slab = nullptr;
   if (c->poly_x) (void)hipFree(c->poly_x);
   c->poly_x = c->poly_rot = nullptr;
+  if (c->poly_stream) (void)hipFree(c->poly_stream);
+  c->poly_stream = nullptr;
+  c->poly_stream_cap = 0;
   memset(&c->L, 0, sizeof(c->L));
   c->layer_elems = 0;
   c->have_elev = false;
@@ -940,7 +946,32 @@ int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, d
   a.def = c->params.fp_default;
   rotate_footprint(n_points, points_xy, 0.0, a.off[0]);
   rotate_footprint(n_points, points_xy, yaw, a.off[1]);
-  HIP_TRY(launch_polygon_footprint(c->geo, a, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot, c->stream));
+  // offset tables (te_polygon.hip); polygons that do not fit the table format, or TE_POLYGON_PER_CELL=1 (a debugging
+  // aid: both kernels give identical layers), take the kernel that evaluates every cell of every bounding box
+  PolygonTables tabs;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's table upload has been consumed
+  c->poly_stream_host.clear();
+  const char* per_cell = getenv("TE_POLYGON_PER_CELL");
+  bool table = !(per_cell && per_cell[0] == '1');
+  for (int w = 0; w < 2 && table; ++w) table = build_polygon_table(c->geo, n_points, a.off[w], c->poly_stream_host, tabs.t[w]);
+  if (!table) {
+    HIP_TRY(launch_polygon_footprint(c->geo, a, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot, c->stream));
+    return TE_OK;
+  }
+  if (c->poly_stream_host.empty()) c->poly_stream_host.push_back(0);
+  if (c->poly_stream_host.size() > c->poly_stream_cap) {
+    if (c->poly_stream) (void)hipFree(c->poly_stream);
+    c->poly_stream = nullptr;
+    c->poly_stream_cap = 0;
+    const size_t cap = c->poly_stream_host.size() + 1024;
+    hipError_t e = hipMalloc((void**)&c->poly_stream, cap * sizeof(unsigned));
+    if (e != hipSuccess) return fail(TE_ERR_HIP, "te_run_polygon_footprint: hipMalloc: %s", hipGetErrorString(e));
+    c->poly_stream_cap = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(c->poly_stream, c->poly_stream_host.data(), c->poly_stream_host.size() * sizeof(unsigned),
+                         hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(launch_polygon_footprint_table(c->geo, a, tabs, c->poly_stream, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot,
+                                         c->stream));
   return TE_OK;
 }
 
