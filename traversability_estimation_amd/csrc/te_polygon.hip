@@ -60,6 +60,23 @@ __device__ __forceinline__ bool polygon_inside(int n, V&& vert, double px, doubl
   return (cross & 1) != 0;
 }
 
+// The usual footprint has four vertices: held in registers, a cell evaluation does not wait for per-edge loads.
+struct Quad {
+  double x[4], y[4];
+  template <class V>
+  __device__ __forceinline__ void load(V&& vert) {
+    vert(0, x[0], y[0]);
+    vert(1, x[1], y[1]);
+    vert(2, x[2], y[2]);
+    vert(3, x[3], y[3]);
+  }
+  __device__ __forceinline__ bool inside(double px, double py) const {  // edges (0,3) (1,0) (2,1) (3,2) like the loop
+    const int cross = (int)edge_crosses(x[0], y[0], x[3], y[3], px, py) + (int)edge_crosses(x[1], y[1], x[0], y[0], px, py) +
+                      (int)edge_crosses(x[2], y[2], x[1], y[1], px, py) + (int)edge_crosses(x[3], y[3], x[2], y[2], px, py);
+    return (cross & 1) != 0;
+  }
+};
+
 // PolygonIterator::findSubmapParameters: the index range [ti, bi] x [tj, bj] the iterator walks
 template <class V>
 __device__ __forceinline__ void polygon_bbox(const Geo& g, int n, V&& vert, int& ti, int& bi, int& tj, int& bj) {
@@ -181,7 +198,11 @@ __global__ __launch_bounds__(256) void k_polygon_footprint_table(Geo g, PolygonA
       y = a.off[which][2 * k + 1] + cy;
     };
     int ti = 0, bi = -1, tj = 0, bj = -1;
-    if (tb.n_uncertain) polygon_bbox(g, a.n, vert, ti, bi, tj, bj);
+    Quad quad = {};
+    if (tb.n_uncertain) {
+      polygon_bbox(g, a.n, vert, ti, bi, tj, bj);
+      if (a.n == 4) quad.load(vert);
+    }
     const unsigned* p = stream + tb.first;
     double t = 0.0;
     int ncells = 0;
@@ -205,7 +226,8 @@ __global__ __launch_bounds__(256) void k_polygon_footprint_table(Geo g, PolygonA
 #pragma unroll 4
           for (int m = 0; m < len; ++m) t += q[m * W];
         } else if (a_in && b0 >= 0 && b0 < g.cols && aa >= ti && aa <= bi && b0 >= tj && b0 <= bj &&
-                   polygon_inside(a.n, vert, cell_x(g, aa), cell_y(g, b0))) {
+                   (a.n == 4 ? quad.inside(cell_x(g, aa), cell_y(g, b0))
+                             : polygon_inside(a.n, vert, cell_x(g, aa), cell_y(g, b0)))) {
           t += q[0];
           ++ncells;
         }
