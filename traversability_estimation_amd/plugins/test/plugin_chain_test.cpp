@@ -16,6 +16,7 @@
 #include <pluginlib/class_list_macros.h>
 
 #include "te_oracle.h"
+#include "traversability_estimation_gpu/TraversabilityMap.hpp"
 
 typedef filters::FilterBase<grid_map::GridMap> Filter;
 using filters::ParamMap;
@@ -213,6 +214,173 @@ static void test_device_circular() {
   CHECK(compare("traversability_step (plugin)", tg["traversability_step"], w) == 0);
 }
 
+// the device-backed TraversabilityMap against the oracle: chain, both footprint passes, path checks
+static void test_traversability_map() {
+  using traversability_estimation_gpu::TraversabilityMap;
+  const int rows = 150, cols = 120, si = 61, sj = 7;
+  const double res = 0.04;
+  grid_map::GridMap flat = make_map(rows, cols, res);
+  const size_t n = (size_t)rows * cols;
+  teo_geom g;
+  teo_geom_init(&g, rows, cols, res, 1.25, -0.5);
+  teo_params p;
+  teo_params_default(&p);
+  p.normals_radius = 0.09;
+  p.rough_radius = 0.13;
+  p.step_radius1 = 0.1;
+  p.step_radius2 = 0.07;
+  p.fp_radius = 0.2;
+  p.fp_offset = 0.1;
+  std::vector<float> sl(n), st(n), ro(n), tr(n), fp(n), fx(n), fr(n);
+  const float* elev = flat["elevation"].data();
+  teo_chain(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), nullptr, nullptr, nullptr);
+  teo_footprint(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), fp.data(), nullptr, nullptr, nullptr);
+  const double foot[8] = {0.45, 0.30, 0.45, -0.30, -0.45, -0.30, -0.45, 0.30};
+  const double yaw = 1.5707963267948966;
+  teo_polygon_footprint(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), 4, foot, yaw, fx.data(), fr.data());
+
+  TraversabilityMap tm;
+  te_params tp = tm.getParameters();
+  tp.normals_radius = p.normals_radius;
+  tp.rough_radius = p.rough_radius;
+  tp.step_radius1 = p.step_radius1;
+  tp.step_radius2 = p.step_radius2;
+  CHECK(tm.setParameters(tp));
+  traversability_msgs::TraversabilityResult r1;
+  traversability_msgs::FootprintPath one;
+  one.poses.poses.resize(1);
+  one.radius = 0.2;
+  CHECK(tm.checkFootprintPath(one, r1) && !r1.is_safe);  // map not initialised: true, unsafe (:323-327)
+  CHECK(!tm.computeTraversability());                    // no elevation map yet (:228-231)
+  CHECK(!tm.traversabilityFootprint(0.2, 0.1) && !tm.traversabilityFootprint(yaw));
+  grid_map::GridMap bare;
+  bare.setGeometry(flat.getLength(), res, flat.getPosition());
+  CHECK(!tm.setElevationMap(bare));  // no "elevation" layer (:145-150)
+  grid_map::GridMap in = rolled(flat, si, sj);
+  CHECK(tm.setElevationMap(in));
+  CHECK(tm.computeTraversability());
+  CHECK(tm.traversabilityFootprint(0.2, 0.1));
+  std::vector<geometry_msgs::Point32> pts(4);
+  for (int k = 0; k < 4; ++k) {
+    pts[k].x = (float)foot[2 * k];
+    pts[k].y = (float)foot[2 * k + 1];
+  }
+  // Point32 is float: the oracle gets the same rounded values
+  double footf[8], foot3[12];
+  for (int k = 0; k < 4; ++k) {
+    footf[2 * k] = pts[k].x;
+    footf[2 * k + 1] = pts[k].y;
+    foot3[3 * k] = pts[k].x;
+    foot3[3 * k + 1] = pts[k].y;
+    foot3[3 * k + 2] = 0.0;
+  }
+  teo_polygon_footprint(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), 4, footf, yaw, fx.data(), fr.data());
+  tm.setFootprintPolygon(pts);
+  CHECK(tm.traversabilityFootprint(yaw));
+  grid_map::GridMap out = tm.getTraversabilityMap();
+  CHECK(out.getStartIndex()(0) == si && out.getStartIndex()(1) == sj);
+  std::printf("TraversabilityMap on a circular-buffer map (start index %d,%d):\n", si, sj);
+  grid_map::GridMap want;
+  want.setGeometry(flat.getLength(), res, flat.getPosition());
+  struct Named {
+    const char* name;
+    const std::vector<float>* v;
+  };
+  const Named layers[] = {{"traversability_slope", &sl}, {"traversability_step", &st}, {"traversability_roughness", &ro},
+                          {"traversability", &tr},       {"traversability_footprint", &fp}, {"traversability_x", &fx},
+                          {"traversability_rot", &fr}};
+  for (const Named& l : layers) {
+    want.add(l.name);
+    std::memcpy(want[l.name].data(), l.v->data(), n * 4);
+  }
+  grid_map::GridMap expect = rolled(want, si, sj);
+  for (const Named& l : layers) {
+    CHECK(out.exists(l.name));
+    if (!out.exists(l.name)) continue;
+    std::vector<float> w(expect[l.name].data(), expect[l.name].data() + n);
+    CHECK(compare(l.name, out[l.name], w) == 0);
+  }
+
+  // a CheckFootprintPath request: circular footprints of two radii and polygonal ones, mixed
+  std::vector<traversability_msgs::FootprintPath> paths;
+  unsigned seed = 12345;
+  auto rnd = [&]() {
+    seed = seed * 1664525u + 1013904223u;
+    return (double)(seed >> 8) / (double)(1u << 24);
+  };
+  for (int k = 0; k < 90; ++k) {
+    traversability_msgs::FootprintPath path;
+    const int np = 1 + (int)(rnd() * 4.0);
+    double x = 1.25 + (rnd() - 0.5) * rows * res * 0.9, y = -0.5 + (rnd() - 0.5) * cols * res * 0.9;
+    for (int m = 0; m < np; ++m) {
+      geometry_msgs::Pose pose;
+      pose.position.x = x;
+      pose.position.y = y;
+      const double a = rnd() * 6.0;
+      pose.orientation.z = std::sin(a / 2);
+      pose.orientation.w = std::cos(a / 2);
+      path.poses.poses.push_back(pose);
+      x += (rnd() - 0.5) * 0.8;
+      y += (rnd() - 0.5) * 0.8;
+    }
+    if (k % 3 == 0) {
+      path.footprint.polygon.points = pts;
+      path.conservative = (k % 2) ? 1 : 0;
+    } else {
+      path.radius = (k % 3 == 1) ? 0.2 : 0.3;
+    }
+    paths.push_back(path);
+  }
+  std::vector<traversability_msgs::TraversabilityResult> results;
+  CHECK(tm.checkFootprintPaths(paths, results));
+  CHECK(results.size() == paths.size());
+  int n_safe = 0, n_bad = 0;
+  for (size_t k = 0; k < paths.size() && k < results.size(); ++k) {
+    const int np = (int)paths[k].poses.poses.size();
+    const int off[2] = {0, np};
+    unsigned char safe = 0;
+    double trav = 0, area = 0;
+    int status = 0;
+    if (paths[k].footprint.polygon.points.empty()) {
+      teo_params q = p;
+      q.fp_radius = paths[k].radius;
+      q.fp_offset = 0.15;
+      std::vector<float> layer(n);
+      teo_footprint(&g, &q, elev, sl.data(), st.data(), ro.data(), tr.data(), layer.data(), nullptr, nullptr, nullptr);
+      std::vector<double> xy;
+      for (const auto& pose : paths[k].poses.poses) {
+        xy.push_back(pose.position.x);
+        xy.push_back(pose.position.y);
+      }
+      teo_check_circular_paths(&g, layer.data(), q.fp_default, 1, off, xy.data(), &safe, &trav, &status);
+    } else {
+      std::vector<double> poses;
+      for (const auto& pose : paths[k].poses.poses) {
+        const double v[7] = {pose.position.x,    pose.position.y,    pose.position.z,   pose.orientation.x,
+                             pose.orientation.y, pose.orientation.z, pose.orientation.w};
+        poses.insert(poses.end(), v, v + 7);
+      }
+      teo_check_polygon_paths(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), 1, off, poses.data(), 4, foot3,
+                              &paths[k].conservative, &safe, &trav, &area, &status);
+    }
+    if (results[k].is_safe != safe || results[k].traversability != trav || results[k].area != area) {
+      ++n_bad;
+      std::fprintf(stderr, "path %zu: got (%d, %.17g, %.17g) want (%d, %.17g, %.17g)\n", k, results[k].is_safe,
+                   results[k].traversability, results[k].area, safe, trav, area);
+    }
+    n_safe += safe;
+  }
+  std::printf("  checkFootprintPaths: %zu paths, %d safe, %d mismatches\n", paths.size(), n_safe, n_bad);
+  CHECK(n_bad == 0);
+  CHECK(n_safe > 5 && n_safe < (int)paths.size() - 5);
+  // a request with a path without poses stops there (TraversabilityEstimation.cpp:290)
+  paths[4].poses.poses.clear();
+  CHECK(!tm.checkFootprintPaths(paths, results) && results.size() == 4);
+  CHECK(!tm.checkFootprintPath(paths[4], r1) && !r1.is_safe);
+  paths.clear();
+  CHECK(!tm.checkFootprintPaths(paths, results));
+}
+
 static void test_no_device() {
   auto t = make(kStep);
   CHECK(t->configure("stepFilter", ParamMap{{"critical_value", 0.12}, {"first_window_radius", 0.04},
@@ -220,6 +388,9 @@ static void test_no_device() {
                                             {"map_type", "traversability_step"}}));
   grid_map::GridMap in = make_map(40, 30, 0.05), out;
   CHECK(!t->update(in, out));  // no GPU: a clean `false` (the chain is marked failed), never a CPU fallback
+  traversability_estimation_gpu::TraversabilityMap tm;  // same for the device-backed map: every entry point refuses
+  CHECK(!tm.setElevationMap(in) && !tm.computeTraversability() && !tm.traversabilityFootprint(0.3, 0.15));
+  CHECK(!tm.error().empty());
 }
 
 int main(int argc, char** argv) {
@@ -228,6 +399,7 @@ int main(int argc, char** argv) {
   if (device) {
     test_device();
     test_device_circular();
+    test_traversability_map();
   } else {
     test_no_device();
   }
