@@ -178,6 +178,28 @@ def main():
         del outs
         host_path = {"ms": best * 1e3, "cells_per_s": B * n * n / best,
                      "what": f"upload elevation + chain + download {len(names)} layers through pageable host buffers, best of 3"}
+        # the same with buffers the host keeps across frames and has page-locked once (te_pin_host)
+        bufs = [np.empty(stack.size, np.float32) for _ in names]
+        try:
+            for b in [stack] + bufs:
+                capi.pin_host(b)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.upload_elevation(stack)
+                ctx.run_chain(flags)
+                for k, b in zip(names, bufs):
+                    ctx.download_into(k, b)
+                ctx.sync()
+                d = time.perf_counter() - t0
+                best = d if best is None or d < best else best
+            host_path["pinned_ms"] = best * 1e3
+            host_path["pinned_cells_per_s"] = B * n * n / best
+            for b in [stack] + bufs:
+                capi.unpin_host(b)
+        except capi.TeError as e:  # page-locking can be refused (ulimit -l); the pageable figure stands
+            host_path["pinned_error"] = str(e)
+        del bufs
 
     check = None
     if args.check and rank == 0:

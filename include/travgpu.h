@@ -215,6 +215,11 @@ int te_check_polygon_footprint_paths(te_ctx* ctx, int map, int n_paths, const in
 int te_sync(te_ctx* ctx);
 
 int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);
+/* Page-lock a host buffer the caller keeps across frames (a GridMap layer that lives as long as the node): uploads from
+ * and downloads into it then run as direct DMA instead of through the runtime's staging copies.  te_unpin_host before
+ * the buffer is freed.  Purely an optimisation: every transfer entry point accepts pageable memory too. */
+int te_pin_host(void* host, size_t bytes);
+int te_unpin_host(void* host);
 
 /* Time `iters` back-to-back te_run_chain(flags) launches with HIP events on the context's stream
  * (after `warmup` untimed ones); inputs and outputs stay resident in HBM. */

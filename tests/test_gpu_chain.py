@@ -295,3 +295,28 @@ def test_circular_buffer_layers(capi, start):
             ctx.upload_layer_circular("elevation", buf, (rows, 0))
         with pytest.raises(capi.TeError):
             ctx.download_layer_circular("traversability", (0, -1))
+
+
+def test_pinned_host_buffers(capi):
+    """te_pin_host: transfers from / into page-locked buffers give the same bytes as pageable ones."""
+    from traversability_estimation_amd import synth
+    rows, cols = 96, 80
+    elev = np.ascontiguousarray(synth.perlin_elevation(rows, cols, seed=3), dtype=np.float32).reshape(-1)
+    plain = run_gpu(capi, elev, rows, cols, 0.05, capi.default_params())
+    src, dst = elev.copy(), np.empty(rows * cols, np.float32)
+    capi.pin_host(src)
+    capi.pin_host(dst)
+    try:
+        with capi.Context(0) as ctx:
+            ctx.set_params(capi.default_params())
+            ctx.set_geometry(rows, cols, 1, 0.05)
+            ctx.upload_elevation(src)
+            ctx.run_chain(0)
+            for k in OUT_LAYERS:
+                ctx.download_into(k, dst)
+                assert np.array_equal(dst.view(np.uint32), plain[k].view(np.uint32)), k
+    finally:
+        capi.unpin_host(src)
+        capi.unpin_host(dst)
+    with pytest.raises(capi.TeError):
+        capi.unpin_host(dst)  # not registered any more

@@ -35,7 +35,7 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_download_layer", "te_time_chain", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
            "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
-           "te_check_polygon_footprint_paths"]
+           "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host"]
 MSG_MAX_NAME = 64
 
 
@@ -118,6 +118,8 @@ def load():
         L.te_check_polygon_footprint_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int,
                                                        C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
                                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.te_pin_host.argtypes = [vp, C.c_size_t]
+        L.te_unpin_host.argtypes = [vp]
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -218,6 +220,15 @@ def bag_write(msg, topic, stamp=(0, 0)):
     out = C.create_string_buffer(max(need.value, 1))
     _check(L.te_bag_write(msg, len(msg), topic.encode(), int(stamp[0]), int(stamp[1]), out, need.value, C.byref(need)))
     return out.raw[:need.value]
+
+
+def pin_host(array):
+    """Page-lock a numpy buffer that is reused across frames (te_pin_host); unpin_host before dropping it."""
+    _check(load().te_pin_host(array.ctypes.data_as(C.c_void_p), array.nbytes))
+
+
+def unpin_host(array):
+    _check(load().te_unpin_host(array.ctypes.data_as(C.c_void_p)))
 
 
 def device_count():
@@ -404,6 +415,14 @@ class Context:
     def download(self, layer, map0=0, nmaps=None):
         nmaps = self.batch - map0 if nmaps is None else nmaps
         out = np.empty(nmaps * self.rows * self.cols, np.float32)
+        _check(load().te_download_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)), int(map0), int(nmaps)))
+        return out
+
+    def download_into(self, layer, out, map0=0, nmaps=None):
+        """te_download_layer into a caller-owned float32 buffer (reused, possibly pinned)."""
+        nmaps = self.batch - map0 if nmaps is None else nmaps
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == nmaps * self.rows * self.cols
         _check(load().te_download_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
                                         out.ctypes.data_as(C.POINTER(C.c_float)), int(map0), int(nmaps)))
         return out

@@ -1108,6 +1108,18 @@ int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
   return TE_OK;
 }
 
+int te_pin_host(void* host, size_t bytes) {
+  if (!host || !bytes) return fail(TE_ERR_INVALID_ARG, "te_pin_host: NULL or empty buffer");
+  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return TE_OK;
+}
+
+int te_unpin_host(void* host) {
+  if (!host) return fail(TE_ERR_INVALID_ARG, "te_unpin_host: NULL");
+  HIP_TRY(hipHostUnregister(host));
+  return TE_OK;
+}
+
 int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_per_iter) {
   if (!c || !ms_per_iter || iters <= 0 || warmup < 0) return fail(TE_ERR_INVALID_ARG, "te_time_chain: bad argument");
   std::lock_guard<std::mutex> lk(c->mu);
