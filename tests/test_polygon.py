@@ -357,7 +357,7 @@ def test_polygon_paths_on_the_device(capi, oracle):
     rows, cols, res = 160, 140, 0.05
     elev = terrain(rows, cols, seed=31, boxes=12)
     ctx, g, op, layers = gpu_setup(capi, oracle, rows, cols, res, (2.0, -3.0), elev, fp_default=0.3)
-    paths, cons = random_pose_paths(g, np.random.default_rng(4), 600)
+    paths, cons = random_pose_paths(g, np.random.default_rng(4), 5000)  # >= 4096: the host side builds the polygons on several threads
     paths.append(np.zeros((0, 7)))
     cons = np.append(cons, 1).astype(np.uint8)
     with ctx:

@@ -121,6 +121,63 @@ def run_n2(capi, synth, res, out):
             "what": "te_check_footprint_paths on packed host arrays, H2D of the poses and D2H of the results included; the oracle "
                     "(1 thread, same layer) on the first 20000 paths, results bit-identical"}
 
+def run_n2p(capi, synth, res, out):
+    # ---- N2, polygonal footprints: checkPolygonalFootprintPath for a batch of candidate paths -------------------
+    from oracle import oracle as O
+    points = [[0.45, 0.30, 0.0], [0.45, -0.30, 0.0], [-0.45, -0.30, 0.0], [-0.45, 0.30, 0.0]]
+    n = 4096
+    rng = np.random.default_rng(6)
+    elev = synth.with_steps(synth.perlin_elevation(n, n, seed=1235), 400, seed=9)
+    with capi.Context(0) as c:
+        p = params(capi, synth, 9.0, res)
+        c.set_params(p)
+        c.set_geometry(n, n, 1, res)
+        c.upload_elevation(elev)
+        c.run_chain(capi.RUN_FOOTPRINT)
+        c.sync()
+        layers = {k: c.download(k) for k in ("traversability_slope", "traversability_step", "traversability_roughness",
+                                             "traversability")}
+        half = 0.5 * n * res
+        paths = []
+        for _ in range(100000):  # 2..5 poses, segments up to 1.5 m, heading along the segment
+            k = int(rng.integers(2, 6))
+            start = rng.uniform(-half + 3.0, half - 3.0, size=2)
+            xy = np.vstack([start, start + np.cumsum(rng.uniform(-1.5, 1.5, size=(k - 1, 2)), axis=0)])
+            yaw = rng.uniform(-np.pi, np.pi, k)
+            paths.append(np.hstack([xy, np.zeros((k, 3)), np.sin(yaw / 2)[:, None], np.cos(yaw / 2)[:, None]]))
+        cons = (np.arange(len(paths)) % 2).astype(np.uint8)
+        c.check_polygon_footprint_paths(paths[:1000], points, cons[:1000])  # warm-up
+        off = np.zeros(len(paths) + 1, np.int32)
+        off[1:] = np.cumsum([len(q) for q in paths])
+        packed = np.concatenate(paths)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            safe, trav, area, st = c.check_polygon_footprint_paths_packed(off, packed, points, cons)
+            d = time.perf_counter() - t0
+            best = d if best is None or d < best else best
+    m = 300
+    g = O.geom(n, n, res)
+    op = O.default_params(**{k: getattr(p, k) for k in ("normals_radius", "rough_radius", "step_radius1", "step_radius2",
+                                                        "fp_radius", "fp_offset")})
+    t0 = time.perf_counter()
+    ws, wt, wa, wst = O.check_polygon_paths(g, op, elev, layers["traversability_slope"], layers["traversability_step"],
+                                            layers["traversability_roughness"], layers["traversability"], paths[:m], points,
+                                            cons[:m])
+    dt_cpu = time.perf_counter() - t0  # includes the oracle's untraversable-cell pass over the whole map ...
+    t0 = time.perf_counter()
+    O.check_polygon_paths(g, op, elev, layers["traversability_slope"], layers["traversability_step"],
+                          layers["traversability_roughness"], layers["traversability"], paths[:3 * m], points, cons[:3 * m])
+    dt_cpu3 = time.perf_counter() - t0  # ... which the difference of two calls removes
+    assert np.array_equal(ws, safe[:m]) and np.array_equal(wt, trav[:m]) and np.array_equal(wa, area[:m])
+    out["N2 checkFootprintPath (polygonal 0.9 x 0.6 m footprint), 100000 paths of 2-5 poses on 4096x4096"] = {
+        "gpu_paths_per_s": len(paths) / best, "gpu_ms": best * 1e3, "safe_fraction": float(safe.mean()),
+        "cpu_oracle_paths_per_s": 2 * m / max(dt_cpu3 - dt_cpu, 1e-9),
+        "what": "te_check_polygon_footprint_paths on packed host arrays: hulls and areas on the host (1 thread), one launch for "
+                "all segment polygons, results back; the oracle (1 thread) timed as the difference of a 900-path and a 300-path "
+                "call (each also recomputes the untraversable-cell mask of the whole map); first 300 results bit-identical"}
+
+
 def run_n3(capi, synth, res, out):
     # ---- N3: traversabilityFootprint(footprintYaw): the polygon footprint layers over the whole map ------------
     from oracle import oracle as O
@@ -178,7 +235,7 @@ def main():
     res = 0.05
     out = {}
     only = [k for k in os.environ.get("TE_CONFIGS", "").split(",") if k]  # e.g. TE_CONFIGS=N3,N3P runs those alone
-    for name, fn in (("cfg2", run_cfg2), ("cfg4", run_cfg4), ("cfg5", run_cfg5), ("N2", run_n2), ("N3", run_n3)):
+    for name, fn in (("cfg2", run_cfg2), ("cfg4", run_cfg4), ("cfg5", run_cfg5), ("N2", run_n2), ("N2P", run_n2p), ("N3", run_n3)):
         if not only or name in only:
             fn(capi, synth, res, out)
     print(json.dumps(out, indent=1))

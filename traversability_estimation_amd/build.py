@@ -16,7 +16,7 @@ HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "csrc/te_e
 LIB = os.path.join(_HERE, "libtravgpu.so")
 OBJDIR = os.path.join(_HERE, "_build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
-LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
 
 
 def hipcc():

@@ -394,7 +394,14 @@ class Context:
         off = np.zeros(n + 1, np.int32)
         if n:
             off[1:] = np.cumsum([len(p) for p in paths])
-        poses = np.ascontiguousarray(np.concatenate(paths) if n and off[-1] else np.zeros((1, 7)), dtype=np.float64)
+        poses = np.concatenate(paths) if n and off[-1] else np.zeros((1, 7))
+        return self.check_polygon_footprint_paths_packed(off, poses, points_xyz, conservative, map_index)
+
+    def check_polygon_footprint_paths_packed(self, off, poses, points_xyz, conservative=None, map_index=0):
+        """The same with the poses already packed: off int32[n+1] (off[0] == 0), poses float64[off[-1], 7]."""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        n = len(off) - 1
         pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
         cons = None if conservative is None else np.ascontiguousarray(conservative, dtype=np.uint8)
         safe = np.zeros(max(n, 1), np.uint8)

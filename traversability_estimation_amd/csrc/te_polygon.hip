@@ -6,10 +6,11 @@
 // untraversable, otherwise the result is the mean traversability of the cells (NaN counts as traversabilityDefault_).
 //   k_polygon_footprint     traversabilityFootprint(footprintYaw) :239-305: for every cell the footprint polygon centred
 //                           on it, as given (traversability_x) and turned by yaw (traversability_rot)
-//   k_polygons_traversable  a batch of arbitrary polygons (the per-segment hulls of checkPolygonalFootprintPath :464-584)
-// One thread owns one polygon and walks its bounding box in SubmapIterator order (row index outer), so the double sum is
-// the reference's sum bit for bit; lanes of a wavefront own adjacent centre cells, so their reads of the traversability
-// and mask layers coalesce.  Inside / outside is grid_map::Polygon::isInside's crossing-number expression evaluated in
+//   k_polygons_traversable  a batch of arbitrary polygons (the per-segment hulls of checkPolygonalFootprintPath :464-584),
+//                           one wavefront each
+// In k_polygon_footprint one thread owns one polygon and walks its bounding box in SubmapIterator order (row index outer),
+// so the double sum is the reference's sum bit for bit; lanes of a wavefront own adjacent centre cells, so their reads of
+// the traversability and mask layers coalesce.  Inside / outside is grid_map::Polygon::isInside's crossing-number expression evaluated in
 // the same order in double: footprints whose edges pass through cell centres (0.45 m at 0.05 m resolution) are decided
 // by its rounding, cell by cell.  The division is skipped when the cell is clearly left or right of the whole edge.
 #include <algorithm>
@@ -244,25 +245,68 @@ __global__ __launch_bounds__(256) void k_polygon_footprint_table(Geo g, PolygonA
   }
 }
 
-__global__ __launch_bounds__(64) void k_polygons_traversable(Geo g, double def, int n_polygons,
-                                                            const int* __restrict__ vertex_offset,
-                                                            const double* __restrict__ vertex_xy, const float* __restrict__ trav,
-                                                            const uint8_t* __restrict__ untrav,
-                                                            unsigned char* __restrict__ is_traversable,
-                                                            double* __restrict__ traversability) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_polygons) return;
+// A batch of arbitrary polygons (the per-segment hulls of a path check are a few thousand cells each): one wavefront per
+// polygon.  The lanes take 64 consecutive cells of the bounding-box walk at a time; the values are then added in lane
+// order (every lane carries the same running sum), so the double sum is still the reference's sum bit for bit -- cells
+// outside the polygon contribute +0.0, which changes nothing.  An untraversable cell anywhere ends the polygon (the
+// reference stops at the first one in walk order; the result is 0 either way).
+__global__ __launch_bounds__(256) void k_polygons_traversable(Geo g, double def, int n_polygons,
+                                                             const int* __restrict__ vertex_offset,
+                                                             const double* __restrict__ vertex_xy, const float* __restrict__ trav,
+                                                             const uint8_t* __restrict__ untrav,
+                                                             unsigned char* __restrict__ is_traversable,
+                                                             double* __restrict__ traversability) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_polygons) return;  // the whole wavefront
   const double* v = vertex_xy + 2 * (size_t)vertex_offset[k];
-  double t;
-  const bool ok = polygon_traversable(
-      g, untrav, trav, def, vertex_offset[k + 1] - vertex_offset[k],
-      [&](int m, double& x, double& y) {
-        x = v[2 * m];
-        y = v[2 * m + 1];
-      },
-      t);
-  is_traversable[k] = ok ? 1 : 0;
-  traversability[k] = t;
+  const int n = vertex_offset[k + 1] - vertex_offset[k];
+  auto vert = [&](int m, double& x, double& y) {
+    x = v[2 * m];
+    y = v[2 * m + 1];
+  };
+  int ti, bi, tj, bj;
+  polygon_bbox(g, n, vert, ti, bi, tj, bj);
+  const unsigned long long H = (unsigned long long)(bj - tj + 1), total = (unsigned long long)(bi - ti + 1) * H;
+  double t = 0.0;
+  unsigned ncells = 0;
+  bool dead = false;
+  for (unsigned long long base = 0; base < total; base += 64) {
+    const unsigned long long idx = base + lane;
+    double add = 0.0;
+    bool inside = false, bad = false;
+    if (idx < total) {
+      const int a = ti + (int)(idx / H), b = tj + (int)(idx % H);  // SubmapIterator order: row index outer
+      if (polygon_inside(n, vert, cell_x(g, a), cell_y(g, b))) {
+        const size_t o = (size_t)b * g.rows + a;
+        if (untrav[o]) {  // :603-611
+          bad = true;
+        } else {
+          inside = true;
+          const float w = trav[o];
+          add = (w == w && fabsf(w) != __builtin_inff()) ? (double)w : def;  // :613-618
+        }
+      }
+    }
+    if (__ballot(bad) != 0ull) {
+      dead = true;
+      break;
+    }
+    ncells += (unsigned)__popcll(__ballot(inside));
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) t += __shfl(add, l);
+  }
+  if (lane != 0) return;
+  if (dead) {
+    is_traversable[k] = 0;
+    traversability[k] = 0.0;
+  } else if (ncells == 0) {  // :626-629
+    is_traversable[k] = def != 0.0 ? 1 : 0;
+    traversability[k] = def;
+  } else {
+    is_traversable[k] = 1;
+    traversability[k] = t / (double)ncells;
+  }
 }
 
 }  // namespace
@@ -507,7 +551,7 @@ hipError_t launch_polygons_traversable(const Geo& g, double def, int n_polygons,
                                        const float* trav, const uint8_t* untrav, unsigned char* is_traversable,
                                        double* traversability, hipStream_t stream) {
   if (n_polygons <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_polygons_traversable, dim3((unsigned)((n_polygons + 63) / 64)), dim3(64), 0, stream, g, def, n_polygons,
+  hipLaunchKernelGGL(k_polygons_traversable, dim3((unsigned)((n_polygons + 3) / 4)), dim3(256), 0, stream, g, def, n_polygons,
                      vertex_offset, vertex_xy, trav, untrav, is_traversable, traversability);
   return hipGetLastError();
 }

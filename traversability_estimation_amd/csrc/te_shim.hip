@@ -7,8 +7,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include <cstdlib>
@@ -32,7 +34,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                            \
   do {                                                                                           \
     hipError_t e__ = (expr);                                                                     \
-    if (e__ != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));    \
+    if (e__ != hipSuccess) {                                                                     \
+      (void)hipGetLastError(); /* the runtime's last-error slot is sticky: later launches check it */ \
+      return fail(TE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));                          \
+    }                                                                                            \
   } while (0)
 
 // Build the row-run table of the disc {di^2+dj^2 <= (radius/res)^2}.  Offsets whose squared norm
@@ -1046,41 +1051,61 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
     if (pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
   for (long k = 0; k < 7L * pose_offset[n_paths]; ++k)
     if (!isfinite(poses[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: pose %ld is not finite", k / 7);
-  PathPolygons pp;
-  build_path_polygons(n_paths, pose_offset, poses, n_points, points_xyz, conservative, pp);
-  const int n_poly = (int)pp.area.size();
-  std::vector<unsigned char> ok(n_poly > 0 ? n_poly : 1);
-  std::vector<double> val(n_poly > 0 ? n_poly : 1);
-  const int rc = polygons_traversable_locked(c, map, n_poly, pp.vertex_offset.data(), pp.vertex_xy.data(), ok.data(), val.data(),
-                                             "te_check_polygon_footprint_paths");
-  if (rc != TE_OK) return rc;
-  // the loop of :480-580 over the precomputed polygons; a path stops at its first untraversable polygon and keeps
-  // the partial traversability / area, like `result` in the reference
-  for (int k = 0; k < n_paths; ++k) {
-    is_safe[k] = 0;
-    traversability[k] = 0.0;
-    area[k] = 0.0;
-    status[k] = pp.status[k];
-    if (pp.status[k] == 2) continue;
-    const int n = pose_offset[k + 1] - pose_offset[k];
-    bool good = true;
-    for (int s = 0; s < pp.count[k] && good; ++s) {
-      const int q = pp.first[k] + s;
-      if (!ok[q]) {
-        good = false;
-        break;
+  // the polygons of all paths: built on the host (hulls, areas), in chunks on a few threads for large requests
+  const int n_chunks = n_paths >= 4096 ? std::min<int>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  std::vector<PathPolygons> chunk(n_chunks);
+  auto first_of = [&](int q) { return (int)((long)n_paths * q / n_chunks); };
+  {
+    std::vector<std::thread> workers;
+    for (int q = 1; q < n_chunks; ++q)
+      workers.emplace_back([&, q]() {
+        const int k0 = first_of(q);
+        build_path_polygons(first_of(q + 1) - k0, pose_offset + k0, poses, n_points, points_xyz,
+                            conservative ? conservative + k0 : nullptr, chunk[q]);
+      });
+    build_path_polygons(first_of(1), pose_offset, poses, n_points, points_xyz, conservative, chunk[0]);
+    for (std::thread& w : workers) w.join();
+  }
+  std::vector<unsigned char> ok;
+  std::vector<double> val;
+  for (int q = 0; q < n_chunks; ++q) {
+    const PathPolygons& pp = chunk[q];
+    const int k0 = first_of(q), nk = first_of(q + 1) - k0;
+    const int n_poly = (int)pp.area.size();
+    ok.assign(n_poly > 0 ? n_poly : 1, 0);
+    val.assign(n_poly > 0 ? n_poly : 1, 0.0);
+    const int rc = polygons_traversable_locked(c, map, n_poly, pp.vertex_offset.data(), pp.vertex_xy.data(), ok.data(),
+                                               val.data(), "te_check_polygon_footprint_paths");
+    if (rc != TE_OK) return rc;
+    // the loop of :480-580 over the precomputed polygons; a path stops at its first untraversable polygon and keeps
+    // the partial traversability / area, like `result` in the reference
+    for (int kk = 0; kk < nk; ++kk) {
+      const int k = k0 + kk;
+      is_safe[k] = 0;
+      traversability[k] = 0.0;
+      area[k] = 0.0;
+      status[k] = pp.status[kk];
+      if (pp.status[kk] == 2) continue;
+      const int n = pose_offset[k + 1] - pose_offset[k];
+      bool good = true;
+      for (int s = 0; s < pp.count[kk] && good; ++s) {
+        const int g = pp.first[kk] + s;
+        if (!ok[g]) {
+          good = false;
+          break;
+        }
+        if (n == 1 || s == 0) {  // :543-544, :576-577
+          area[k] = pp.area[g];
+          traversability[k] = val[g];
+        } else {  // :570-575
+          const double area_previous = area[k];
+          const double area_polygon = pp.area[g] - pp.area_previous[g];
+          area[k] += area_polygon;
+          traversability[k] = (area_polygon * val[g] + area_previous * traversability[k]) / area[k];
+        }
       }
-      if (n == 1 || s == 0) {  // :543-544, :576-577
-        area[k] = pp.area[q];
-        traversability[k] = val[q];
-      } else {  // :570-575
-        const double area_previous = area[k];
-        const double area_polygon = pp.area[q] - pp.area_previous[q];
-        area[k] += area_polygon;
-        traversability[k] = (area_polygon * val[q] + area_previous * traversability[k]) / area[k];
-      }
+      if (good && pp.status[kk] == 0) is_safe[k] = 1;
     }
-    if (good && pp.status[k] == 0) is_safe[k] = 1;
   }
   return TE_OK;
 }
