@@ -240,3 +240,42 @@ def test_message_in_message_out(capi, bag, start):
         assert n_bad == 0, (k, n_bad, mx)
     # and the written message survives a trip through a bag
     assert capi.bag_find_message(capi.bag_write(out, "traversability_map"), "traversability_map") == out
+
+
+def test_parsers_survive_corrupted_input(capi):
+    """Messages and bags come off the wire: any corruption must end in TE_OK or an error code, never in a crash or an
+    out-of-bounds payload offset."""
+    rows, cols = 7, 5
+    info = make_info(capi, rows, cols, start=(3, 1))
+    msg = capi.msg_write(info, random_layers(rows, cols, ["elevation", "variance"]), basic_layers=("elevation",))
+    bag = capi.bag_write(msg, "grid_map", (12, 34))
+    rng = np.random.default_rng(2024)
+    parsed = rejected = 0
+    for blob, is_bag in ((msg, False), (bag, True)):
+        for trial in range(3000):
+            b = bytearray(blob)
+            kind = trial % 4
+            if kind == 0:  # flip a few bytes
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:  # overwrite a 32-bit length-like field with an extreme value
+                at = int(rng.integers(0, max(1, len(b) - 4)))
+                b[at:at + 4] = struct.pack("<I", int(rng.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF, 0xFFFFFFF0, len(b), len(b) - at])))
+            elif kind == 2:  # truncate
+                b = b[:int(rng.integers(0, len(b)))]
+            else:  # splice garbage in
+                at = int(rng.integers(0, len(b)))
+                b[at:at] = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+            b = bytes(b)
+            try:
+                if is_bag:
+                    m = capi.bag_find_message(b, "grid_map")
+                    assert len(m) <= len(b)
+                else:
+                    got, offs = capi.msg_parse(b)
+                    for off in offs.values():
+                        assert 0 <= off and off + 4 * got.rows * got.cols <= len(b)
+                parsed += 1
+            except capi.TeError:
+                rejected += 1
+    assert parsed > 100 and rejected > 1000

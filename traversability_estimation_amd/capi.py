@@ -178,7 +178,7 @@ def msg_parse(msg):
     off = C.c_size_t()
     for k in range(info.n_layers):
         _check(load().te_msg_layer(msg, len(msg), k, name, C.byref(off)))
-        layers[name.value.decode()] = off.value
+        layers[name.value.decode(errors="replace")] = off.value
     return info, layers
 
 
