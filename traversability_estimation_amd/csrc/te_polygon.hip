@@ -455,6 +455,7 @@ bool build_polygon_table(const Geo& g, int n, const double* off, std::vector<uns
   // is left to that evaluation
   const double scale = fabs(g.pos_x) + fabs(g.pos_y) + g.len_x + g.len_y + ext;
   const double tol = 1e-7 * g.res + 1e-9 * scale;
+  if (!(ext / g.res < 1e6)) return false;  // far beyond any table; also keeps the casts below defined
   const int di_lo = (int)floor(-xmax / g.res) - 1, di_hi = (int)ceil(-xmin / g.res) + 1;
   const int dj_lo = (int)floor(-ymax / g.res) - 1, dj_hi = (int)ceil(-ymin / g.res) + 1;
   if (di_hi - di_lo + 1 > 255 || dj_hi - dj_lo + 1 > 255) return false;
