@@ -18,7 +18,19 @@ def driver():
     build.build_lib()
     O.build()
     exe = os.path.join(PLUG, "plugin_chain_test")
-    if not os.path.exists(exe) or os.environ.get("TE_REBUILD_PLUGINS"):
+
+    def newest(*dirs):
+        t = 0.0
+        for d in dirs:
+            for base, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith((".cpp", ".hpp", ".h")):
+                        t = max(t, os.path.getmtime(os.path.join(base, f)))
+        return t
+
+    src = max(newest(os.path.join(PLUG, "src"), os.path.join(PLUG, "include"), os.path.join(PLUG, "stubs"), os.path.join(PLUG, "test")),
+              os.path.getmtime(os.path.join(ROOT, "include", "travgpu.h")), os.path.getmtime(os.path.join(ROOT, "oracle", "te_oracle.h")))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < src or os.environ.get("TE_REBUILD_PLUGINS"):
         runpy.run_path(os.path.join(PLUG, "build_plugins.py"))["build"]()
     return exe
 
