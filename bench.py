@@ -180,9 +180,11 @@ def main():
                      "what": f"upload elevation + chain + download {len(names)} layers through pageable host buffers, best of 3"}
         # the same with buffers the host keeps across frames and has page-locked once (te_pin_host)
         bufs = [np.empty(stack.size, np.float32) for _ in names]
+        pinned = []
         try:
             for b in [stack] + bufs:
                 capi.pin_host(b)
+                pinned.append(b)
             best = None
             for _ in range(3):
                 t0 = time.perf_counter()
@@ -195,10 +197,14 @@ def main():
                 best = d if best is None or d < best else best
             host_path["pinned_ms"] = best * 1e3
             host_path["pinned_cells_per_s"] = B * n * n / best
-            for b in [stack] + bufs:
-                capi.unpin_host(b)
         except capi.TeError as e:  # page-locking can be refused (ulimit -l); the pageable figure stands
             host_path["pinned_error"] = str(e)
+        finally:
+            for b in pinned:
+                try:
+                    capi.unpin_host(b)
+                except capi.TeError:
+                    pass
         del bufs
 
     check = None
