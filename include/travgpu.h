@@ -30,10 +30,19 @@
  *                           isTraversableForFilters :774-792, checkFor{Slope,Step,Roughness} :794-921)
  *   te_download_layer    <- mapOut.add(type_) / mapOut.at(type_, index) results of each plugin
  *                           (SlopeFilter.cpp:63,77-80 etc.)
+ *   te_check_footprint_paths, te_check_polygon_footprint_paths
+ *                        <- TraversabilityMap::checkFootprintPath, TraversabilityMap.cpp:320-342
+ *                           (checkCircularFootprintPath :344-462, checkPolygonalFootprintPath :464-584)
+ *   te_polygons_traversable <- TraversabilityMap::isTraversable(polygon, traversability), :586-645
+ *   te_run_polygon_footprint <- TraversabilityMap::traversabilityFootprint(footprintYaw), :239-305
+ *   te_upload_msg / te_download_msg / te_msg_* / te_bag_*
+ *                        <- GridMapRosConverter::fromMessage / toMessage / loadFromBag / saveToBag as called in
+ *                           TraversabilityMap.cpp:135-154 and TraversabilityEstimation.cpp:125-152, 248-270, 318-329
  *
  * Data contract (identical to grid_map::Matrix = Eigen::MatrixXf): float32, COLUMN-major,
  * element (row i, col j) of map m at ptr[m*rows*cols + j*rows + i]; invalid cell = non-finite.
- * Circular-buffer start index must be (0,0) (GridMap::convertToDefaultStartIndex() on the host).
+ * The device layers are in logical order; a GridMap that has been move()d (circular-buffer start index != (0,0))
+ * goes through te_upload_layer_circular / te_download_layer_circular / te_upload_msg, which rotate inside the copy.
  *
  * All functions return TE_OK (0) or a negative te_status; te_last_error() gives the message of the
  * calling thread's last failure.  A context is internally serialised (one mutex, one HIP stream);
