@@ -161,7 +161,7 @@ def main():
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
-    if rank == 0 and not args.no_host_path:
+    if rank == 0 and world == 1 and not args.no_host_path:  # N = 1 only: at N > 1 the other ranks would wait for it
         stack = np.stack(elevs)
         names = ["traversability_slope", "traversability_step", "traversability_roughness", "traversability"]
         if with_fp:
@@ -270,7 +270,7 @@ def main():
             out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
         if host_path is not None:
             out["host_path"] = host_path
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
             if args.cpu_all_cores:  # extra, not part of the contract: the same oracle on every host core
                 out["cpu_baseline_all_cores"] = cpu_baseline(args, elevs[0], p, with_fp, threads=os.cpu_count() or 1)
