@@ -221,6 +221,15 @@ int te_polygons_traversable(te_ctx* ctx, int map, int n_polygons, const int* ver
 int te_check_polygon_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
                                      const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
                                      double* traversability, double* area, int* status);
+/* Host part of the above on its own (no device, no context): the polygons checkPolygonalFootprintPath hands to
+ * isTraversable -- the pose polygon of a one-pose path, the convex hull of consecutive (conservatively extended) pose
+ * polygons otherwise -- e.g. to publish them like publishFootprintPolygon (:527, :558).  Path k owns the polygons
+ * polygon_first[k] .. polygon_first[k+1]); polygon p has the vertices vertex_xy[2*vertex_offset[p] .. 2*vertex_offset[p+1])
+ * and the area area[p] (Polygon::getArea).  *n_polygons / *n_vertices receive the totals; nothing is written beyond
+ * cap_polygons polygons / cap_vertices vertices (TE_ERR_INVALID_ARG then: call once with zero capacities to size). */
+int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
+                     const unsigned char* conservative, int cap_polygons, int cap_vertices, int* n_polygons, int* n_vertices,
+                     int* polygon_first, int* vertex_offset, double* vertex_xy, double* area);
 int te_sync(te_ctx* ctx);
 
 int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);

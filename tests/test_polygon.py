@@ -352,6 +352,60 @@ def test_oracle_polygon_paths_match_python_restatement(oracle):
     assert 10 < safe.sum() < len(paths) - 10 and st[-1] == 2
 
 
+def py_path_polygons(poses, points, conservative):
+    """The polygons py_check_polygon_path evaluates, with their areas."""
+    out, poly2, ex, ey = [], [], 0.0, 0.0
+    n = len(poses)
+    for i in range(n):
+        q = [float(v) for v in poses[i]]
+        poly1 = list(poly2)
+        sx, sy, ex, ey = ex, ey, q[0], q[1]
+        x, y, z, w = q[3:7]
+        tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+        twx, twy, twz, txx, txy, txz, tyy, tyz, tzz = tx * w, ty * w, tz * w, tx * x, ty * x, tz * x, ty * y, tz * y, tz * z
+        r00, r01, r02 = 1.0 - (tyy + tzz), txy - twz, txz + twy
+        r10, r11, r12 = txy + twz, 1.0 - (txx + tzz), tyz - twx
+        poly2 = [(((r00 * px + r01 * py) + r02 * pz) + q[0], ((r10 * px + r11 * py) + r12 * pz) + q[1]) for px, py, pz in points]
+        if conservative and i > 0:
+            dx, dy = ex - sx, ey - sy
+            v1, v2 = list(poly1), list(poly2)
+            poly2 += [(vx + dx, vy + dy) for vx, vy in v1]
+            poly1 += [(vx - dx, vy - dy) for vx, vy in v2]
+        if n == 1:
+            out.append((poly2, py_area(poly2)))
+        if n > 1 and i > 0:
+            hull = py_hull(poly1 + poly2)
+            out.append((hull, py_area(hull)))
+    return out
+
+
+def test_library_path_polygons_match_python_restatement(capi):
+    """te_path_polygons: the host half of the polygonal path check (pose polygons, conservative extension, monotone-chain
+    hulls, areas) runs without a device; vertex for vertex and bit for bit the restatement's."""
+    class G:  # only what random_pose_paths reads
+        pos_x, pos_y, len_x, len_y = 0.4, -2.0, 8.0, 6.0
+    paths, cons = random_pose_paths(G, np.random.default_rng(8), 300)
+    # degenerate shapes: repeated poses, a two-point and a one-point "footprint"
+    paths.append(np.tile(paths[0][:1], (3, 1)))
+    cons = np.append(cons, 1).astype(np.uint8)
+    paths.append(np.zeros((0, 7)))
+    cons = np.append(cons, 0).astype(np.uint8)
+    for points in (POINTS_XYZ, [[0.3, 0.0, 0.0], [-0.3, 0.1, 0.05]], [[0.0, 0.0, 0.0]],
+                   [[0.3, 0.3, 0], [0.3, -0.3, 0], [0.0, -0.3, 0], [0.0, 0.0, 0], [-0.3, 0.0, 0], [-0.3, 0.3, 0]]):
+        for conservative in (None, cons):
+            got = capi.path_polygons(paths, points, conservative)
+            assert len(got) == len(paths)
+            for k, path in enumerate(paths):
+                want = py_path_polygons(path, [tuple(float(v) for v in p) for p in points],
+                                        bool(conservative[k]) if conservative is not None else False)
+                assert len(got[k]) == len(want), k
+                for (gv, ga), (wv, wa) in zip(got[k], want):
+                    assert gv.shape == (len(wv), 2) and np.array_equal(gv, np.array(wv, dtype=np.float64).reshape(-1, 2)), k
+                    assert ga == wa, (k, ga, wa)
+    with pytest.raises(capi.TeError, match="footprint points"):
+        capi.path_polygons(paths[:1], np.zeros((0, 3)))
+
+
 @pytest.mark.gpu
 def test_polygon_paths_on_the_device(capi, oracle):
     rows, cols, res = 160, 140, 0.05

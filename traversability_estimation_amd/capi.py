@@ -35,7 +35,7 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_download_layer", "te_time_chain", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
            "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
-           "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host"]
+           "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host", "te_path_polygons"]
 MSG_MAX_NAME = 64
 
 
@@ -120,6 +120,9 @@ def load():
                                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.te_pin_host.argtypes = [vp, C.c_size_t]
         L.te_unpin_host.argtypes = [vp]
+        ip_, dp_ = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.te_path_polygons.argtypes = [C.c_int, ip_, dp_, C.c_int, dp_, C.POINTER(C.c_ubyte), C.c_int, C.c_int, ip_, ip_, ip_, ip_,
+                                       dp_, dp_]
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -229,6 +232,32 @@ def pin_host(array):
 
 def unpin_host(array):
     _check(load().te_unpin_host(array.ctypes.data_as(C.c_void_p)))
+
+
+def path_polygons(paths, points_xyz, conservative=None):
+    """The polygons checkPolygonalFootprintPath evaluates (host computation, no device): returns a list per path of
+    (vertices float64[n, 2], area) tuples."""
+    paths = [np.asarray(p, dtype=np.float64).reshape(-1, 7) for p in paths]
+    n = len(paths)
+    off = np.zeros(n + 1, np.int32)
+    if n:
+        off[1:] = np.cumsum([len(p) for p in paths])
+    poses = np.ascontiguousarray(np.concatenate(paths) if n and off[-1] else np.zeros((1, 7)), dtype=np.float64)
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float64).reshape(-1, 3)
+    cons = None if conservative is None else np.ascontiguousarray(conservative, dtype=np.uint8)
+    ip_, dp_ = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    args = (n, off.ctypes.data_as(ip_), poses.ctypes.data_as(dp_), len(pts), pts.ctypes.data_as(dp_),
+            None if cons is None else cons.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    npoly, nvert = C.c_int(), C.c_int()
+    L = load()
+    L.te_path_polygons(*args, 0, 0, C.byref(npoly), C.byref(nvert), None, None, None, None)  # sizing call
+    first = np.zeros(n + 1, np.int32)
+    voff = np.zeros(npoly.value + 1, np.int32)
+    xy = np.zeros((max(nvert.value, 1), 2), np.float64)
+    area = np.zeros(max(npoly.value, 1), np.float64)
+    _check(L.te_path_polygons(*args, npoly.value, nvert.value, C.byref(npoly), C.byref(nvert), first.ctypes.data_as(ip_),
+                              voff.ctypes.data_as(ip_), xy.ctypes.data_as(dp_), area.ctypes.data_as(dp_)))
+    return [[(xy[voff[q]:voff[q + 1]].copy(), float(area[q])) for q in range(first[k], first[k + 1])] for k in range(n)]
 
 
 def device_count():

@@ -1110,6 +1110,31 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
   return TE_OK;
 }
 
+int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
+                     const unsigned char* conservative, int cap_polygons, int cap_vertices, int* n_polygons, int* n_vertices,
+                     int* polygon_first, int* vertex_offset, double* vertex_xy, double* area) {
+  if (n_paths < 0 || !n_polygons || !n_vertices || !points_xyz || (n_paths > 0 && (!pose_offset || !poses)))
+    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL argument");
+  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
+    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
+  for (int k = 0; k < n_paths; ++k)
+    if (pose_offset[0] != 0 || pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: bad pose offsets");
+  PathPolygons pp;
+  build_path_polygons(n_paths, pose_offset, poses, n_points, points_xyz, conservative, pp);
+  *n_polygons = (int)pp.area.size();
+  *n_vertices = pp.vertex_offset.back();
+  if (*n_polygons > cap_polygons || *n_vertices > cap_vertices)
+    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d polygons / %d vertices do not fit the buffers (%d / %d)", *n_polygons,
+                *n_vertices, cap_polygons, cap_vertices);
+  if (!polygon_first || !vertex_offset || !vertex_xy || !area) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL output");
+  for (int k = 0; k < n_paths; ++k) polygon_first[k] = pp.first[k];
+  polygon_first[n_paths] = *n_polygons;
+  memcpy(vertex_offset, pp.vertex_offset.data(), pp.vertex_offset.size() * sizeof(int));
+  if (*n_vertices) memcpy(vertex_xy, pp.vertex_xy.data(), pp.vertex_xy.size() * sizeof(double));
+  if (*n_polygons) memcpy(area, pp.area.data(), pp.area.size() * sizeof(double));
+  return TE_OK;
+}
+
 int te_sync(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);
