@@ -133,6 +133,8 @@ inline int fix_groups(int ntiles) { return (ntiles + kFixTiles - 1) / kFixTiles;
 
 struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
   int ntx, nty, nbz;
+  int frame;  // > 0: the fix-up pass also owns every cell within `frame` cells of the map border (k_normals3 computes
+              // only discs that lie inside the map), whatever the flags and the slope layer say
 };
 
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
@@ -156,8 +158,12 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
                      hipStream_t s);
 // normals + slope + roughness (same disc for normals and roughness, positive axis z); with `combine`
 // the traversability layer is written too (the step layer must be complete).
+// *combined tells whether it did (the k_normals3 path leaves the combine to the caller).
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
-                  const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s);
+                  const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s, bool* combined);
+// te_normals3.hip: the cells whose disc lies inside the map (false: shape / region not taken)
+bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags,
+                   FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
 void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast

@@ -241,7 +241,9 @@ __device__ __forceinline__ void normals_cell(const Geo& g, const NormalsArgs& a,
         covariance(m, g.res, cov);
         o_rough = roughness_score(m, cov, nf, a.rough_crit);
       } else {
-        o_rough = 0.0f;  // 0 points: mean = 0/0, roughness NaN -> "roughness < crit" false -> 0.0
+        // 0 points: nPoints is a size_t, so sum / (nPoints - 1) = 0 / SIZE_MAX = 0 (RoughnessFilter.cpp:117):
+        // roughness 0 -> score 1 when the critical value is positive
+        o_rough = a.rough_crit > 0.0 ? 1.0f : 0.0f;
       }
     }
     rough[o] = o_rough;
@@ -328,8 +330,14 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
   if (tid0 < 64) {
     const int t = blockIdx.x + tid0 * (int)gridDim.x;
     const int slot = blockIdx.x * kFixTiles + tid0;
-    const bool f = tid0 < kFixTiles && t < ntiles && flags[slot] != 0;
+    bool f = tid0 < kFixTiles && t < ntiles && flags[slot] != 0;
     if (f) flags[slot] = 0;
+    if (fg.frame > 0 && tid0 < kFixTiles && t < ntiles) {  // tiles that reach into the frame are always processed
+      const int ftx = t % fg.ntx, fty = (t / fg.ntx) % fg.nty;
+      const int fi0 = rg.i0 + ftx * TX, fj0 = rg.j0 + fty * TY;
+      const int fi1 = fi0 + TX < rg.i1 ? fi0 + TX : rg.i1, fj1 = fj0 + TY < rg.j1 ? fj0 + TY : rg.j1;
+      f = f || fi0 < fg.frame || fj0 < fg.frame || fi1 > g.rows - fg.frame || fj1 > g.cols - fg.frame;
+    }
     const unsigned long long m = __ballot(f);
     if (tid0 == 0) pending = m;
   }
@@ -360,7 +368,20 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       if (i < rg.i1 && j < jb1) {
         const float z0 = tile[(lj + K) * tw + (threadIdx.x + K)];
         const float s = slope[mo + (size_t)j * g.rows + i];
-        need = (z0 == z0) && !(s == s);
+        const bool in_frame = fg.frame > 0 && (i < fg.frame || j < fg.frame || i >= g.rows - fg.frame || j >= g.cols - fg.frame);
+        need = (z0 == z0) && (!(s == s) || in_frame);
+        if (in_frame && !(z0 == z0)) {  // nobody else writes the frame: an invalid centre has no normal, slope or roughness
+          const size_t o = mo + (size_t)j * g.rows + i;
+          const float qn = __builtin_nanf("");
+          slope[o] = qn;
+          rough[o] = qn;
+          if (a.combine) trav[o] = qn;
+          if (onx) {
+            onx[o] = qn;
+            ony[o] = qn;
+            onz[o] = qn;
+          }
+        }
       }
       // order-preserving compaction (one LDS atomic per wave): neighbouring lanes keep neighbouring cells, so
       // the tile reads of the gather stay (nearly) bank-conflict free
@@ -560,17 +581,20 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   float* const knz = keep ? L.nz : nullptr;
   const bool fused_combine = whole && !overlap && !normals_only;
   FastGrid fg;
+  bool combined = false;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
-      fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream)) {
+      fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream, &combined)) {
+    na.combine = combined ? 1 : 0;
     hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {
+    combined = na.combine != 0;
     hipLaunchKernelGGL(k_normals, tile_grid(g, rn), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, rn);
   }
   if (overlap) (void)hipStreamWaitEvent(stream, L.ev_join, 0);
   // with the footprint pass right behind, its mask kernel (which reads the three scores anyway) combines
-  if (!fused_combine && !normals_only && !(overlap && (flags & kDeferCombine))) {
+  if (!combined && !normals_only && !(overlap && (flags & kDeferCombine))) {
     const dim3 cgrid((unsigned)((rc.i1 - rc.i0 + 255) / 256), (unsigned)(rc.j1 - rc.j0),
                      (unsigned)(rc.map >= 0 ? 1 : g.batch));
     hipLaunchKernelGGL(k_combine, cgrid, dim3(256), 0, stream, g, p.w_scale, p.w_slope, p.w_step, p.w_rough, L.slope,

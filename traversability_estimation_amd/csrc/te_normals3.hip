@@ -1,0 +1,563 @@
+// te_normals3.hip -- NormalVectorsFilter + SlopeFilter + RoughnessFilter for cells whose disc lies inside the map,
+// third formulation of the sliding-disc kernel for gfx950.
+//
+//   NormalVectorsFilter (area method; un-vendored grid_map_filters, call site
+//                        traversability_estimation/config/robot_filter_parameter.yaml:3-9)
+//   SlopeFilter::update      traversability_estimation_filters/src/SlopeFilter.cpp:59-88
+//   RoughnessFilter::update  traversability_estimation_filters/src/RoughnessFilter.cpp:73-132
+//
+// Same mathematics as te_slide_normals.hip (one wavefront owns 64 adjacent cells along i and marches down j; each
+// lane slides the four double z-moments of its disc by the 2R+1 cells of the leading and of the trailing edge), laid
+// out for what bounds this code on gfx950: ONE WAVE ISSUES AT MOST ONE INSTRUCTION PER ~8.3 CYCLES, whatever its type
+// (profiles/r01_valu_rates.txt), while a SIMD retires one fp64 operation per ~4.3 cycles.  Two waves per SIMD can
+// therefore keep the fp64 pipe busy only if they issue nothing but fp64 operations; the previous kernel (2 waves per
+// SIMD, ~440 instructions per row of which 190 fp64) ran at the per-wave issue limit with the fp64 pipe half idle.
+// Here:
+//   * 3 waves per SIMD: <= 168 VGPRs and a ring of exactly 2R+2 rows (12 x 13.1 KB per CU at R = 9);
+//   * the ring is addressed through NR/C "chunk" base registers that rotate once every C rows, the row loop is unrolled
+//     C times and every LDS address is  base register + immediate: no per-row address arithmetic, no scalar ring
+//     bookkeeping (the previous kernel spent ~130 scalar instructions per row, mostly on that);
+//   * the y-moment uses  Sjz' = Sjz - (Sz + Sz')/2 + sum_g (h_g + 1/2) * V_g,  V_g = sum of (lead + trail) over the
+//     columns of half-height h_g: one add per column and one fma per distinct height instead of an fma + add per column;
+//   * the tail keeps fp64 only where the result needs it: D = N*Szz - Sz^2, s = sqrt(delta^2 + h2) (float32 rsq seed +
+//     one Newton step: 2^-45), the smallest eigenvalue (delta + D) - s for the roughness, and  m = 1 - nz^2 =
+//     h2 / (2 s t)  (float32 rcp seed + one Newton step).  nz = sqrt(1 - m) is evaluated as the series
+//     1 - m/2 - m^2/8 - m^3/16 in double where float32 rounding of nz decides the slope (m < 2^-8: |error| < 2^-36),
+//     and as a float32 square root elsewhere (there one float32 ulp of nz moves the slope by < 1.2e-6 rad);
+//   * global addresses are a scalar row pointer + a constant lane offset; blocks never need a lane mask (the last
+//     block of a row of blocks is shifted left to end at the region's edge and recomputes a few columns).
+//   * discs clipped by the map border need no other moments (cells outside the map count as zeros): rows of the top and
+//     bottom frame and the first / last block column take the x/y moments of the clipped disc from the host-built table
+//     and the general tail of te_eig3.h; those block columns are cut into shorter strips so that all blocks of the one
+//     round finish together.
+// Cells whose disc meets an invalid cell are left NaN and their 64x16 tile is flagged for k_normals_fixup, as before.
+#include "te_internal.h"
+#include "te_march.h"
+#include "te_eig.h"
+#include "te_eig3.h"
+
+#include <cstdlib>
+
+namespace te {
+namespace fast {
+
+namespace {
+
+constexpr int kN3Waves = 3;  // waves per SIMD the kernel is compiled for
+#ifndef TE_N3_DIAG
+#define TE_N3_DIAG 0  // measurement builds only: 1 = no tail, 2 = ring reads but no moment arithmetic, 3 = arithmetic on constants, no ring reads
+#endif
+
+struct N3Args {
+  const float* elev;
+  float* slope;
+  float* rough;
+  float* nx;
+  float* ny;
+  float* nz;
+  int* tile_flags;
+  int rows, cols;
+  long long map_cells;
+  int map;             // >= 0: this map only; < 0: blockIdx.z
+  int i_lo, i_hi;      // columns [i_lo, i_hi) and rows [j_lo, j_hi) of the region, i_hi - i_lo >= 64
+  int j_lo, j_hi;
+  // Block columns whose lanes include cells of the left / right map frame (the first edge0 and the last edge1 block
+  // columns: the last block is shifted left to end at the region's edge, so its neighbour can reach the frame too)
+  // and the rows of the top / bottom frame take the general tail; the rest -- n_int block columns, rows [jf_lo, jf_hi) --
+  // the closed-form tail.  Edge columns are cut into shorter strips (rows_edge < rows_int): their rows take longer.
+  int nbx, edge0, edge1, n_int, s_int, s_edge, rows_int, rows_edge, n_top, jf_lo, jf_hi;
+  const int* gtab;     // [(2R+1)^2][6] x/y moments {n, si, sj, sii, sij, sjj} of the disc clipped by the map border
+  double res;
+  double Nd, K1h, Kr2, kinv;  // N; N*res^2*sum(di^2)/2; (N*res)^2; 1/(N(N-1))
+  float inv_slope_crit, inv_rough_crit;
+  float Krf;                  // N*res (normals only)
+  int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
+};
+
+constexpr int n3_chunk_rows(int NR) {
+  const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 2};
+  for (int c : pref)
+    if (NR % c == 0) return c;
+  return 1;
+}
+
+typedef float __attribute__((address_space(1))) gfloat;
+
+// One block: columns [i0, i0 + 64), output rows [js, jend).  GENERAL: every row takes the x/y moments of its (possibly
+// clipped) disc from the table and the general tail -- the blocks of the first / last block column and of the top / bottom
+// frame rows; otherwise every disc of the block lies inside the map and the closed-form tail is used.
+template <int Q, bool KEEP, bool GENERAL>
+__device__ __forceinline__ void march3(const N3Args& a, double* ring, const int i0, const int js, const int jend) {
+  constexpr int R = Shape<Q>::R;
+  constexpr int W = kLanes + 2 * R;
+  constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R: exactly what one slide reads
+  constexpr int C = n3_chunk_rows(NR);
+  constexpr int NC = NR / C;
+  constexpr int RB = W * 8;  // bytes per ring row
+  char* const ringb = reinterpret_cast<char*>(ring);
+  const int lane = threadIdx.x;
+  const int map = a.map >= 0 ? a.map : (int)blockIdx.z;
+  const size_t mo = (size_t)map * (size_t)a.map_cells;
+  const float* __restrict__ em = a.elev + mo;  // uniform
+
+  // ---- reference height: any finite elevation of the strip's first rows (uniform) ---------------------------------
+  float zref32 = 0.0f;
+  {
+    bool found = false;
+    for (int r = js; r <= js + R && r < a.cols && !found; ++r) {
+      const float t = em[(size_t)r * a.rows + i0 + lane];
+      const unsigned long long msk = __ballot(__builtin_isfinite(t));
+      if (msk) {
+        zref32 = __shfl(t, __ffsll((long long)msk) - 1);
+        found = true;
+      }
+    }
+  }
+  const double zref = (double)zref32;
+
+  // ---- ring: zero, then the first real row (js - R) in the newest slot --------------------------------------------
+  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
+  // chunk base registers: byte address of the chunk + the lane's own column
+  unsigned vb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) vb[c] = (unsigned)(c * C * RB + lane * 8);
+  // halo cell of this lane: window columns 0..R-1 and 64+R..W-1, one load covers both sides (lanes >= 2R repeat the last)
+  const int hl = lane < 2 * R ? lane : 2 * R - 1;
+  const int hcol = hl < R ? hl : kLanes + hl;  // window column
+  const int vhd = hcol * 8 - lane * 8;         // added to a chunk base
+  const int lmain = lane;            // lane index of the main cell relative to column i0
+  const bool halo_in = i0 - R + hcol >= 0 && i0 - R + hcol < a.rows;  // halo columns beyond the map edge hold zeros
+  const int lhalo = halo_in ? hcol - R : lane;  // ... of the halo cell (any valid address if there is none)
+  // clip of my disc by the left / right map border (0: none; k > 0: columns di < -R+k missing; k < 0: di > R+k missing)
+  const int icol = i0 + lane;
+  const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
+
+  int dirty_until = js - R - 1;  // outputs j <= dirty_until may see an invalid cell
+  float pm, ph;                  // the prefetched row: main cell, halo cell
+  typedef const float __attribute__((address_space(1))) cgfloat;
+  // (signed 64-bit arithmetic: the first rows of a strip at the top of the map lie above the map and are never loaded)
+  cgfloat* ldp = (cgfloat*)(em + ((long long)(js - R) * a.rows + i0));  // uniform: column i0 of the next row to load
+  auto load_row = [&](int r) __attribute__((always_inline)) {
+    if (r >= 0 && r < a.cols) {
+      pm = ldp[lmain];
+      ph = ldp[lhalo];
+    }
+    ldp += a.rows;
+  };
+  // converts the prefetched row r and writes it to ring slot (chunk base vbase, row offset ro); rows and halo columns
+  // outside the map hold zeros like invalid cells, but do not make a row "dirty": their discs are clipped, not broken
+  auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
+    const bool rin = r >= 0 && r < a.cols;
+    const bool okm = __builtin_isfinite(pm), okh = __builtin_isfinite(ph);
+    const float tm = (okm && rin) ? pm : zref32, th = (okh && halo_in && rin) ? ph : zref32;  // contributes dz = 0
+    const double dm = (double)tm - zref, dh = (double)th - zref;
+    *reinterpret_cast<double*>(ringb + vbase + (ro * RB + R * 8)) = dm;
+    *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = dh;
+    if (rin && __any(!(okm && (okh || !halo_in)))) dirty_until = r + R;
+  };
+  const int jstart = js - (2 * R + 1);  // the march starts with an EMPTY disc: rows above js-R count as zeros
+  __syncthreads();
+  pm = ph = 0.0f;
+  load_row(js - R);
+  stage_row(js - R, vb[NC - 1], C - 1);  // row jstart + R + 1 = slot NR - 1
+  load_row(js - R + 1);                  // row j + 2 + R of step j = jstart
+
+  double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
+  // output pointers of this block's first row (uniform base + lane), advanced by one map row per output row
+  gfloat* p_slope = (gfloat*)(a.slope + mo + (size_t)js * a.rows + i0);
+  gfloat* p_rough = (gfloat*)(a.rough + mo + (size_t)js * a.rows + i0);
+  gfloat* p_nx = KEEP ? (gfloat*)(a.nx + mo + (size_t)js * a.rows + i0) : nullptr;
+  gfloat* p_ny = KEEP ? (gfloat*)(a.ny + mo + (size_t)js * a.rows + i0) : nullptr;
+  gfloat* p_nz = KEEP ? (gfloat*)(a.nz + mo + (size_t)js * a.rows + i0) : nullptr;
+  const int tile_base = (a.map >= 0 ? 0 : (int)blockIdx.z) * a.ntx * a.nty;
+
+  auto flag_tiles = [&](int j) __attribute__((always_inline)) {
+    if (lane == 0) {
+      const int tr = ((j - a.fj0) >> 4) * a.ntx;
+      const int tc0 = (i0 - a.fi0) >> 6, tc1 = (i0 + kLanes - 1 - a.fi0) >> 6;  // a shifted block straddles two tiles
+      const int t0 = tile_base + tr + tc0, t1 = tile_base + tr + tc1;
+      a.tile_flags[(t0 % a.fix_groups) * kFixTiles + t0 / a.fix_groups] = 1;
+      a.tile_flags[(t1 % a.fix_groups) * kFixTiles + t1 / a.fix_groups] = 1;
+    }
+  };
+
+  // ---- tail of row j: closed-form smallest eigenpair of [[c,0,ca],[0,c,cb],[ca,cb,cd]] scaled by N^2 ---------------
+  // (values only: the stores are issued at the end of the step, behind the staging of the next row, so that the wait
+  // for the prefetched row never includes this row's stores)
+  float o_slope, o_rough, fx = 0.0f, fy = 0.0f, fz = 0.0f;
+  auto tail = [&](int j) __attribute__((always_inline)) {
+    bool bad;
+    {
+      const double D = fma(a.Nd, Szz, -(Sz * Sz));        // N^2 var(z)
+      const double dl = fma(-0.5, D, a.K1h);              // delta = (N^2 cxx - D) / 2
+      const double hs = fma(Siz, Siz, Sjz * Sjz);
+      const double h2 = a.Kr2 * hs;                       // N^4 (ca^2 + cb^2)
+      const double q = fma(dl, dl, h2);
+      const float qf = (float)q;
+      double y = (double)__builtin_amdgcn_rsqf(qf);       // 1/sqrt(q), 2^-22
+      {
+        const double e = fma(-(q * y), y, 1.0);
+        y = fma(0.5 * y, e, y);                           // 2^-44
+      }
+      const double s = q * y;                             // sqrt(delta^2 + h2)
+      const double t = dl + s;                            // nz ~ t
+      const double X = fma(dl, s, q);                     // s * t
+      double r = (double)__builtin_amdgcn_rcpf((float)X);
+      {
+        const double e = fma(-X, r, 1.0);
+        r = fma(r, e, r);
+      }
+      const double m2 = h2 * r;                           // 2 (1 - nz^2) = h2 / (s t)
+      // nz = sqrt(1 - m2/2): series where float32 rounding of nz matters, float32 square root elsewhere
+      double pz = fma(m2, 1.0 / 128.0, 1.0 / 32.0);
+      pz = fma(m2, pz, 0.25);
+      const float nz_a = (float)fma(-m2, pz, 1.0);
+      const float om = (float)fma(-0.5, m2, 1.0);         // nz^2
+      const float nz_b = __builtin_amdgcn_sqrtf(om);
+      fz = om > 0.99609375f ? nz_a : nz_b;                // m < 2^-8
+      // degenerate: t <= 0 / not finite, t cancelled (delta < 0 and almost no tilt), q outside float32
+      bad = !(t > 1e-6 * s) || !(qf < 3.0e38f) || !(qf > 1.0e-37f);
+      // roughness^2 (N-1)/N = smallest eigenvalue = (cxx + cd)/2 - s (RoughnessFilter.cpp:105-117)
+      const double lam = fma(0.5, D, a.K1h) - s;
+      float rq = (float)(lam * a.kinv);
+      rq = rq > 0.0f ? rq : 0.0f;
+      const float rgh = __builtin_amdgcn_sqrtf(rq);
+      o_rough = fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f);
+      if (KEEP) {
+        // normal ~ (N res Siz, N res Sjz, t) / sqrt(2 s t)
+        const float inv = __builtin_amdgcn_rsqf((float)(2.0 * X));
+        fx = (float)Siz * a.Krf * inv;
+        fy = (float)Sjz * a.Krf * inv;
+      }
+    }
+    // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
+    const float sl = acosf_poly(fz);
+    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    if (__builtin_expect(__any(bad), 0)) {
+      const float qn = __builtin_nanf("");
+      o_slope = bad ? qn : o_slope;
+      o_rough = bad ? qn : o_rough;
+      fx = bad ? qn : fx;
+      fy = bad ? qn : fy;
+      fz = bad ? qn : fz;
+      flag_tiles(j);
+    }
+  };
+  // rows of the top / bottom frame and block columns with lanes in the left / right frame: x/y moments of the clipped
+  // disc from the host-built table, general tail (te_eig3.h); the z-moments are already right (cells outside count 0)
+  auto tail_clipped = [&](int j, int ky) __attribute__((always_inline)) {
+    const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+    const int n = gt[0];
+    double qs = 0.0;
+    const int unresolved = general_tail3(a.res, n, gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+    const float sl = acosf_poly(fz);
+    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    float rq = (float)(qs * rcp_fast((double)n * (double)(n - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    o_rough = n > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+    if (__builtin_expect(__any(unresolved != 0), 0)) {
+      const float qn = __builtin_nanf("");
+      const bool bad = unresolved != 0;
+      o_slope = bad ? qn : o_slope;
+      o_rough = bad ? qn : o_rough;
+      fx = bad ? qn : fx;
+      fy = bad ? qn : fy;
+      fz = bad ? qn : fz;
+      flag_tiles(j);
+    }
+  };
+  auto dirty_row = [&](int j) __attribute__((always_inline)) {
+    const float qn = __builtin_nanf("");
+    o_slope = o_rough = fx = fy = fz = qn;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
+    flag_tiles(j);
+  };
+  auto store_row = [&]() __attribute__((always_inline)) {
+    p_slope[lane] = o_slope;
+    p_rough[lane] = o_rough;
+    p_slope += a.rows;
+    p_rough += a.rows;
+    if (KEEP) {
+      p_nx[lane] = fx;
+      p_ny[lane] = fy;
+      p_nz[lane] = fz;
+      p_nx += a.rows;
+      p_ny += a.rows;
+      p_nz += a.rows;
+    }
+  };
+
+  // ---- slide from row j to row j+1 at unrolled position u (the oldest row j-R is row u of chunk role 0) -------------
+  auto slide = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    double sv[R + 1];  // sum of (lead + trail) over the columns of half-height h
+    const double Sz0 = Sz;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr int pl = u + R + 1 + h, pt = u + R - h;  // ring positions of the leading row j+1+h and the trailing row j-h
+      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      const char* rl = ringb + vb[al];
+      const char* rt = ringb + vb[at];
+      // one column: leading and trailing cell
+      auto column = [&](auto ec, bool init) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value - R;  // column offset
+        double zl, zt;
+        if (TE_N3_DIAG == 3) {
+          zl = Sjz;
+          zt = Szz;
+        } else {
+          zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + e) * 8));
+          zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + e) * 8));
+        }
+        if (TE_N3_DIAG == 2) {
+          Sz += zl;
+          Szz += zt;
+          if (init) sv[h] = 0.0;
+          return;
+        }
+        const double uu = zl - zt, vv = zl + zt;
+        Sz += uu;
+        if (e != 0) Siz = fma((double)e, uu, Siz);
+        Szz = fma(uu, vv, Szz);
+        if (init)
+          sv[h] = vv;
+        else
+          sv[h] += vv;
+      };
+      column(std::integral_constant<int, R + d>{}, first);
+      if (d != 0) column(std::integral_constant<int, R - d>{}, false);
+    });
+    double acc = Sjz;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      if (first) acc = fma((double)h + 0.5, sv[h], acc);
+    });
+    Sjz = fma(-0.5, Sz0 + Sz, acc);
+  };
+
+  // ---- the march ---------------------------------------------------------------------------------------------------
+  int j = jstart;
+#pragma unroll 1
+  while (true) {
+    bool finished = false;
+    static_for<C>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if (finished) return;
+      if (__builtin_expect(j >= jend, 0)) {
+        finished = true;
+        return;
+      }
+      const bool out = j >= js;  // (uniform) the warm-up rows have no output
+      if (out) {
+        if (TE_N3_DIAG == 1) {
+          o_slope = (float)Sz; o_rough = (float)(Siz + Sjz + Szz);
+        } else if (__builtin_expect(j > dirty_until, 1)) {
+          if (GENERAL) {
+            const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+            tail_clipped(j, ky);
+          } else {
+            tail(j);
+          }
+        } else {
+          dirty_row(j);
+        }
+      }
+      slide(uc);
+      // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
+      stage_row(j + 2 + R, vb[0], u);
+      load_row(j + 3 + R);
+      if (out) store_row();
+      ++j;
+    });
+    if (finished) break;
+    if (NC > 1) {  // the chunk that held the oldest rows now holds the newest
+      const unsigned v0 = vb[0];
+#pragma unroll
+      for (int c = 0; c + 1 < NC; ++c) vb[c] = vb[c + 1];
+      vb[NC - 1] = v0;
+    }
+  }
+}
+
+template <int Q, bool KEEP>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3(N3Args a) {
+  constexpr int R = Shape<Q>::R;
+  __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+  // which block (uniform): [0, nb_fast) interior columns x interior rows; then the edge block columns over all rows;
+  // then the top and the bottom frame rows of the interior columns
+  int b = (int)blockIdx.x, bx, js, jend;
+  bool general = true;
+  const int nb_fast = a.n_int * a.s_int, ne = a.edge0 + a.edge1;
+  if (b < nb_fast) {
+    general = false;
+    bx = a.edge0 + b % a.n_int;
+    js = a.jf_lo + (b / a.n_int) * a.rows_int;
+    jend = js + a.rows_int < a.jf_hi ? js + a.rows_int : a.jf_hi;
+  } else if ((b -= nb_fast) < ne * a.s_edge) {
+    const int q = b % ne;
+    bx = q < a.edge0 ? q : a.nbx - ne + q;
+    js = a.j_lo + (b / ne) * a.rows_edge;
+    jend = js + a.rows_edge < a.j_hi ? js + a.rows_edge : a.j_hi;
+  } else {
+    b -= ne * a.s_edge;
+    const bool bottom = b >= a.n_top;  // n_top = n_int if the region has top frame rows, else 0
+    bx = a.edge0 + (bottom ? b - a.n_top : b);
+    js = bottom ? a.jf_hi : a.j_lo;
+    jend = bottom ? a.j_hi : a.jf_lo;
+  }
+  int i0 = a.i_lo + bx * kLanes;
+  i0 = i0 + kLanes > a.i_hi ? a.i_hi - kLanes : i0;  // the last block ends at the edge
+  if (js >= jend) return;
+  if (general)
+    march3<Q, KEEP, true>(a, ring, i0, js, jend);
+  else
+    march3<Q, KEEP, false>(a, ring, i0, js, jend);
+}
+
+// Resident single-wave blocks per CU and CUs of the current device.  The LDS allocation granularity decides: at R = 9
+// (13 120 B) 11 blocks fit, not 12 (tools/census.hip), and a grid of 12 per CU runs in two rounds -- twice the time.
+template <int Q, bool KEEP>
+int resident_blocks() {
+  static int cached = 0;
+  if (cached == 0) {
+    // (hipOccupancyMaxActiveBlocksPerMultiprocessor answers 12 for 13 120 B; the hardware admits 11: the census fits an
+    // allocation granule of 1280..2048 bytes, the conservative end is used here)
+    constexpr int R = Shape<Q>::R;
+    constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8;
+    int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048), dev = 0;
+    hipDeviceProp_t prop;
+    if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    static const char* ov = getenv("TE_N3_BLOCKS_PER_CU");  // measurement aid
+    if (ov && atoi(ov) > 0) per_cu = atoi(ov);
+    cached = per_cu * prop.multiProcessorCount;
+  }
+  return cached;
+}
+
+template <int Q>
+bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s) {
+  N3Args a = a0;
+  const int H = a.j_hi - a.j_lo;
+  // As many blocks as fill the resident wave slots in ONE round.  Edge block columns run the general tail on every row
+  // (about 1.5x the time of an interior row): their strips are 1.5x shorter so that all blocks finish together.
+  const int capacity = (keep ? resident_blocks<Q, true>() : resident_blocks<Q, false>()) / (maps > 0 ? maps : 1);
+  const int ne = a.edge0 + a.edge1;
+  constexpr int R = Shape<Q>::R;
+  a.n_int = a.nbx - ne;
+  a.jf_lo = a.j_lo > R ? a.j_lo : (R < a.j_hi ? R : a.j_hi);                          // first row below the top frame
+  a.jf_hi = a.j_hi < g.cols - R ? a.j_hi : (g.cols - R > a.jf_lo ? g.cols - R : a.jf_lo);  // one past the last above the bottom frame
+  a.n_top = a.jf_lo > a.j_lo ? a.n_int : 0;
+  const int n_bottom = a.j_hi > a.jf_hi ? a.n_int : 0;
+  const int Hf = a.jf_hi - a.jf_lo;
+  int rows_int = 512;
+  static const char* ev = getenv("TE_N3_EDGE_PERCENT");  // measurement aid: strip height of the edge columns in percent
+  const int pct = ev && atoi(ev) > 0 ? atoi(ev) : 50;
+  auto edge_rows = [&](int h) { return (pct * h + 99) / 100; };
+  for (int h = 24; h <= 512; ++h) {  // smallest strip height whose block count fits
+    const int he = edge_rows(h);
+    const int blocks = a.n_int * ((Hf + h - 1) / h) + ne * ((H + he - 1) / he) + a.n_top + n_bottom;
+    if (blocks <= capacity) {
+      rows_int = h;
+      break;
+    }
+  }
+  a.rows_int = rows_int;
+  a.rows_edge = edge_rows(rows_int);
+  a.s_int = (a.n_int > 0 && Hf > 0) ? (Hf + a.rows_int - 1) / a.rows_int : 0;
+  a.s_edge = ne > 0 ? (H + a.rows_edge - 1) / a.rows_edge : 0;
+  const int nblocks = a.n_int * a.s_int + ne * a.s_edge + a.n_top + n_bottom;
+  if (nblocks <= 0) return true;
+  const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
+  if (keep)
+    hipLaunchKernelGGL((k_normals3<Q, true>), grid, dim3(kLanes), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_normals3<Q, false>), grid, dim3(kLanes), 0, s, a);
+  return true;
+}
+
+}  // namespace
+
+// shapes this file is instantiated for
+#ifndef TE_N3_SHAPES
+#define TE_N3_SHAPES(X) X(2) X(25) X(81)
+#endif
+
+// The normals / slope / roughness pass over region r (discs clipped by the map border included); returns false
+// if this kernel does not take the case (the caller then uses the sliding kernel of te_slide_normals.hip for everything).
+// On success the caller still owes the fix-up pass for the tiles this kernel flagged.
+bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* flags,
+                   FastGrid* fgp, hipStream_t s) {
+  FastGrid& fg = *fgp;
+  const Disc& d = p.normals;
+  if (d.n_ties != 0 || d.R < 1 || d.Q < 1 || d.npoints < 3) return false;
+  const int R = d.R;
+  N3Args a;
+  a.i_lo = r.i0;
+  a.i_hi = r.i1;
+  a.j_lo = r.j0;
+  a.j_hi = r.j1;
+  if (a.i_hi - a.i_lo < kLanes || a.j_hi <= a.j_lo || !L.clip_table) return false;
+  if (g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;  // both borders inside one disc: the clip codes do not cover that
+  if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;  // 32-bit byte offsets inside a map
+  long long sii = 0;
+  for (int dj = -R; dj <= R; ++dj) {
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) sii += di * di;
+  }
+  const double N = (double)d.npoints;
+  if (!(g.res * g.res * ((double)sii / N) > 1e-8)) return false;  // NormalVectorsFilter's eigenvalue test would fail everywhere
+  a.elev = L.elev;
+  a.slope = L.slope;
+  a.rough = L.rough;
+  a.nx = L.nx;
+  a.ny = L.ny;
+  a.nz = L.nz;
+  a.tile_flags = flags;
+  a.rows = g.rows;
+  a.cols = g.cols;
+  a.map_cells = (long long)g.rows * g.cols;
+  a.map = r.map;
+  a.nbx = (a.i_hi - a.i_lo + kLanes - 1) / kLanes;
+  a.edge0 = a.edge1 = 0;
+  {
+    auto is_edge = [&](int bx) {
+      int i0 = a.i_lo + bx * kLanes;
+      i0 = i0 + kLanes > a.i_hi ? a.i_hi - kLanes : i0;
+      return i0 < R || i0 + kLanes - 1 > g.rows - 1 - R;
+    };
+    while (a.edge0 < a.nbx && is_edge(a.edge0) && (a.i_lo + a.edge0 * kLanes < R)) ++a.edge0;  // left: columns that reach i < R
+    while (a.edge1 < a.nbx - a.edge0 && is_edge(a.nbx - 1 - a.edge1)) ++a.edge1;
+  }
+  a.gtab = L.clip_table;
+  a.res = g.res;
+  a.Nd = N;
+  a.K1h = 0.5 * N * g.res * g.res * (double)sii;
+  a.Kr2 = (N * g.res) * (N * g.res);
+  a.kinv = 1.0 / (N * (N - 1.0));
+  a.inv_slope_crit = (float)(1.0 / p.slope_crit);
+  a.inv_rough_crit = (float)(1.0 / p.rough_crit);
+  a.Krf = (float)(N * g.res);
+  a.fi0 = r.i0;
+  a.fj0 = r.j0;
+  a.ntx = fg.ntx;
+  a.nty = fg.nty;
+  a.fix_groups = fix_groups(fg.ntx * fg.nty * fg.nbz);
+  const int maps = r.map >= 0 ? 1 : g.batch;
+  switch (d.Q) {
+#define X(q) \
+  case q:    \
+    return launch3<q>(g, a, keep_normals, maps, s);
+    TE_N3_SHAPES(X)
+#undef X
+    default:
+      return false;
+  }
+}
+
+}  // namespace fast
+}  // namespace te

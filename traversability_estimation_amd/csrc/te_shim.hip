@@ -136,6 +136,11 @@ struct te_ctx {
   int* fp_clip_table = nullptr;
   bool combine_deferred = false;
   bool tables_ready = false;
+  // the circular-footprint tables are built separately: a footprint this build cannot handle (more than 20 cells) must
+  // not stop the filter chain or the per-plugin entry points, which never use them (the reference has no such coupling)
+  bool fp_tables_ready = false;
+  int fp_tables_rc = TE_OK;
+  char fp_tables_err[256] = "";
   // the launch sequence of a whole-map run, captured once per (flags, parameters, geometry) and replayed
   static constexpr int kGraphs = 4;  // one per flag combination in use
   hipGraphExec_t graph_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
@@ -153,39 +158,12 @@ void drop_graph(te_ctx* c) {
   }
 }
 
-int rebuild_tables(te_ctx* c) {
-  c->tables_ready = false;
-  drop_graph(c);  // kernel arguments (disc tables, grids) are baked into the captured launches
-  if (!c->have_params || !c->have_geo) return TE_OK;
+// Discs of the three footprint checks, SpiralIterator order and clip table of the circular footprint pass.  A failure is
+// recorded (fp_tables_rc / fp_tables_err) and reported by the entry points that need the footprint, not by the chain.
+int rebuild_footprint_tables_impl(te_ctx* c) {
   const te_params& p = c->params;
   const double res = c->geo.res;
   int rc;
-  if ((rc = build_disc(p.normals_radius, res, &c->cp.normals, "normals"))) return rc;
-  if ((rc = build_disc(p.rough_radius, res, &c->cp.rough, "roughness estimation"))) return rc;
-  if ((rc = build_disc(p.step_radius1, res, &c->cp.step1, "step first window"))) return rc;
-  if ((rc = build_disc(p.step_radius2, res, &c->cp.step2, "step second window"))) return rc;
-  c->cp.same_rough_disc = same_disc(c->cp.normals, c->cp.rough) ? 1 : 0;
-  c->cp.axis = p.normals_axis;
-  c->cp.slope_crit = p.slope_critical;
-  c->cp.step_crit = p.step_critical;
-  c->cp.rough_crit = p.rough_critical;
-  c->cp.step_ncrit = p.step_ncrit;
-  c->cp.w_scale = p.w_scale;
-  c->cp.w_slope = p.w_slope;
-  c->cp.w_step = p.w_step;
-  c->cp.w_rough = p.w_rough;
-  // x/y moments of the normals disc clipped by the map border, for the sliding-disc kernel
-  if (c->cp.normals.n_ties == 0 && c->cp.normals.R >= 1) {
-    const int R = c->cp.normals.R;
-    std::vector<int> tab((size_t)(2 * R + 1) * (2 * R + 1) * 6);
-    fast::build_clip_table(c->cp.normals, R, tab.data());
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1)));
-    HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
-  c->L.clip_table = c->clip_table;
-
   // ---- circular footprint: discs of the three checks, spiral order, clip table ----------------------
   {
     FootprintParams& f = c->fp;
@@ -269,7 +247,57 @@ int rebuild_tables(te_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->fp_clip_table, ctab.data(), ctab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  return TE_OK;
+}
+
+void rebuild_footprint_tables(te_ctx* c) {
+  c->fp_tables_ready = false;
+  const int rc = rebuild_footprint_tables_impl(c);
+  c->fp_tables_rc = rc;
+  if (rc) {
+    snprintf(c->fp_tables_err, sizeof(c->fp_tables_err), "%s", g_err);
+    (void)hipGetLastError();
+  } else {
+    c->fp_tables_ready = true;
+  }
+}
+
+int rebuild_tables(te_ctx* c) {
+  c->tables_ready = false;
+  c->fp_tables_ready = false;
+  drop_graph(c);  // kernel arguments (disc tables, grids) are baked into the captured launches
+  if (!c->have_params || !c->have_geo) return TE_OK;
+  const te_params& p = c->params;
+  const double res = c->geo.res;
+  int rc;
+  if ((rc = build_disc(p.normals_radius, res, &c->cp.normals, "normals"))) return rc;
+  if ((rc = build_disc(p.rough_radius, res, &c->cp.rough, "roughness estimation"))) return rc;
+  if ((rc = build_disc(p.step_radius1, res, &c->cp.step1, "step first window"))) return rc;
+  if ((rc = build_disc(p.step_radius2, res, &c->cp.step2, "step second window"))) return rc;
+  c->cp.same_rough_disc = same_disc(c->cp.normals, c->cp.rough) ? 1 : 0;
+  c->cp.axis = p.normals_axis;
+  c->cp.slope_crit = p.slope_critical;
+  c->cp.step_crit = p.step_critical;
+  c->cp.rough_crit = p.rough_critical;
+  c->cp.step_ncrit = p.step_ncrit;
+  c->cp.w_scale = p.w_scale;
+  c->cp.w_slope = p.w_slope;
+  c->cp.w_step = p.w_step;
+  c->cp.w_rough = p.w_rough;
+  // x/y moments of the normals disc clipped by the map border, for the sliding-disc kernel
+  if (c->cp.normals.n_ties == 0 && c->cp.normals.R >= 1) {
+    const int R = c->cp.normals.R;
+    std::vector<int> tab((size_t)(2 * R + 1) * (2 * R + 1) * 6);
+    fast::build_clip_table(c->cp.normals, R, tab.data());
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1)));
+    HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->L.clip_table = c->clip_table;
+
   c->tables_ready = true;
+  rebuild_footprint_tables(c);
   return TE_OK;
 }
 
@@ -333,6 +361,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
 int run_footprint_locked(te_ctx* c, unsigned flags) {
   if (!c->chain_done || !c->tables_ready)
     return fail(TE_ERR_NOT_READY, "te_run_footprint: run the filter chain first (it produces the layers the footprint reads)");
+  if (!c->fp_tables_ready) return fail(c->fp_tables_rc ? c->fp_tables_rc : TE_ERR_NOT_READY, "%s", c->fp_tables_err);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
                            c->combine_deferred ? &c->cp : nullptr, c->stream));
@@ -569,7 +598,10 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const size_t elems = (size_t)rows * cols * batch;
-  if (elems != c->layer_elems) {
+  // a new shape always gets a fresh slab: the fix-up flag array is sized from (rows, cols, batch), not from the cell
+  // count (a transposed map of equal size needs a different number of 64x16 tiles), and layers computed for another
+  // shape must not be served as if they belonged to this one
+  if (elems != c->layer_elems || rows != c->geo.rows || cols != c->geo.cols || batch != c->geo.batch) {
     free_layers(c);
     // one slab: 13 float layers + 1 byte layer, each 256-byte aligned
     const size_t lb = (elems * sizeof(float) + 255) & ~(size_t)255;

@@ -30,6 +30,8 @@
 #include "te_march.h"
 #include "te_eig.h"
 
+#include <cstdlib>
+
 namespace te {
 namespace fast {
 
@@ -489,7 +491,7 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
 // Normals + slope + roughness for a tie-free disc (same disc for normals and roughness, positive axis
 // z, at least 3 cells).  Returns false if the shape is not supported by this kernel.
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
-                  const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s) {
+                  const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s, bool* combined) {
   const Disc& d = p.normals;
   if (d.n_ties != 0 || d.R < 1 || d.R > 16 || d.npoints < 3) return false;
   SlideArgs a;
@@ -523,6 +525,14 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.combine = combine ? 1 : 0;
   a.gtab = gtab;
   if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
+  // cells whose disc lies inside the map: k_normals3 (3 waves per SIMD); this file keeps the frame
+  static const bool no_n3 = getenv("TE_NO_N3") != nullptr;
+  fg->frame = 0;
+  if (!no_n3 && normals_fast3(g, p, L, keep_normals, r, flags, fg, s)) {
+    *combined = false;  // k_normals3 does not combine: the caller runs k_combine (or the footprint mask kernel does)
+    return true;        // the frame and whatever that kernel flagged belong to the fix-up pass
+  }
+  *combined = combine;
   if (d.Q >= 1) {  // instantiated shape: compile-time run table
     switch (d.Q) {
 #define X(q)                                                              \
