@@ -11,12 +11,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
+SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 OBJDIR = os.path.join(_HERE, "_build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
+# per-source flags.  te_normals3: keep the ring reads as single ds_read_b64 -- a merged ds_read2_b64 halves the LDS rate
+# (MI355X_MICROARCH.md, LDS table) and the kernel sits at 60 % LDS occupancy with them (4 % slower, same-box A/B)
+_SINGLE_DS_READS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
+EXTRA_CFLAGS = {"csrc/te_normals3.hip": _SINGLE_DS_READS, "csrc/te_footprint3.hip": _SINGLE_DS_READS}
 
 
 def hipcc():
@@ -42,7 +46,7 @@ def _obj(src):
 
 
 def _compile(src, verbose):
-    cmd = [hipcc()] + CFLAGS + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
+    cmd = [hipcc()] + CFLAGS + EXTRA_CFLAGS.get(src, []) + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
                                os.path.join(_HERE, src), "-o", _obj(src) + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -61,6 +61,21 @@ __device__ __forceinline__ float acosf_poly(float x) {
   return x < 0.0f ? 3.14159274f - r : r;
 }
 
+// the same for 0 <= x <= 1 (a normal turned towards +z)
+__device__ __forceinline__ float acosf_poly01(float x) {
+  const bool big = x > 0.5f;
+  const float u = big ? 0.5f * (1.0f - x) : x * x;
+  const float y = big ? __builtin_amdgcn_sqrtf(u) : x;
+  float p = 3.369084721e-02f;
+  p = fmaf(p, u, 1.714923835e-02f);
+  p = fmaf(p, u, 3.110066274e-02f);
+  p = fmaf(p, u, 4.459940153e-02f);
+  p = fmaf(p, u, 7.500094543e-02f);
+  p = fmaf(p, u, 1.666666634e-01f);
+  const float as = fmaf(y * u, p, y);
+  return big ? 2.0f * as : 1.57079637f - as;
+}
+
 // General tail for a disc clipped by the map border (or any validity pattern whose x/y moments are
 // known): population covariance from the moments, smallest eigenpair of the 3x3 via a Jacobi
 // rotation of the x/y block and a safeguarded Newton iteration on the secular equation of the

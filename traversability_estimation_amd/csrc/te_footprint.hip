@@ -756,6 +756,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.rmin = p.rmin;
   a.rmax = p.rmax;
   a.def = p.def;
+  // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
+  if (fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream)) return hipGetLastError();
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
     const int Rk = p.reach;

@@ -1,0 +1,283 @@
+// te_footprint3.hip -- the sliding-sum kernel of the circular footprint pass, laid out like k_normals3.
+//
+//   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
+//     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
+//
+// Same arithmetic as k_fp_slide (te_footprint.hip): one double per cell, T' + 4096 U (T' = traversability, NaN ->
+// default; U = 1 for a cell that fails isTraversableForFilters), the disc sum slides one row per step, a disc without
+// an untraversable cell gives the mean, otherwise the lane walks the host-built SpiralIterator table over the rows in
+// the ring until the first untraversable cell.  What changed is the instruction stream (te_normals3.hip explains why
+// that is what counts on gfx950): ring of exactly 2R+2 rows addressed through rotating chunk base registers with
+// immediate offsets (no scalar ring bookkeeping: the old kernel issued 65 scalar instructions per row), one running
+// scalar row pointer per layer, 11-12 single-wave blocks per CU instead of 8.
+#include "te_internal.h"
+#include "te_march.h"
+
+#include <cstdlib>
+
+namespace te {
+namespace fast {
+
+namespace {
+
+constexpr int kF3Waves = 3;
+constexpr double kUOff3 = 4096.0;  // as in te_footprint.hip: sums of T' stay below it, so sum(T') and sum(U) split exactly
+
+struct F3Args {
+  const float* trav;
+  const uint8_t* untrav;
+  float* footprint;
+  int rows, cols;
+  long long map_cells;
+  int nbx, strip_rows;
+  int n_spiral;
+  const int16_t* table;  // [n_spiral][4]: di, dj, ring (integer norm), tie flag (never set here: tie-free discs only)
+  const int* gtab;       // clip table of the disc: {n, ...} per (ky, kx)
+  double rmin, rmax, def, res;
+};
+
+constexpr int f3_chunk_rows(int NR) {
+  const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 2};
+  for (int c : pref)
+    if (NR % c == 0) return c;
+  return 1;
+}
+
+template <int Q>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves, 4))) void k_fp_slide3(F3Args a) {
+  constexpr int R = Shape<Q>::R;
+  constexpr int W = kLanes + 2 * R;
+  constexpr int NR = 2 * R + 2;
+  constexpr int C = f3_chunk_rows(NR);
+  constexpr int NC = NR / C;
+  constexpr int RB = W * 8;
+  __shared__ double ring[NR * W];
+  char* const ringb = reinterpret_cast<char*>(ring);
+  typedef const float __attribute__((address_space(1))) cgfloat;
+  typedef const uint8_t __attribute__((address_space(1))) cgbyte;
+  typedef float __attribute__((address_space(1))) gfloat;
+
+  const int lane = threadIdx.x;
+  const int bx = (int)blockIdx.x % a.nbx, strip = (int)blockIdx.x / a.nbx;
+  int i0 = bx * kLanes;
+  i0 = i0 + kLanes > a.rows ? a.rows - kLanes : i0;  // the last block ends at the map edge (rows >= 64)
+  const int js = strip * a.strip_rows;
+  if (js >= a.cols) return;
+  const int jend = js + a.strip_rows < a.cols ? js + a.strip_rows : a.cols;
+  const size_t mo = (size_t)blockIdx.z * (size_t)a.map_cells;
+
+  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
+  unsigned vb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) vb[c] = (unsigned)(c * C * RB + lane * 8);
+  const int hl = lane < 2 * R ? lane : 2 * R - 1;
+  const int hcol = hl < R ? hl : kLanes + hl;
+  const int vhd = hcol * 8 - lane * 8;
+  const bool halo_in = i0 - R + hcol >= 0 && i0 - R + hcol < a.rows;
+  const int lhalo = halo_in ? hcol - R : lane;
+  const int icol = i0 + lane;
+  const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
+  const int nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
+
+  float pm = 0.0f, ph = 0.0f;
+  unsigned um = 0, uh = 0;
+  cgfloat* ldt = (cgfloat*)(a.trav + mo + ((long long)(js - R) * a.rows + i0));
+  cgbyte* ldu = (cgbyte*)(a.untrav + mo + ((long long)(js - R) * a.rows + i0));
+  auto load_row = [&](int r) __attribute__((always_inline)) {
+    if (r >= 0 && r < a.cols) {
+      pm = ldt[lane];
+      ph = ldt[lhalo];
+      um = ldu[lane];
+      uh = ldu[lhalo];
+    }
+    ldt += a.rows;
+    ldu += a.rows;
+  };
+  auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
+    const bool rin = r >= 0 && r < a.cols;
+    const double tm = __builtin_isfinite(pm) ? (double)pm : a.def;  // :719-724
+    const double th = __builtin_isfinite(ph) ? (double)ph : a.def;
+    const double vm = fma((double)um, kUOff3, tm), vh = fma((double)uh, kUOff3, th);
+    *reinterpret_cast<double*>(ringb + vbase + (ro * RB + R * 8)) = rin ? vm : 0.0;  // cells outside the map: nothing
+    *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0.0;
+  };
+  const int jstart = js - (2 * R + 1);
+  __syncthreads();
+  load_row(js - R);
+  stage_row(js - R, vb[NC - 1], C - 1);
+  load_row(js - R + 1);
+
+  double S = 0.0;
+  gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
+  float out = 0.0f;
+  double rnt = 1.0 / (double)nt_mid;
+  const double drmin = a.rmin, inv_span = 1.0 / (a.rmax - a.rmin);
+
+  auto tail = [&](int j, int u) __attribute__((always_inline)) {
+    int nt = nt_mid;
+    double rn = rnt;
+    const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+    if (__builtin_expect(ky != 0, 0)) {
+      nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
+      rn = 1.0 / (double)nt;
+    }
+    out = (float)(S * rn);  // :732-735 no untraversable cell in the footprint: the mean
+    const bool blocked = S >= 0.5 * kUOff3;
+    if (__builtin_expect(__any(blocked), 0)) {
+      if (blocked) {
+        // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
+        // oldest row of the ring, which is row u of the chunk vb[0] points to
+        const int slot0 = (int)((__builtin_amdgcn_readfirstlane(vb[0])) / RB) + u;
+        double t = 0.0;
+        int ncells = 0;
+        float o = __builtin_nanf("");
+        for (int kk = 0; kk < a.n_spiral; ++kk) {
+          const int di = a.table[4 * kk + 0], dj = a.table[4 * kk + 1];
+          const int ii = icol + di, jj = j + dj;
+          if (ii < 0 || ii >= a.rows || jj < 0 || jj >= a.cols) continue;
+          int sl = slot0 + dj + R;
+          sl = sl >= NR ? sl - NR : sl;
+          sl = sl >= NR ? sl - NR : sl;
+          const double v = ring[sl * W + lane + R + di];
+          if (v >= 0.5 * kUOff3) {
+            const double ru = (double)a.table[4 * kk + 2] * a.res;  // getCurrentRadius()
+            if (drmin == 0.0 || ru <= drmin) {
+              o = 0.0f;  // :694-704
+            } else {
+              const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
+              t *= factor / ncells;
+              o = (float)t;
+            }
+            break;
+          }
+          ncells++;
+          t += v;
+        }
+        if (!(o == o)) o = (float)(t / ncells);  // cannot happen (an untraversable cell is in the disc)
+        out = o;
+      }
+    }
+  };
+
+  auto slide = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    double acc = 0.0;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr int pl = u + R + 1 + h, pt = u + R - h;
+      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
+      const char* rl = ringb + vb[al];
+      const char* rt = ringb + vb[at];
+      const double zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + d) * 8));
+      const double zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + d) * 8));
+      if (d == 0) {
+        acc = zl - zt;
+      } else {
+        const double zl2 = *reinterpret_cast<const double*>(rl + (ol * RB + (R - d) * 8));
+        const double zt2 = *reinterpret_cast<const double*>(rt + (ot * RB + (R - d) * 8));
+        acc += (zl - zt) + (zl2 - zt2);
+      }
+    });
+    S += acc;  // every term is exact (multiples of the float quantum below 2^53), so is any order
+  };
+
+  int j = jstart;
+#pragma unroll 1
+  while (true) {
+    bool finished = false;
+    static_for<C>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if (finished) return;
+      if (__builtin_expect(j >= jend, 0)) {
+        finished = true;
+        return;
+      }
+      const bool emit = j >= js;
+      if (emit) tail(j, u);
+      slide(uc);
+      stage_row(j + 2 + R, vb[0], u);
+      load_row(j + 3 + R);
+      if (emit) {
+        p_out[lane] = out;
+        p_out += a.rows;
+      }
+      ++j;
+    });
+    if (finished) break;
+    if (NC > 1) {
+      const unsigned v0 = vb[0];
+#pragma unroll
+      for (int c = 0; c + 1 < NC; ++c) vb[c] = vb[c + 1];
+      vb[NC - 1] = v0;
+    }
+  }
+}
+
+template <int Q>
+void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
+  F3Args a = a0;
+  constexpr int R = Shape<Q>::R;
+  constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8;
+  static int capacity = 0;
+  if (capacity == 0) {
+    int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048), dev = 0;  // see te_normals3.hip (resident_blocks)
+    hipDeviceProp_t prop;
+    if (per_cu > 16) per_cu = 16;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    capacity = per_cu * prop.multiProcessorCount;
+  }
+  const int per_row = a.nbx * (batch > 0 ? batch : 1);
+  int strips = capacity / per_row;
+  strips = strips < 1 ? 1 : strips;
+  int sr = (a.cols + strips - 1) / strips;
+  sr = sr < 32 ? 32 : (sr > 512 ? 512 : sr);
+  a.strip_rows = sr;
+  const int nstrips = (a.cols + sr - 1) / sr;
+  hipLaunchKernelGGL((k_fp_slide3<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
+}
+
+}  // namespace
+
+#ifndef TE_F3_SHAPES
+#define TE_F3_SHAPES(X) X(2) X(25) X(81)
+#endif
+
+// The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.
+bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
+                      hipStream_t s) {
+  const Disc& d = p.fp_disc;
+  static const bool off = getenv("TE_NO_F3") != nullptr;
+  if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
+    return false;
+  if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
+  F3Args a;
+  a.trav = L.trav;
+  a.untrav = L.untrav;
+  a.footprint = L.footprint;
+  a.rows = g.rows;
+  a.cols = g.cols;
+  a.map_cells = (long long)g.rows * g.cols;
+  a.nbx = (g.rows + kLanes - 1) / kLanes;
+  a.strip_rows = 0;
+  a.n_spiral = p.n_spiral;
+  a.table = spiral_table;
+  a.gtab = clip_table;
+  a.rmin = p.rmin;
+  a.rmax = p.rmax;
+  a.def = p.def;
+  a.res = g.res;
+  switch (d.Q) {
+#define X(q)                          \
+  case q:                             \
+    launch_f3<q>(a, g.batch, s);      \
+    return true;
+    TE_F3_SHAPES(X)
+#undef X
+    default:
+      return false;
+  }
+}
+
+}  // namespace fast
+}  // namespace te

@@ -165,6 +165,9 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
 bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags,
                    FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
+// te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)
+bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
+                      hipStream_t s);
 void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast
 

@@ -44,8 +44,8 @@ namespace fast {
 namespace {
 
 constexpr int kN3Waves = 3;  // waves per SIMD the kernel is compiled for
-#ifndef TE_N3_DIAG
-#define TE_N3_DIAG 0  // measurement builds only: 1 = no tail, 2 = ring reads but no moment arithmetic, 3 = arithmetic on constants, no ring reads
+#ifndef TE_N3_ORDER
+#define TE_N3_ORDER 0  // 1: the columns are consumed in the reverse order of their reads (one LDS wait per step)
 #endif
 
 struct N3Args {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
   // (signed 64-bit arithmetic: the first rows of a strip at the top of the map lie above the map and are never loaded)
   cgfloat* ldp = (cgfloat*)(em + ((long long)(js - R) * a.rows + i0));  // uniform: column i0 of the next row to load
   auto load_row = [&](int r) __attribute__((always_inline)) {
-    if (r >= 0 && r < a.cols) {
+    if ((GENERAL ? r >= 0 : true) && r < a.cols) {  // (only a GENERAL block starts above the map)
       pm = ldp[lmain];
       ph = ldp[lhalo];
     }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
   // converts the prefetched row r and writes it to ring slot (chunk base vbase, row offset ro); rows and halo columns
   // outside the map hold zeros like invalid cells, but do not make a row "dirty": their discs are clipped, not broken
   auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
-    const bool rin = r >= 0 && r < a.cols;
+    const bool rin = GENERAL ? (r >= 0 && r < a.cols) : true;  // (below the map: stale finite values, never part of an output)
     const bool okm = __builtin_isfinite(pm), okh = __builtin_isfinite(ph);
     const float tm = (okm && rin) ? pm : zref32, th = (okh && halo_in && rin) ? ph : zref32;  // contributes dz = 0
     const double dm = (double)tm - zref, dh = (double)th - zref;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
       const float nz_b = __builtin_amdgcn_sqrtf(om);
       fz = om > 0.99609375f ? nz_a : nz_b;                // m < 2^-8
       // degenerate: t <= 0 / not finite, t cancelled (delta < 0 and almost no tilt), q outside float32
-      bad = !(t > 1e-6 * s) || !(qf < 3.0e38f) || !(qf > 1.0e-37f);
+      bad = !(t > 1e-6 * s) || !__builtin_isnormal(qf);
       // roughness^2 (N-1)/N = smallest eigenvalue = (cxx + cd)/2 - s (RoughnessFilter.cpp:105-117)
       const double lam = fma(0.5, D, a.K1h) - s;
       float rq = (float)(lam * a.kinv);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
       }
     }
     // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
-    const float sl = acosf_poly(fz);
+    const float sl = acosf_poly01(fz);
     o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
     if (__builtin_expect(__any(bad), 0)) {
       const float qn = __builtin_nanf("");
@@ -292,32 +292,41 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
     constexpr int u = decltype(uc)::value;
     double sv[R + 1];  // sum of (lead + trail) over the columns of half-height h
     const double Sz0 = Sz;
+    // all ring reads of the step first ...
+    double zl[2 * R + 1], zt[2 * R + 1];  // indexed by column offset e + R
     static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
       constexpr int d = decltype(dc)::value;
       constexpr int h = Shape<Q>::hw(d);
       constexpr int pl = u + R + 1 + h, pt = u + R - h;  // ring positions of the leading row j+1+h and the trailing row j-h
       constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
-      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
       const char* rl = ringb + vb[al];
       const char* rt = ringb + vb[at];
-      // one column: leading and trailing cell
+      zl[R + d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R + d) * 8));
+      zt[R + d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R + d) * 8));
+      if (d != 0) {
+        zl[R - d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R - d) * 8));
+        zt[R - d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R - d) * 8));
+      }
+    });
+    // ... then the moment updates, column by column
+#if TE_N3_ORDER == 1
+    // (last read first: one wait for the whole step instead of one per column pair)
+    static_for<R + 1>([&](auto dcr) __attribute__((always_inline)) {
+      constexpr int d = R - decltype(dcr)::value;
+#else
+    static_for<R + 1>([&](auto dcr) __attribute__((always_inline)) {
+      constexpr int d = decltype(dcr)::value;
+#endif
+      constexpr int h = Shape<Q>::hw(d);
+      // first column of its height group in the order the columns are visited
+#if TE_N3_ORDER == 1
+      constexpr bool first = d == R || Shape<Q>::hw(d < R ? d + 1 : R) != h;
+#else
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+#endif
       auto column = [&](auto ec, bool init) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value - R;  // column offset
-        double zl, zt;
-        if (TE_N3_DIAG == 3) {
-          zl = Sjz;
-          zt = Szz;
-        } else {
-          zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + e) * 8));
-          zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + e) * 8));
-        }
-        if (TE_N3_DIAG == 2) {
-          Sz += zl;
-          Szz += zt;
-          if (init) sv[h] = 0.0;
-          return;
-        }
-        const double uu = zl - zt, vv = zl + zt;
+        const double uu = zl[R + e] - zt[R + e], vv = zl[R + e] + zt[R + e];
         Sz += uu;
         if (e != 0) Siz = fma((double)e, uu, Siz);
         Szz = fma(uu, vv, Szz);
@@ -326,8 +335,13 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
         else
           sv[h] += vv;
       };
+#if TE_N3_ORDER == 1
+      if (d != 0) column(std::integral_constant<int, R - d>{}, first);
+      column(std::integral_constant<int, R + d>{}, first && d == 0);
+#else
       column(std::integral_constant<int, R + d>{}, first);
       if (d != 0) column(std::integral_constant<int, R - d>{}, false);
+#endif
     });
     double acc = Sjz;
     static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
@@ -353,9 +367,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
       }
       const bool out = j >= js;  // (uniform) the warm-up rows have no output
       if (out) {
-        if (TE_N3_DIAG == 1) {
-          o_slope = (float)Sz; o_rough = (float)(Siz + Sjz + Szz);
-        } else if (__builtin_expect(j > dirty_until, 1)) {
+        if (__builtin_expect(j > dirty_until, 1)) {
           if (GENERAL) {
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
             tail_clipped(j, ky);
