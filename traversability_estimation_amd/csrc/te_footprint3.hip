@@ -240,7 +240,11 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
 }  // namespace
 
 #ifndef TE_F3_SHAPES
-#define TE_F3_SHAPES(X) X(2) X(25) X(81)
+// every disc shape up to radius 10 (te_march.h) except the single cell
+#define TE_F3_SHAPES(X) \
+  X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
+  X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
+  X(89) X(90) X(97) X(98) X(100)
 #endif
 
 // The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.
