@@ -86,8 +86,12 @@ typedef float __attribute__((address_space(1))) gfloat;
 // One block: columns [i0, i0 + 64), output rows [js, jend).  GENERAL: every row takes the x/y moments of its (possibly
 // clipped) disc from the table and the general tail -- the blocks of the first / last block column and of the top / bottom
 // frame rows; otherwise every disc of the block lies inside the map and the closed-form tail is used.
-template <int Q, bool KEEP, bool GENERAL>
-__device__ __forceinline__ void march3(const N3Args& a, double* ring, const int i0, const int js, const int jend) {
+// HOLES: the march can also handle discs with invalid cells (below).  Without it the march gives up at the first invalid
+// cell it stages and returns false; the kernel then runs the strip again with HOLES.  A clean strip -- the common case by
+// far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
+// clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
+template <int Q, bool KEEP, bool GENERAL, bool HOLES>
+__device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int i0, const int own_lo, const int js, const int jend) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
   constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R: exactly what one slide reads
@@ -116,7 +120,11 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
   const double zref = (double)zref32;
 
   // ---- ring: zero, then the first real row (js - R) in the newest slot --------------------------------------------
-  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
+  // An invalid cell -- and a cell that is not there: outside the map, above the strip's first disc -- is held as the
+  // smallest denormal: it adds nothing to the z-sums (absorbed by rounding, and 0 when squared) and can be told from every
+  // valid dz, which is a difference of two float32 values (a multiple of 2^-149, or exactly 0).
+  const double kAbsent = __builtin_bit_cast(double, 1ull);
+  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = HOLES ? kAbsent : 0.0;
   // chunk base registers: byte address of the chunk + the lane's own column
   unsigned vb[NC];
 #pragma unroll
@@ -130,9 +138,17 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
   const int lhalo = halo_in ? hcol - R : lane;  // ... of the halo cell (any valid address if there is none)
   // clip of my disc by the left / right map border (0: none; k > 0: columns di < -R+k missing; k < 0: di > R+k missing)
   const int icol = i0 + lane;
+  // The last block of a row of blocks is shifted left to end at the region's edge; the columns it shares with its
+  // neighbour belong to the neighbour (the two blocks use different reference heights, so a borderline decision --
+  // "unresolved, leave it to the fix-up pass" -- can differ between them, and mixed stores would race).
+  const bool own = icol >= own_lo;
   const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
 
-  int dirty_until = js - R - 1;  // outputs j <= dirty_until may see an invalid cell
+  // bit k: row (oldest row of the ring + k) holds an invalid cell of the map inside this block's window ("dirty")
+  unsigned dmask = 0;
+  constexpr unsigned kTopBit = 1u << (NR - 1);
+  constexpr unsigned kDiscMask = (1u << (2 * R + 1)) - 1u;  // the rows j-R .. j+R of the disc of row j
+  bool row_dirty = false;
   float pm, ph;                  // the prefetched row: main cell, halo cell
   typedef const float __attribute__((address_space(1))) cgfloat;
   // (signed 64-bit arithmetic: the first rows of a strip at the top of the map lie above the map and are never loaded)
@@ -145,21 +161,28 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
     ldp += a.rows;
   };
   // converts the prefetched row r and writes it to ring slot (chunk base vbase, row offset ro); rows and halo columns
-  // outside the map hold zeros like invalid cells, but do not make a row "dirty": their discs are clipped, not broken
+  // outside the map are absent like invalid cells, but do not make a row dirty: their discs are clipped, not broken
   auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
     const bool rin = GENERAL ? (r >= 0 && r < a.cols) : true;  // (below the map: stale finite values, never part of an output)
-    const bool okm = __builtin_isfinite(pm), okh = __builtin_isfinite(ph);
-    const float tm = (okm && rin) ? pm : zref32, th = (okh && halo_in && rin) ? ph : zref32;  // contributes dz = 0
-    const double dm = (double)tm - zref, dh = (double)th - zref;
-    *reinterpret_cast<double*>(ringb + vbase + (ro * RB + R * 8)) = dm;
-    *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = dh;
-    if (rin && __any(!(okm && (okh || !halo_in)))) dirty_until = r + R;
+    const bool okm = __builtin_isfinite(pm) && rin, okh = __builtin_isfinite(ph) && halo_in && rin;
+    const float tm = okm ? pm : zref32, th = okh ? ph : zref32;
+    typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+    u32x2 bm = __builtin_bit_cast(u32x2, (double)tm - zref);  // +0.0 where absent ...
+    u32x2 bh = __builtin_bit_cast(u32x2, (double)th - zref);
+    if (HOLES) {
+      bm.x = okm ? bm.x : 1u;                                  // ... turned into the marker (one select on the low word)
+      bh.x = okh ? bh.x : 1u;
+    }
+    *reinterpret_cast<u32x2*>(ringb + vbase + (ro * RB + R * 8)) = bm;
+    *reinterpret_cast<u32x2*>(ringb + (vbase + vhd) + ro * RB) = bh;
+    row_dirty = rin && __any(!__builtin_isfinite(pm) || (!__builtin_isfinite(ph) && halo_in));
   };
   const int jstart = js - (2 * R + 1);  // the march starts with an EMPTY disc: rows above js-R count as zeros
   __syncthreads();
   pm = ph = 0.0f;
   load_row(js - R);
   stage_row(js - R, vb[NC - 1], C - 1);  // row jstart + R + 1 = slot NR - 1
+  dmask = row_dirty ? kTopBit : 0u;
   load_row(js - R + 1);                  // row j + 2 + R of step j = jstart
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
@@ -171,13 +194,22 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
   gfloat* p_nz = KEEP ? (gfloat*)(a.nz + mo + (size_t)js * a.rows + i0) : nullptr;
   const int tile_base = (a.map >= 0 ? 0 : (int)blockIdx.z) * a.ntx * a.nty;
 
-  auto flag_tiles = [&](int j) __attribute__((always_inline)) {
+  // Tiles to hand to the fix-up pass: one bit per 16-row tile row this strip touches, written out after the march (the
+  // index arithmetic of the flag array stays out of the row loop).
+  unsigned long long flag_rows = 0;
+  const int tile_row0 = (js - a.fj0) >> 4;
+  auto flag_tiles = [&](int j) __attribute__((always_inline)) { flag_rows |= 1ull << ((((j - a.fj0) >> 4) - tile_row0) & 63); };
+  auto write_flags = [&]() __attribute__((always_inline)) {
     if (lane == 0) {
-      const int tr = ((j - a.fj0) >> 4) * a.ntx;
       const int tc0 = (i0 - a.fi0) >> 6, tc1 = (i0 + kLanes - 1 - a.fi0) >> 6;  // a shifted block straddles two tiles
-      const int t0 = tile_base + tr + tc0, t1 = tile_base + tr + tc1;
-      a.tile_flags[(t0 % a.fix_groups) * kFixTiles + t0 / a.fix_groups] = 1;
-      a.tile_flags[(t1 % a.fix_groups) * kFixTiles + t1 / a.fix_groups] = 1;
+      while (flag_rows) {
+        const int k = __ffsll((long long)flag_rows) - 1;
+        flag_rows &= flag_rows - 1;
+        const int tr = (tile_row0 + k) * a.ntx;
+        const int t0 = tile_base + tr + tc0, t1 = tile_base + tr + tc1;
+        a.tile_flags[(t0 % a.fix_groups) * kFixTiles + t0 / a.fix_groups] = 1;
+        a.tile_flags[(t1 % a.fix_groups) * kFixTiles + t1 / a.fix_groups] = 1;
+      }
     }
   };
 
@@ -233,7 +265,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
     // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
     const float sl = acosf_poly01(fz);
     o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    if (__builtin_expect(__any(bad), 0)) {
+    if (__builtin_expect(__any(bad && own), 0)) {
       const float qn = __builtin_nanf("");
       o_slope = bad ? qn : o_slope;
       o_rough = bad ? qn : o_rough;
@@ -256,7 +288,7 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
     rq = rq > 0.0f ? rq : 0.0f;
     const float rgh = __builtin_amdgcn_sqrtf(rq);
     o_rough = n > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
-    if (__builtin_expect(__any(unresolved != 0), 0)) {
+    if (__builtin_expect(__any(unresolved != 0 && own), 0)) {
       const float qn = __builtin_nanf("");
       const bool bad = unresolved != 0;
       o_slope = bad ? qn : o_slope;
@@ -267,20 +299,74 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
       flag_tiles(j);
     }
   };
-  auto dirty_row = [&](int j) __attribute__((always_inline)) {
+  // ---- rows whose disc holds invalid cells: x/y moments of the VALID cells, slid like the z-moments -------------------
+  // They are kept only while a dirty row is in the ring ("holes" mode).  On entry they are counted once from the ring
+  // itself (absent cells carry the marker, whatever the reason: invalid, outside the map, above the strip), so no case
+  // analysis of borders and warm-up is needed; a disc without a dirty row never looks at them.
+  int Mn = 0, Mi = 0, Mj = 0, Mii = 0, Mij = 0, Mjj = 0;
+  bool holes = false;
+  auto absent = [&](double v) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned long long, v) == 1ull; };
+  auto count_moments = [&](int u) __attribute__((always_inline)) {
+    // disc of row j: ring rows u .. u+2R counted from the row vb[0] points to
+    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / RB) + u;
+    int n = 0, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
+#pragma unroll 1
+    for (int dj = -R; dj <= R; ++dj) {
+      const int hw = isqrt_c(Q - dj * dj);
+      int sl = slot0 + R + dj;
+      sl = sl >= NR ? sl - NR : sl;
+      sl = sl >= NR ? sl - NR : sl;
+      const double* row = ring + sl * W + lane + R;
+#pragma unroll 1
+      for (int di = -hw; di <= hw; ++di) {
+        const int w = absent(row[di]) ? 0 : 1;
+        n += w;
+        si += w * di;
+        sii += w * di * di;
+        sj += w * dj;
+        sij += w * di * dj;
+        sjj += w * dj * dj;
+      }
+    }
+    Mn = n; Mi = si; Mj = sj; Mii = sii; Mij = sij; Mjj = sjj;
+  };
+  auto tail_holes = [&](int j, auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int pc = u + R;  // ring position of row j
+    const double ctr = *reinterpret_cast<const double*>(ringb + vb[(pc / C) % NC] + ((pc % C) * RB + R * 8));
+    double qs = 0.0;
+    const int unresolved = general_tail3(a.res, Mn, Mi, Mj, Mii, Mij, Mjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+    const float sl = acosf_poly01(fz);
+    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    float rq = (float)(qs * rcp_fast((double)Mn * (double)(Mn - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
     const float qn = __builtin_nanf("");
-    o_slope = o_rough = fx = fy = fz = qn;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
-    flag_tiles(j);
+    const bool nocentre = absent(ctr);  // no normal, slope or roughness where the input layer is invalid
+    const bool bad = unresolved != 0 && !nocentre;
+    if (nocentre || bad) {
+      o_slope = qn;
+      o_rough = qn;
+      fx = qn;
+      fy = qn;
+      fz = qn;
+    }
+    if (__builtin_expect(__any(bad && own), 0)) flag_tiles(j);
   };
   auto store_row = [&]() __attribute__((always_inline)) {
-    p_slope[lane] = o_slope;
-    p_rough[lane] = o_rough;
+    if (own) {
+      p_slope[lane] = o_slope;
+      p_rough[lane] = o_rough;
+    }
     p_slope += a.rows;
     p_rough += a.rows;
     if (KEEP) {
-      p_nx[lane] = fx;
-      p_ny[lane] = fy;
-      p_nz[lane] = fz;
+      if (own) {
+        p_nx[lane] = fx;
+        p_ny[lane] = fy;
+        p_nz[lane] = fz;
+      }
       p_nx += a.rows;
       p_ny += a.rows;
       p_nz += a.rows;
@@ -353,46 +439,169 @@ __device__ __forceinline__ void march3(const N3Args& a, double* ring, const int 
     Sjz = fma(-0.5, Sz0 + Sz, acc);
   };
 
+  // the slide of a step in holes mode: the z-moments as above (absent cells add nothing) and the six x/y moments of the
+  // valid cells.  With w = 1 for a valid cell, column e of half-height h, leading cell wl (row j+1+h), trailing wt (j-h):
+  //   n'  = n  + sum (wl - wt)             i'  = i  + sum e (wl - wt)        ii' = ii + sum e^2 (wl - wt)
+  //   j'  = j  - n  + sum [h wl + (h+1) wt]
+  //   ij' = ij - i  + sum e [h wl + (h+1) wt]
+  //   jj' = jj - 2j + n + sum [h^2 wl - (h+1)^2 wt]          (n, i, j on the right: before the step)
+  auto slide_holes = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    double sv[R + 1];
+    int wl_g[R + 1], wt_g[R + 1], el_g[R + 1], et_g[R + 1];  // per half-height: sum wl, sum wt, sum e wl, sum e wt
+    int q_l = 0, q_t = 0;                                     // sum e^2 wl, sum e^2 wt
+    const double Sz0 = Sz;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr int pl = u + R + 1 + h, pt = u + R - h;
+      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      const char* rl = ringb + vb[al];
+      const char* rt = ringb + vb[at];
+      auto column = [&](auto ec, bool init) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value - R;
+        const double zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + e) * 8));
+        const double zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + e) * 8));
+        const double uu = zl - zt, vv = zl + zt;
+        Sz += uu;
+        if (e != 0) Siz = fma((double)e, uu, Siz);
+        Szz = fma(uu, vv, Szz);
+        const int wl = absent(zl) ? 0 : 1, wt = absent(zt) ? 0 : 1;
+        if (init) {
+          sv[h] = vv;
+          wl_g[h] = wl;
+          wt_g[h] = wt;
+          el_g[h] = e * wl;
+          et_g[h] = e * wt;
+        } else {
+          sv[h] += vv;
+          wl_g[h] += wl;
+          wt_g[h] += wt;
+          el_g[h] += e * wl;
+          et_g[h] += e * wt;
+        }
+        q_l += e * e * wl;
+        q_t += e * e * wt;
+      };
+      column(std::integral_constant<int, R + d>{}, first);
+      if (d != 0) column(std::integral_constant<int, R - d>{}, false);
+    });
+    double acc = Sjz;
+    int dn = 0, di = 0, dj = 0, dij = 0, djj = 0;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      if (first) {
+        acc = fma((double)h + 0.5, sv[h], acc);
+        dn += wl_g[h] - wt_g[h];
+        di += el_g[h] - et_g[h];
+        dj += h * wl_g[h] + (h + 1) * wt_g[h];
+        dij += h * el_g[h] + (h + 1) * et_g[h];
+        djj += h * h * wl_g[h] - (h + 1) * (h + 1) * wt_g[h];
+      }
+    });
+    Sjz = fma(-0.5, Sz0 + Sz, acc);
+    Mjj += djj - 2 * Mj + Mn;
+    Mij += dij - Mi;
+    Mj += dj - Mn;
+    Mn += dn;
+    Mi += di;
+    Mii += q_l - q_t;
+  };
+
   // ---- the march ---------------------------------------------------------------------------------------------------
   int j = jstart;
-#pragma unroll 1
-  while (true) {
-    bool finished = false;
-    static_for<C>([&](auto uc) __attribute__((always_inline)) {
-      constexpr int u = decltype(uc)::value;
-      if (finished) return;
-      if (__builtin_expect(j >= jend, 0)) {
-        finished = true;
-        return;
-      }
-      const bool out = j >= js;  // (uniform) the warm-up rows have no output
-      if (out) {
-        if (__builtin_expect(j > dirty_until, 1)) {
-          if (GENERAL) {
-            const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
-            tail_clipped(j, ky);
-          } else {
-            tail(j);
-          }
-        } else {
-          dirty_row(j);
-        }
-      }
-      slide(uc);
-      // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
-      stage_row(j + 2 + R, vb[0], u);
-      load_row(j + 3 + R);
-      if (out) store_row();
-      ++j;
-    });
-    if (finished) break;
+  auto rotate = [&]() __attribute__((always_inline)) {
     if (NC > 1) {  // the chunk that held the oldest rows now holds the newest
       const unsigned v0 = vb[0];
 #pragma unroll
       for (int c = 0; c + 1 < NC; ++c) vb[c] = vb[c + 1];
       vb[NC - 1] = v0;
     }
+  };
+  if constexpr (!HOLES) {
+    if (__builtin_expect(dmask != 0, 0)) return false;
+    bool aborted = false;
+#pragma unroll 1
+    while (true) {
+      bool leave = false;
+      static_for<C>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (leave) return;
+        if (__builtin_expect(j >= jend, 0)) {
+          leave = true;
+          return;
+        }
+        const bool out = j >= js;  // (uniform) the warm-up rows have no output
+        if (out) {
+          if (GENERAL) {
+            const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+            tail_clipped(j, ky);
+          } else {
+            tail(j);
+          }
+        }
+        slide(uc);
+        // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
+        stage_row(j + 2 + R, vb[0], u);
+        load_row(j + 3 + R);
+        if (out) store_row();
+        ++j;
+        if (__builtin_expect(row_dirty && j < jend, 0)) {  // an invalid cell: this strip needs the other march
+          aborted = true;
+          leave = true;
+        }
+      });
+      if (leave) break;
+      rotate();
+    }
+    if (aborted) return false;
+  } else {
+    bool done = false;
+#pragma unroll 1
+    while (!done) {
+      static_for<C>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        if (done) return;
+        if (__builtin_expect(j >= jend, 0)) {
+          done = true;
+          return;
+        }
+        const bool out = j >= js;
+        if (dmask != 0 && !holes) {  // a dirty row has entered the ring (it leads in this step's slide)
+          count_moments(u);
+          holes = true;
+        }
+        if (out) {
+          if ((dmask & kDiscMask) == 0) {
+            if (GENERAL) {
+              const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+              tail_clipped(j, ky);
+            } else {
+              tail(j);
+            }
+          } else {
+            tail_holes(j, uc);
+          }
+        }
+        if (holes)
+          slide_holes(uc);
+        else
+          slide(uc);
+        stage_row(j + 2 + R, vb[0], u);
+        dmask = (dmask >> 1) | (row_dirty ? kTopBit : 0u);
+        holes = holes && dmask != 0;  // the last dirty row has left the ring: the table / closed form serves again
+        load_row(j + 3 + R);
+        if (out) store_row();
+        ++j;
+      });
+      if (!done) rotate();
+    }
   }
+  if (__builtin_expect(flag_rows != 0, 0)) write_flags();
+  return true;
 }
 
 template <int Q, bool KEEP>
@@ -421,13 +630,18 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
     js = bottom ? a.jf_hi : a.j_lo;
     jend = bottom ? a.j_hi : a.jf_lo;
   }
-  int i0 = a.i_lo + bx * kLanes;
-  i0 = i0 + kLanes > a.i_hi ? a.i_hi - kLanes : i0;  // the last block ends at the edge
+  const int own_lo = a.i_lo + bx * kLanes;
+  const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
   if (js >= jend) return;
-  if (general)
-    march3<Q, KEEP, true>(a, ring, i0, js, jend);
-  else
-    march3<Q, KEEP, false>(a, ring, i0, js, jend);
+  const bool clean = general ? march3<Q, KEEP, true, false>(a, ring, i0, own_lo, js, jend)
+                             : march3<Q, KEEP, false, false>(a, ring, i0, own_lo, js, jend);
+  if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
+    __syncthreads();
+    if (general)
+      march3<Q, KEEP, true, true>(a, ring, i0, own_lo, js, jend);
+    else
+      march3<Q, KEEP, false, true>(a, ring, i0, own_lo, js, jend);
+  }
 }
 
 // Resident single-wave blocks per CU and CUs of the current device.  The LDS allocation granularity decides: at R = 9
