@@ -12,8 +12,10 @@ once over RCCL before the timed region.
 
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the whole chain launch
 sequence: algorithmic bytes (20 B/cell chain, 24 B/cell with the footprint pass) divided
-by the chain's average duration measured with HIP events on the stream the kernels run on;
-`roofline.dominant_kernel` is the normals/slope/roughness kernel timed alone the same way (12 B/cell).
+by the chain's duration measured with HIP events on the stream the kernels run on (median of >= 100
+launches, one event pair per launch); `roofline.dominant_kernel` is the normals/slope/roughness pass timed
+alone the same way (12 B/cell); `roofline_issue` prices the same launch against the double-precision
+issue rate, which is what bounds these kernels.
 `cpu_baseline` times the CPU oracle (our restatement of the reference; kind "port") on one host thread
 over a bounded crop of the same map.
 """
@@ -29,6 +31,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+FP64_LANE_OPS_PEAK = 39.3e12  # 78.6 TFLOP/s vector fp64 = 39.3e12 fused multiply-adds (lane operations) per second
+# double-precision lane operations per cell of one launch: the sliding moments of k_normals3 (6 per disc
+# column and edge + 1 per distinct run length: 118 at R = 9, scaled with 2R+1 for other radii), its tail (31), the
+# footprint's sliding sum (3 per column) and mean
+def fp64_lane_ops_per_cell(radius_cells, with_footprint):
+    cols = 2 * int(radius_cells) + 1
+    return 6.2 * cols + 31 + ((3 * cols + 5) if with_footprint else 0)
+
+
+def kernel_sources_sha16():
+    """Identifies the kernels a committed counter profile belongs to (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "traversability_estimation_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -154,10 +175,13 @@ def main():
     dt = time.perf_counter() - t0
     dt = tdist.max_over_ranks(dt)
 
-    # kernel-only duration of the chain: HIP events on the context's own stream
-    ms_chain = ctx.time_chain(flags, warmup=1, iters=max(5, min(args.steps, 50)))
-    # the dominant kernel alone (normals/slope/roughness + its fix-up pass), the same way
-    ms_normals = ctx.time_chain(capi.RUN_NORMALS_ONLY, warmup=1, iters=max(5, min(args.steps, 50)))
+    # kernel-only duration of the chain: HIP events on the context's own stream, one pair per launch, median of >= 100
+    n_samples = max(100, args.steps)
+    chain_samples = ctx.time_chain_samples(flags, warmup=20, iters=n_samples)
+    ms_chain = float(np.median(chain_samples))
+    # the dominant kernel alone (normals/slope/roughness + its fix-up pass: TE_RUN_NORMALS_ONLY), the same way
+    normals_samples = ctx.time_chain_samples(capi.RUN_NORMALS_ONLY, warmup=5, iters=n_samples)
+    ms_normals = float(np.median(normals_samples))
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
@@ -245,7 +269,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 moments and eigen-solve, f32 acos and score tail (step filter and combine: f32 compare/add, exact)",
             "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)" + (f", holes {args.holes}" if args.holes else ""),
             "config": {"workload": f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
                                    f" (normals/roughness/step), slope+roughness+step+normals+combine"
@@ -255,19 +279,33 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "chain launch sequence (all kernels of one te_run_chain)",
-                         "ms_per_launch": ms_chain, "algorithmic_bytes_per_cell": bytes_per_cell,
-                         "dominant_kernel": {"name": "k_normals_slide (+ k_normals_fixup), alone on the GPU",
+                         "ms_per_launch": ms_chain, "ms_per_launch_stat": f"median of {n_samples} launches, one HIP event pair each "
+                                                                          f"(p10 {np.percentile(chain_samples, 10):.4f}, p90 {np.percentile(chain_samples, 90):.4f})",
+                         "algorithmic_bytes_per_cell": bytes_per_cell,
+                         "dominant_kernel": {"name": "k_normals3 (+ k_normals_fixup), alone on the GPU (TE_RUN_NORMALS_ONLY; rocprofv3 "
+                                                     "lists the two kernels separately, profiles/)",
                                              "ms": ms_normals, "algorithmic_bytes_per_cell": 12,
                                              "achieved": B * n * n * 12 / (ms_normals * 1e-3) / 1e9,
                                              "frac": B * n * n * 12 / (ms_normals * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        # second roofline: what actually bounds these kernels is instruction issue, most of it double precision
+        ops = fp64_lane_ops_per_cell(args.radius_cells, with_fp) * B * n * n
+        out["roofline_issue"] = {"bound": "valu-f64", "achieved": ops / (ms_chain * 1e-3), "peak": FP64_LANE_OPS_PEAK,
+                                 "unit": "fp64 lane operations/s", "frac": ops / (ms_chain * 1e-3) / FP64_LANE_OPS_PEAK,
+                                 "lane_ops_per_cell": fp64_lane_ops_per_cell(args.radius_cells, with_fp),
+                                 "note": "algorithmic fp64 operations of the sliding moments, the tails and the footprint sum; "
+                                         "strip warm-up, staging and the float32 work are not counted"}
         # HBM traffic of the same launch sequence: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
-        # WRITE_SIZE do not fit one pass), so the number is taken from the committed profile of this exact
-        # workload (profiles/r01_hbm_traffic.json), never measured inside the timed run
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        # WRITE_SIZE do not fit one pass), so the number comes from the committed profile of this exact workload --
+        # and only if that profile was taken with the kernels of this tree (hash of csrc/)
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
-            out["roofline"]["traffic"] = json.load(open(tpath))["traffic_bytes"]
-            out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_hbm_traffic.json)"
+            t = json.load(open(tpath))
+            if t.get("kernel_sources_sha16") == kernel_sources_sha16():
+                out["roofline"]["traffic"] = t["traffic_bytes"]
+                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02_hbm_traffic.json)"
+            else:
+                out["roofline"]["traffic_unit"] = "not reported: profiles/r02_hbm_traffic.json was taken with other kernel sources"
         if host_path is not None:
             out["host_path"] = host_path
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -242,6 +242,9 @@ int te_unpin_host(void* host);
 /* Time `iters` back-to-back te_run_chain(flags) launches with HIP events on the context's stream
  * (after `warmup` untimed ones); inputs and outputs stay resident in HBM. */
 int te_time_chain(te_ctx* ctx, unsigned flags, int warmup, int iters, float* ms_per_iter);
+/* The same, one event pair per launch: ms[k] = device time of the k-th launch (for a median; the launches are not
+ * back to back, every one is waited for). */
+int te_time_chain_samples(te_ctx* ctx, unsigned flags, int warmup, int iters, float* ms);
 
 /* ---- wire formats either side of the chain: grid_map_msgs/GridMap (ROS1 serialisation) and rosbag V2.0 ----
  * The reference node gets its elevation map as such a message (TraversabilityEstimation.cpp:248-270 requestElevationMap ->

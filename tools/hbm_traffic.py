@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 
 
@@ -22,7 +23,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"k_[a-z_]+", r["Kernel_Name"])
+            m = re.search(r"k_[a-z0-9_]+", r["Kernel_Name"])
             if m:
                 acc[m.group(0)].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
@@ -36,14 +37,18 @@ def main():
     fb = sum(v["FETCH_SIZE_bytes"] for v in kernels.values())
     wb = sum(v["WRITE_SIZE_bytes"] for v in kernels.values())
     cells = 4096 * 4096
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     print(json.dumps({
+        "kernel_sources_sha16": bench.kernel_sources_sha16(),
         "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path "
                    "(two separate passes), summarised by tools/hbm_traffic.py",
         "config": "1 x 4096x4096, radius 9 cells, footprint pass",
         "unit": "bytes per te_run_chain launch",
         "kernels": kernels,
         "note": "FETCH_SIZE/WRITE_SIZE are in KB; loads are 4 B/lane (dword), for which the counter matched the byte "
-                "count of a plain read within 15%, so no x2 correction (that applies to 16 B/lane streams) is used",
+                "count of a plain read within 15%, so no x2 correction (that applies to 16 B/lane streams) is used; "
+                "kernel_sources_sha16 ties the numbers to the kernels they were measured with (bench.py checks it)",
         "fetch_bytes": fb, "write_bytes": wb, "traffic_bytes": fb + wb, "algorithmic_bytes": 24 * cells}, indent=1))
 
 

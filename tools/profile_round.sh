@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $ROOT/bench.py"
-PROF_ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-host-path"
+PROF_ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-host-path"  # (bench.py itself adds 2 x 100 event-timed launches)
 
 (cd $ROOT && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > $OUT/pytest.log
 timeout 600 $BENCH --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -32,6 +32,7 @@ if [ -z "$QUICK" ]; then
     fi
   done
   python $ROOT/tools/sq_counters.py $OUT/pmc > $OUT/sq_counters.json 2> $OUT/sq_counters.err
+  python $ROOT/tools/hbm_traffic.py $OUT/pmc/p4 $OUT/pmc/p5 > $OUT/hbm_traffic.json 2>> $OUT/sq_counters.err
   [ -n "$PMC_ALSO_OLD" ] && python $ROOT/tools/sq_counters.py $OUT/pmc_no_n3 > $OUT/sq_counters_no_n3.json 2>> $OUT/sq_counters.err
 fi
 # keep what is merged back small: drop the raw per-dispatch traces, keep the statistics

@@ -32,7 +32,7 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
            "te_device_ptr", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
-           "te_download_layer", "te_time_chain", "te_last_error", "te_version",
+           "te_download_layer", "te_time_chain", "te_time_chain_samples", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
            "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
            "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host", "te_path_polygons"]
@@ -126,6 +126,7 @@ def load():
         L.te_sync.argtypes = [vp]
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.te_time_chain_samples.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
         szp, cpp = C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)
         L.te_msg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TeMsgInfo)]
         L.te_msg_layer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, szp]
@@ -467,3 +468,9 @@ class Context:
         ms = C.c_float()
         _check(load().te_time_chain(self._h, int(flags), int(warmup), int(iters), C.byref(ms)))
         return ms.value
+
+    def time_chain_samples(self, flags=0, warmup=3, iters=100):
+        """Device time of each of `iters` launches (HIP events on the context's stream), in ms."""
+        ms = (C.c_float * int(iters))()
+        _check(load().te_time_chain_samples(self._h, int(flags), int(warmup), int(iters), ms))
+        return np.array(ms[:], dtype=np.float64)

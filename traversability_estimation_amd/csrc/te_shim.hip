@@ -1223,4 +1223,23 @@ int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_pe
   return TE_OK;
 }
 
+int te_time_chain_samples(te_ctx* c, unsigned flags, int warmup, int iters, float* ms) {
+  if (!c || !ms || iters <= 0 || warmup < 0) return fail(TE_ERR_INVALID_ARG, "te_time_chain_samples: bad argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_time_chain_samples: geometry not set");
+  for (int k = 0; k < warmup; ++k) {
+    int rc = run_whole_locked(c, flags);
+    if (rc) return rc;
+  }
+  for (int k = 0; k < iters; ++k) {
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int rc = run_whole_locked(c, flags);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms[k], c->ev0, c->ev1));
+  }
+  return TE_OK;
+}
+
 }  // extern "C"
