@@ -7,6 +7,7 @@
 #ifndef TRAVGPU_PLUGINS_DEVICEMAP_HPP
 #define TRAVGPU_PLUGINS_DEVICEMAP_HPP
 
+#include <cstdint>
 #include <mutex>
 #include <string>
 
@@ -24,7 +25,14 @@ class DeviceMap {
   bool prepare(const grid_map::GridMap& map);                       // (re)sets the geometry if it changed, notes the start index
   bool params(te_params& p);                                        // current parameter set (to edit and pass back)
   bool setParams(const te_params& p);
+  // Uploads a layer unless the device already holds exactly this one: the reference's chain hands every plugin a deep
+  // copy of the whole map (SlopeFilter.cpp:62, StepFilter.cpp:105, RoughnessFilter.cpp:76), so StepFilter and
+  // RoughnessFilter both arrive with the same `elevation`, SlopeFilter and RoughnessFilter with the same
+  // `surface_normal_z`.  A device layer is identified by the map's time stamp, geometry and start index plus a hash of
+  // the buffer (sampled; TRAVGPU_PLUGIN_HASH=full hashes every cell, TRAVGPU_PLUGIN_CACHE=0 always uploads).
   bool upload(const grid_map::GridMap& map, const std::string& layer, int te_layer);
+  unsigned long uploads() const { return uploads_; }               // transfers actually made / avoided (tests, logging)
+  unsigned long uploadsSkipped() const { return uploads_skipped_; }
   bool runFilter(int filter);
   bool runChain(unsigned flags);
   bool download(grid_map::GridMap& map, const std::string& layer, int te_layer);
@@ -39,6 +47,16 @@ class DeviceMap {
   int rows_, cols_;
   int start_row_, start_col_;  // GridMap::getStartIndex() of the map last passed to prepare()
   double res_, px_, py_;
+  struct LayerKey {
+    bool valid;
+    uint64_t stamp, hash;
+    size_t n;
+    int start_row, start_col;
+  };
+  static const int kLayers = 16;
+  LayerKey resident_[kLayers];  // what each device layer holds, as far as the plugins put it there
+  void forget();                // after a geometry change or a launch that overwrites input layers
+  unsigned long uploads_, uploads_skipped_;
   std::string error_;
 };
 

@@ -1,5 +1,8 @@
 #include "travgpu_plugins/DeviceMap.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace travgpu_plugins {
 
 DeviceMap& DeviceMap::instance() {
@@ -7,7 +10,34 @@ DeviceMap& DeviceMap::instance() {
   return d;
 }
 
-DeviceMap::DeviceMap() : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0) {}
+DeviceMap::DeviceMap()
+    : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0), uploads_(0), uploads_skipped_(0) {
+  forget();
+}
+
+void DeviceMap::forget() {
+  for (int k = 0; k < kLayers; ++k) resident_[k].valid = false;
+}
+
+namespace {
+// FNV-1a over the bit patterns: all cells, or ~4096 evenly spaced ones plus the ends (a new elevation map differs
+// almost everywhere; together with the time stamp this identifies a buffer without reading 64 MB per plugin call)
+uint64_t hash_layer(const float* d, size_t n, bool full) {
+  uint64_t h = 1469598103934665603ull;
+  const size_t step = full || n <= 8192 ? 1 : n / 4096;
+  for (size_t k = 0; k < n; k += step) {
+    uint32_t w;
+    memcpy(&w, d + k, 4);
+    h = (h ^ w) * 1099511628211ull;
+  }
+  if (n) {
+    uint32_t w;
+    memcpy(&w, d + (n - 1), 4);
+    h = (h ^ w) * 1099511628211ull;
+  }
+  return h ^ (uint64_t)n;
+}
+}  // namespace
 
 DeviceMap::~DeviceMap() {
   if (ctx_) te_destroy(ctx_);
@@ -29,6 +59,7 @@ bool DeviceMap::prepare(const grid_map::GridMap& map) {
   if (rows != rows_ || cols != cols_ || res != res_ || px != px_ || py != py_) {
     if (!check(te_set_geometry(ctx_, rows, cols, 1, res, px, py))) return false;
     rows_ = rows; cols_ = cols; res_ = res; px_ = px; py_ = py;
+    forget();
   }
   return true;
 }
@@ -48,12 +79,35 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
     error_ = "input layer '" + layer + "' is missing";
     return false;
   }
-  if (start_row_ || start_col_) return check(te_upload_layer_circular(ctx_, te_layer, map.get(layer).data(), 0, start_row_, start_col_));
-  return check(te_upload_layer(ctx_, te_layer, map.get(layer).data(), 0, 1));
+  static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
+  static const bool full_hash = getenv("TRAVGPU_PLUGIN_HASH") && !strcmp(getenv("TRAVGPU_PLUGIN_HASH"), "full");
+  const float* data = map.get(layer).data();
+  const size_t n = (size_t)rows_ * cols_;
+  LayerKey key = {true, (uint64_t)map.getTimestamp(), 0, n, start_row_, start_col_};
+  if (cache_on && te_layer >= 0 && te_layer < kLayers) {
+    key.hash = hash_layer(data, n, full_hash);
+    const LayerKey& r = resident_[te_layer];
+    if (r.valid && r.stamp == key.stamp && r.hash == key.hash && r.n == key.n && r.start_row == key.start_row && r.start_col == key.start_col) {
+      ++uploads_skipped_;
+      return true;
+    }
+  }
+  const bool ok = (start_row_ || start_col_) ? check(te_upload_layer_circular(ctx_, te_layer, data, 0, start_row_, start_col_))
+                                             : check(te_upload_layer(ctx_, te_layer, data, 0, 1));
+  if (te_layer >= 0 && te_layer < kLayers) {
+    resident_[te_layer] = key;
+    resident_[te_layer].valid = ok && cache_on;
+  }
+  if (ok) ++uploads_;
+  return ok;
 }
 
 bool DeviceMap::runFilter(int filter) { return check(te_run_filter(ctx_, filter, 0)); }
-bool DeviceMap::runChain(unsigned flags) { return check(te_run_chain(ctx_, flags)); }
+bool DeviceMap::runChain(unsigned flags) {
+  // the fused chain writes the normal layers itself (TE_RUN_KEEP_NORMALS): whatever a plugin uploaded there is gone
+  resident_[TE_LAYER_NORMAL_X].valid = resident_[TE_LAYER_NORMAL_Y].valid = resident_[TE_LAYER_NORMAL_Z].valid = false;
+  return check(te_run_chain(ctx_, flags));
+}
 
 bool DeviceMap::download(grid_map::GridMap& map, const std::string& layer, int te_layer) {
   if (start_row_ || start_col_) return check(te_download_layer_circular(ctx_, te_layer, map.get(layer).data(), 0, start_row_, start_col_));

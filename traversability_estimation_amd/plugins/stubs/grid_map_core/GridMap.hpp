@@ -1,6 +1,7 @@
 // stand-in for grid_map_core's GridMap: float32 column-major layers + geometry, only what the adapters use
 #pragma once
 #include <cmath>
+#include <cstdint>
 #include <limits>
 #include <map>
 #include <stdexcept>
@@ -39,7 +40,9 @@ class Matrix {  // Eigen::MatrixXf look-alike (column-major)
 
 class GridMap {
  public:
-  GridMap() : res_(0) { len_ = {{0, 0}}; pos_ = {{0, 0}}; size_ = {{0, 0}}; start_ = {{0, 0}}; }
+  GridMap() : res_(0), stamp_(0) { len_ = {{0, 0}}; pos_ = {{0, 0}}; size_ = {{0, 0}}; start_ = {{0, 0}}; }
+  void setTimestamp(uint64_t t) { stamp_ = t; }  // grid_map::Time, nanoseconds
+  uint64_t getTimestamp() const { return stamp_; }
   void setGeometry(const Vec2d& length, double resolution, const Vec2d& position) {
     size_.v[0] = (int)std::lround(length(0) / resolution);
     size_.v[1] = (int)std::lround(length(1) / resolution);
@@ -81,6 +84,7 @@ class GridMap {
   Vec2d len_, pos_;
   Arr2i size_, start_;
   double res_;
+  uint64_t stamp_;
 };
 
 }  // namespace grid_map

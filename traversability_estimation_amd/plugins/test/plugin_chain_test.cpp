@@ -16,6 +16,7 @@
 #include <pluginlib/class_list_macros.h>
 
 #include "te_oracle.h"
+#include "travgpu_plugins/DeviceMap.hpp"
 #include "traversability_estimation_gpu/TraversabilityMap.hpp"
 
 typedef filters::FilterBase<grid_map::GridMap> Filter;
@@ -143,9 +144,31 @@ static void test_device() {
   CHECK(r->configure("roughnessFilter", ParamMap{{"critical_value", p.rough_critical}, {"estimation_radius", p.rough_radius},
                                                  {"map_type", "traversability_roughness"}}));
   grid_map::GridMap m1, m2, m3;
+  map0.setTimestamp(1529564943122772932ull);
+  travgpu_plugins::DeviceMap& dev = travgpu_plugins::DeviceMap::instance();
+  const unsigned long up0 = dev.uploads(), sk0 = dev.uploadsSkipped();
   CHECK(s->update(map0, m1));
   CHECK(t->update(m1, m2));
   CHECK(r->update(m2, m3));
+  // every plugin gets a deep copy of the whole map, but a layer crosses PCIe once: surface_normal_z for SlopeFilter,
+  // elevation for StepFilter, surface_normal_x / _y for RoughnessFilter (its elevation and _z are already resident)
+  CHECK(dev.uploads() - up0 == 4);
+  CHECK(dev.uploadsSkipped() - sk0 == 2);
+  {  // the same map again (the node re-filters on a parameter update): nothing is uploaded
+    grid_map::GridMap a, b, c;
+    CHECK(s->update(map0, a) && t->update(a, b) && r->update(b, c));
+    CHECK(dev.uploads() - up0 == 4);
+    CHECK(dev.uploadsSkipped() - sk0 == 8);
+    CHECK(compare("traversability_roughness (resident inputs)", c["traversability_roughness"], ro) == 0);
+    // a new elevation map (new stamp, new content) is uploaded again
+    grid_map::GridMap next = map0;
+    next.setTimestamp(map0.getTimestamp() + 250000000ull);
+    next["elevation"](7, 9) += 0.25f;
+    CHECK(t->update(next, b));
+    CHECK(dev.uploads() - up0 == 5);
+    CHECK(t->update(map0, b));  // and back: the device layer is identified, not assumed
+    CHECK(dev.uploads() - up0 == 6);
+  }
   std::printf("drop-in plugins (Slope -> Step -> Roughness):\n");
   CHECK(compare("traversability_slope", m3["traversability_slope"], sl) == 0);
   CHECK(compare("traversability_step", m3["traversability_step"], st) == 0);
