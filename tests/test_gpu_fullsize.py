@@ -78,6 +78,32 @@ def test_full_map_fast_vs_generic_and_oracle_crops(capi, oracle, n, cells, seed)
             b = want[k].reshape(m, m)[lo_j:hi_j, lo_i:hi_i]
             n_bad, mx, _ = compare_layer(k, a, b)
             assert n_bad == 0, (k, (j0, i0), n_bad, mx)
+    if n < 4096:
+        return
+    # the HBM-roofline map against the oracle on whole bands (full width / full height: every block column, every
+    # strip boundary of the marching kernels is crossed), oracle on the host cores with OpenMP: 10 bands of 96 rows
+    # or columns, 3.9 M of the 16.8 M cells
+    import os
+    band = 96
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    try:
+        for axis, starts in ((0, (0, 500, 1300, 2100, 3000, n - band)), (1, (0, 960, 2040, n - band))):
+            for s0 in starts:
+                sl = (slice(s0, s0 + band), slice(0, n)) if axis == 0 else (slice(0, n), slice(s0, s0 + band))
+                crop = np.ascontiguousarray(elev[sl])
+                g = oracle.geom(crop.shape[1], crop.shape[0], res)  # rows = extent along i (the fast axis)
+                want = oracle.chain(g, op, crop)
+                want["traversability_footprint"] = oracle.footprint(g, op, crop, want)
+                lo = 0 if s0 == 0 else margin
+                hi = band if s0 + band == n else band - margin
+                keep = (slice(lo, hi), slice(0, n)) if axis == 0 else (slice(0, n), slice(lo, hi))
+                for k in ALL:
+                    a = img(fast[k])[sl][keep]
+                    b = want[k].reshape(crop.shape)[keep]
+                    n_bad, mx, _ = compare_layer(k, a, b)
+                    assert n_bad == 0, (k, "band", axis, s0, n_bad, mx)
+    finally:
+        oracle.set_threads(1)
 
 
 def test_batch_of_512_maps_shape(capi, oracle):
