@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--holes", type=float, default=0.0, help="fraction of invalid (NaN) cells: speckle if < 0.5, else "
                     "solid unobserved regions covering about (value - 0.5) of the map (not the BASELINE workload)")
     ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
+    ap.add_argument("--config", choices=("cfg3", "cfg4"), default="cfg3",
+                    help="cfg3 (default): BASELINE.json configs[2], one 4096^2 map per GPU, radius 9, footprint pass (weak scaling). "
+                         "cfg4: configs[3], a batch of 512 maps of 512^2, radius 5, cut into contiguous blocks over the ranks "
+                         "(dist.shard_range; strong scaling, params broadcast over RCCL)")
     ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
     return ap.parse_args()
 
@@ -134,6 +138,11 @@ def main():
     # filter parameters: rank 0 decides, every other rank receives the te_params blob over RCCL
     p = tdist.broadcast_params(capi, make_params(capi, synth, args), src=0)
 
+    total_maps = None
+    if args.config == "cfg4":
+        args.size, args.radius_cells, total_maps = 512, 5.0, 512
+        a, b = tdist.shard_range(total_maps, rank, world)
+        args.maps_per_gpu = b - a
     with_fp = not args.no_footprint
     flags = capi.RUN_FOOTPRINT if with_fp else 0
     if args.sequential:
@@ -141,7 +150,13 @@ def main():
     n = args.size
     B = args.maps_per_gpu
     # shard of the batch owned by this rank: maps rank*B .. rank*B+B-1 (seed = 1235 + global map index)
-    elevs = [synth.perlin_elevation(n, n, seed=1235 + rank * B + b) for b in range(B)]
+    if total_maps is None:
+        elevs = [synth.perlin_elevation(n, n, seed=1235 + rank * B + b) for b in range(B)]
+    else:  # cfg4: one base map + N(0, 1 cm) perturbations, seed = global map index (the MPC-rollout shape)
+        base = synth.perlin_elevation(n, n, seed=2000)
+        first = tdist.shard_range(total_maps, rank, world)[0]
+        elevs = [(base + np.random.default_rng(2000 + first + b).normal(0.0, 0.01, size=base.shape).astype(np.float32)).astype(np.float32)
+                 for b in range(B)]
     if args.holes > 0.0:
         rng = np.random.default_rng(99)
         for b in range(B):
@@ -185,7 +200,7 @@ def main():
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
-    if rank == 0 and world == 1 and not args.no_host_path:  # N = 1 only: at N > 1 the other ranks would wait for it
+    if rank == 0 and world == 1 and not args.no_host_path and total_maps is None:  # N = 1 only: at N > 1 the other ranks would wait for it
         stack = np.stack(elevs)
         names = ["traversability_slope", "traversability_step", "traversability_roughness", "traversability"]
         if with_fp:
@@ -283,7 +298,7 @@ def main():
             check = {k: compare_layer(k, c2.download(k), want[k])[:2] for k in names}
 
     if rank == 0:
-        cells_per_step = world * B * n * n
+        cells_per_step = (total_maps if total_maps is not None else world * B) * n * n
         bytes_per_cell = 24 if with_fp else 20
         achieved = B * n * n * bytes_per_cell / (ms_chain * 1e-3) / 1e9
         out = {
@@ -295,11 +310,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if total_maps is not None else "weak",
             "vs_baseline": None,
             "dtype": "f64 moments and eigen-solve, f32 acos and score tail (step filter and combine: f32 compare/add, exact)",
             "data": "synthetic (gradient noise, 5 octaves, seed 1235+map)" + (f", holes {args.holes}" if args.holes else ""),
-            "config": {"workload": f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
+            "config": {"workload": (f"batch of {total_maps} maps cut over {world} rank(s), " if total_maps is not None else "") +
+                                   f"{B} x {n}x{n} elevation map per GPU, res {args.res} m, radius {args.radius_cells:g} cells"
                                    f" (normals/roughness/step), slope+roughness+step+normals+combine"
                                    f"{' + traversability_footprint pass' if with_fp else ''}",
                        "maps_per_gpu": B, "map_cells": n * n, "radius_cells": args.radius_cells,

@@ -239,6 +239,25 @@ int te_download_layer(te_ctx* ctx, int layer, float* host, int map0, int nmaps);
 int te_pin_host(void* host, size_t bytes);
 int te_unpin_host(void* host);
 
+/* ---- several GPUs from one process -------------------------------------------------------------
+ * The path shards on the batch axis only: maps are independent, there is no data-path collective.  A host that owns
+ * all GPUs of a node (the reference's node is one process) creates one context per device, gives every context its
+ * block of the batch, and drives them from one thread -- every entry point above is asynchronous on its context's own
+ * stream, so the devices run side by side.
+ *   te_shard_range      contiguous block [first, first + count) of `batch` maps owned by shard k of n (sizes differ by
+ *                       at most one map; the same split as traversability_estimation_amd/dist.py)
+ *   te_bcast_params     every context receives the parameters of ctxs[root].  Contexts on different devices get the
+ *                       te_params block through an RCCL broadcast over xGMI (librccl is loaded when first needed;
+ *                       communicators are created per call: this is configure-time, TraversabilityMap.cpp:764-772);
+ *                       contexts sharing the root's device are copied on the host.  TE_ERR_UNSUPPORTED if several
+ *                       devices are involved and librccl cannot be loaded.
+ *   te_run_chain_multi  te_run_chain(flags) on every context, in order, without waiting
+ *   te_sync_multi       te_sync on every context */
+int te_shard_range(int batch, int n_shards, int k, int* first, int* count);
+int te_bcast_params(te_ctx** ctxs, int n, int root);
+int te_run_chain_multi(te_ctx** ctxs, int n, unsigned flags);
+int te_sync_multi(te_ctx** ctxs, int n);
+
 /* Time `iters` back-to-back te_run_chain(flags) launches with HIP events on the context's stream
  * (after `warmup` untimed ones); inputs and outputs stay resident in HBM. */
 int te_time_chain(te_ctx* ctx, unsigned flags, int warmup, int iters, float* ms_per_iter);

@@ -83,3 +83,22 @@ def test_header_is_plain_c(tmp_path):
         if shutil.which(cc) is None:
             pytest.skip(f"{cc} not installed")
         subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only"] + extra + [str(src)])
+
+
+def test_shard_range_matches_the_python_split(capi):
+    """te_shard_range (what a C++ host uses) and dist.shard_range (what bench.py uses) cut the batch the same way."""
+    from traversability_estimation_amd import dist
+    for n in (0, 1, 5, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            for k in range(world):
+                first, count = capi.shard_range(n, world, k)
+                assert (first, first + count) == dist.shard_range(n, k, world)
+    import ctypes as C
+    import pytest
+    with pytest.raises(capi.TeError):
+        capi.shard_range(8, 0, 0)
+    with pytest.raises(capi.TeError):
+        capi.shard_range(8, 2, 2)
+    L = capi.load()
+    assert L.te_bcast_params(None, 2, 0) != 0 and L.te_run_chain_multi(None, 1, 0) != 0 and L.te_sync_multi(None, 1) != 0
+    assert L.te_shard_range(4, 2, 0, None, None) != 0

@@ -1,0 +1,114 @@
+"""The batch axis across several contexts / ranks through libtravgpu (on a one-GPU box they share device 0): the C-ABI's
+single-process entry points (te_bcast_params, te_run_chain_multi, te_sync_multi, te_shard_range) and two gloo ranks
+driving their shards; both must reproduce the single-context result map by map."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+from tests.helpers import OUT_LAYERS, compare_layer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1
+    return capi
+
+
+def _params(capi):
+    return capi.default_params(normals_radius=0.21, rough_radius=0.21, step_radius1=0.16, step_radius2=0.11, step_ncrit=3,
+                               slope_critical=0.8, fp_radius=0.2, fp_offset=0.1)
+
+
+def test_single_process_contexts_share_a_batch(capi):
+    from traversability_estimation_amd import synth
+    rows, cols, res, B, n_ctx = 160, 128, 0.05, 7, 3
+    elevs = np.stack([synth.perlin_elevation(rows, cols, seed=2000 + b) for b in range(B)])
+    per = rows * cols
+    with capi.Context(0) as one:
+        one.set_params(_params(capi))
+        one.set_geometry(rows, cols, B, res)
+        one.upload_elevation(elevs)
+        one.run_chain(capi.RUN_FOOTPRINT)
+        one.sync()
+        want = {k: one.download(k) for k in OUT_LAYERS + ("traversability_footprint",)}
+    n_dev = capi.device_count()
+    ctxs = [capi.Context(k % n_dev) for k in range(n_ctx)]
+    try:
+        ctxs[1].set_params(_params(capi))  # the root decides; the others start from the defaults
+        capi.bcast_params(ctxs, root=1)
+        for c in ctxs:
+            assert capi.params_to_bytes(c.get_params()) == capi.params_to_bytes(ctxs[1].get_params())
+        spans = [capi.shard_range(B, n_ctx, k) for k in range(n_ctx)]
+        assert sum(n for _, n in spans) == B
+        for c, (first, count) in zip(ctxs, spans):
+            c.set_geometry(rows, cols, count, res)
+            c.upload_elevation(elevs[first:first + count])
+        capi.run_chain_multi(ctxs, capi.RUN_FOOTPRINT)
+        capi.sync_multi(ctxs)
+        for c, (first, count) in zip(ctxs, spans):
+            for k in want:
+                # (a shard is cut into other strips than the whole batch, so the sliding sums are rounded differently:
+                # the same tolerance as against the oracle, not bit equality)
+                n_bad, mx, _ = compare_layer(k, c.download(k), want[k][first * per:(first + count) * per], tol=2e-6)
+                assert n_bad == 0, (k, first, n_bad, mx)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["TE_ROOT"])
+import torch
+from traversability_estimation_amd import capi, dist, synth
+rank, world, local_rank = dist.init_process_group("gloo")
+assert world == 2
+capi.load()
+p = capi.default_params(normals_radius=0.21 if rank == 0 else 0.4, rough_radius=0.21, step_radius1=0.16, step_radius2=0.11,
+                        step_ncrit=3 if rank == 0 else 7)
+p = dist.broadcast_params(capi, p, src=0)
+rows, cols, res, n_maps = 160, 128, 0.05, 5
+a, b = dist.shard_range(n_maps, rank, world)
+with capi.Context(local_rank % max(1, torch.cuda.device_count())) as ctx:
+    ctx.set_params(p)
+    ctx.set_geometry(rows, cols, b - a, res)
+    ctx.upload_elevation(np.stack([synth.perlin_elevation(rows, cols, seed=2000 + m) for m in range(a, b)]))
+    ctx.run_chain(0)
+    ctx.sync()
+    local = ctx.download("traversability").reshape(b - a, rows * cols)
+full = dist.gather_shards(local, n_maps)
+dist.barrier()
+if rank == 0:
+    np.save(os.environ["TE_OUT"], full)
+'''
+
+
+def test_two_gloo_ranks_drive_their_shards_through_libtravgpu(capi, tmp_path):
+    from traversability_estimation_amd import synth
+    out = tmp_path / "full.npy"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, TE_ROOT=ROOT, TE_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    full = np.load(out)
+    rows, cols, res, n_maps = 160, 128, 0.05, 5
+    with capi.Context(0) as one:
+        one.set_params(capi.default_params(normals_radius=0.21, rough_radius=0.21, step_radius1=0.16, step_radius2=0.11, step_ncrit=3))
+        one.set_geometry(rows, cols, n_maps, res)
+        one.upload_elevation(np.stack([synth.perlin_elevation(rows, cols, seed=2000 + m) for m in range(n_maps)]))
+        one.run_chain(0)
+        one.sync()
+        want = one.download("traversability").reshape(n_maps, rows * cols)
+    n_bad, mx, _ = compare_layer("traversability", full, want, tol=2e-6)
+    assert n_bad == 0, (n_bad, mx)

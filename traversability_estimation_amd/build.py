@@ -16,7 +16,7 @@ HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "csrc/te_e
 LIB = os.path.join(_HERE, "libtravgpu.so")
 OBJDIR = os.path.join(_HERE, "_build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
-LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-ldl"]
 # per-source flags.  te_normals3: keep the ring reads as single ds_read_b64 -- a merged ds_read2_b64 halves the LDS rate
 # (MI355X_MICROARCH.md, LDS table) and the kernel sits at 60 % LDS occupancy with them (4 % slower, same-box A/B)
 _SINGLE_DS_READS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]

@@ -35,8 +35,32 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_download_layer", "te_time_chain", "te_time_chain_samples", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
            "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
-           "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host", "te_path_polygons"]
+           "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host", "te_path_polygons",
+           "te_shard_range", "te_bcast_params", "te_run_chain_multi", "te_sync_multi"]
 MSG_MAX_NAME = 64
+
+
+def shard_range(batch, n_shards, k):
+    first, count = C.c_int(), C.c_int()
+    _check(load().te_shard_range(int(batch), int(n_shards), int(k), C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
+def _handles(ctxs):
+    return (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+
+
+def bcast_params(ctxs, root=0):
+    """Every context receives the parameters of ctxs[root] (RCCL across devices, host copy within one)."""
+    _check(load().te_bcast_params(_handles(ctxs), len(ctxs), int(root)))
+
+
+def run_chain_multi(ctxs, flags=0):
+    _check(load().te_run_chain_multi(_handles(ctxs), len(ctxs), int(flags)))
+
+
+def sync_multi(ctxs):
+    _check(load().te_sync_multi(_handles(ctxs), len(ctxs)))
 
 
 def pack_paths(paths):
@@ -127,6 +151,10 @@ def load():
         L.te_download_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_time_chain.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.te_time_chain_samples.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.te_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.te_bcast_params.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.te_run_chain_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_uint]
+        L.te_sync_multi.argtypes = [C.POINTER(vp), C.c_int]
         szp, cpp = C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)
         L.te_msg_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(TeMsgInfo)]
         L.te_msg_layer.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, szp]
