@@ -6,7 +6,7 @@
   cfg5  8192 x 8192 resident map, 256 x 256 dirty tiles per tick  (te_upload_tile + te_run_chain_region)
   N2    batched circular checkFootprintPath, N3 polygon footprint layers
 
-Prints one JSON object; the committed copy is profiles/r01_configs.json.  Needs an MI355X.
+Prints one JSON object; the committed copies are profiles/rNN_configs.json.  Needs an MI355X.
 """
 import json
 import math
@@ -24,6 +24,29 @@ def params(capi, synth, cells, res):
     r = synth.benchmark_radius(cells, res)
     return capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
                                fp_radius=synth.benchmark_radius(6.0, res), fp_offset=synth.benchmark_radius(3.0, res))
+
+
+def run_bag(capi, synth, res, out):
+    # ---- the reference's own map: 100 x 133 at 0.03 m, default YAML (latency of one node update) ---------------------
+    d = np.load(os.path.join(ROOT, "tests", "golden", "bag_map.npz"))
+    rows, cols = int(d["rows"]), int(d["cols"])
+    with capi.Context(0) as c:
+        c.set_params(capi.default_params())
+        c.set_geometry(rows, cols, 1, float(d["resolution"]), tuple(d["position"]))
+        c.upload_elevation(d["elevation"])
+        for flags, name in ((0, "chain"), (capi.RUN_FOOTPRINT, "chain+footprint")):
+            s = c.time_chain_samples(flags, warmup=20, iters=200)
+            out[f"cfg1 bag map {rows}x{cols} default YAML {name}"] = {"ms_per_launch_median": float(np.median(s)), "ms_p90": float(np.percentile(s, 90)),
+                                                                  "cells_per_s": rows * cols / (float(np.median(s)) * 1e-3)}
+        t0 = time.perf_counter()
+        for _ in range(200):
+            c.upload_elevation(d["elevation"])
+            c.run_chain(0)
+            outs = [c.download(k) for k in ("traversability_slope", "traversability_step", "traversability_roughness", "traversability")]
+        c.sync()
+        out[f"cfg1 bag map {rows}x{cols} default YAML host in / host out"] = {"ms_per_update": (time.perf_counter() - t0) / 200 * 1e3,
+                                                                          "what": "upload elevation + chain + download 4 layers, pageable buffers, mean of 200"}
+        del outs
 
 
 def run_cfg2(capi, synth, res, out):
@@ -235,7 +258,7 @@ def main():
     res = 0.05
     out = {}
     only = [k for k in os.environ.get("TE_CONFIGS", "").split(",") if k]  # e.g. TE_CONFIGS=N3,N3P runs those alone
-    for name, fn in (("cfg2", run_cfg2), ("cfg4", run_cfg4), ("cfg5", run_cfg5), ("N2", run_n2), ("N2P", run_n2p), ("N3", run_n3)):
+    for name, fn in (("bag", run_bag), ("cfg2", run_cfg2), ("cfg4", run_cfg4), ("cfg5", run_cfg5), ("N2", run_n2), ("N2P", run_n2p), ("N3", run_n3)):
         if not only or name in only:
             fn(capi, synth, res, out)
     print(json.dumps(out, indent=1))

@@ -26,7 +26,9 @@ if [ -z "$QUICK" ]; then
   i=0
   for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    timeout 600 rocprofv3 --pmc $P -d $OUT/pmc/p$i -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/pmc_p$i.log 2>&1
+    SEQ=--sequential
+    [ $i -ge 4 ] && SEQ=   # the traffic passes measure the default (two-stream, combine in the mask kernel) launch sequence
+    timeout 600 rocprofv3 --pmc $P -d $OUT/pmc/p$i -o p --output-format csv -- $BENCH $PROF_ARGS $SEQ > $OUT/pmc_p$i.log 2>&1
     if [ -n "$PMC_ALSO_OLD" ]; then
       TE_NO_N3=1 timeout 600 rocprofv3 --pmc $P -d $OUT/pmc_no_n3/p$i -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/pmc_no_n3_p$i.log 2>&1
     fi

@@ -79,11 +79,18 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
   const int nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
 
-  float pm = 0.0f, ph = 0.0f;
-  unsigned um = 0, uh = 0;
+  // rows are loaded C steps before they are staged (a queue slot per unrolled position): with one step of lead the
+  // wave waited for memory 38 % of its time (SQ_WAIT_ANY, profiles/r02_sq_counters.json)
+  float pmq[C], phq[C];
+  unsigned umq[C], uhq[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    pmq[k] = phq[k] = 0.0f;
+    umq[k] = uhq[k] = 0;
+  }
   cgfloat* ldt = (cgfloat*)(a.trav + mo + ((long long)(js - R) * a.rows + i0));
   cgbyte* ldu = (cgbyte*)(a.untrav + mo + ((long long)(js - R) * a.rows + i0));
-  auto load_row = [&](int r) __attribute__((always_inline)) {
+  auto load_row = [&](int r, float& pm, float& ph, unsigned& um, unsigned& uh) __attribute__((always_inline)) {
     if (r >= 0 && r < a.cols) {
       pm = ldt[lane];
       ph = ldt[lhalo];
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     ldt += a.rows;
     ldu += a.rows;
   };
-  auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
+  auto stage_row = [&](int r, unsigned vbase, int ro, float pm, float ph, unsigned um, unsigned uh) __attribute__((always_inline)) {
     const bool rin = r >= 0 && r < a.cols;
     const double tm = __builtin_isfinite(pm) ? (double)pm : a.def;  // :719-724
     const double th = __builtin_isfinite(ph) ? (double)ph : a.def;
@@ -103,9 +110,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   };
   const int jstart = js - (2 * R + 1);
   __syncthreads();
-  load_row(js - R);
-  stage_row(js - R, vb[NC - 1], C - 1);
-  load_row(js - R + 1);
+  load_row(js - R, pmq[0], phq[0], umq[0], uhq[0]);
+  stage_row(js - R, vb[NC - 1], C - 1, pmq[0], phq[0], umq[0], uhq[0]);
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_row(js - R + 1 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
 
   double S = 0.0;
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
       const bool emit = j >= js;
       if (emit) tail(j, u);
       slide(uc);
-      stage_row(j + 2 + R, vb[0], u);
-      load_row(j + 3 + R);
+      stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u], umq[u], uhq[u]);
+      load_row(j + 2 + R + C, pmq[u], phq[u], umq[u], uhq[u]);
       if (emit) {
         p_out[lane] = out;
         p_out += a.rows;

@@ -149,11 +149,11 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   constexpr unsigned kTopBit = 1u << (NR - 1);
   constexpr unsigned kDiscMask = (1u << (2 * R + 1)) - 1u;  // the rows j-R .. j+R of the disc of row j
   bool row_dirty = false;
-  float pm, ph;                  // the prefetched row: main cell, halo cell
+  float pmq[C], phq[C];          // prefetched rows (main cell, halo cell), loaded C steps before they are staged
   typedef const float __attribute__((address_space(1))) cgfloat;
   // (signed 64-bit arithmetic: the first rows of a strip at the top of the map lie above the map and are never loaded)
   cgfloat* ldp = (cgfloat*)(em + ((long long)(js - R) * a.rows + i0));  // uniform: column i0 of the next row to load
-  auto load_row = [&](int r) __attribute__((always_inline)) {
+  auto load_row = [&](int r, float& pm, float& ph) __attribute__((always_inline)) {
     if ((GENERAL ? r >= 0 : true) && r < a.cols) {  // (only a GENERAL block starts above the map)
       pm = ldp[lmain];
       ph = ldp[lhalo];
@@ -162,7 +162,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   };
   // converts the prefetched row r and writes it to ring slot (chunk base vbase, row offset ro); rows and halo columns
   // outside the map are absent like invalid cells, but do not make a row dirty: their discs are clipped, not broken
-  auto stage_row = [&](int r, unsigned vbase, int ro) __attribute__((always_inline)) {
+  auto stage_row = [&](int r, unsigned vbase, int ro, float pm, float ph) __attribute__((always_inline)) {
     const bool rin = GENERAL ? (r >= 0 && r < a.cols) : true;  // (below the map: stale finite values, never part of an output)
     const bool okm = __builtin_isfinite(pm) && rin, okh = __builtin_isfinite(ph) && halo_in && rin;
     const float tm = okm ? pm : zref32, th = okh ? ph : zref32;
@@ -179,11 +179,13 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   };
   const int jstart = js - (2 * R + 1);  // the march starts with an EMPTY disc: rows above js-R count as zeros
   __syncthreads();
-  pm = ph = 0.0f;
-  load_row(js - R);
-  stage_row(js - R, vb[NC - 1], C - 1);  // row jstart + R + 1 = slot NR - 1
+#pragma unroll
+  for (int k = 0; k < C; ++k) pmq[k] = phq[k] = 0.0f;
+  load_row(js - R, pmq[0], phq[0]);
+  stage_row(js - R, vb[NC - 1], C - 1, pmq[0], phq[0]);  // row jstart + R + 1 = slot NR - 1
   dmask = row_dirty ? kTopBit : 0u;
-  load_row(js - R + 1);                  // row j + 2 + R of step j = jstart
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_row(js - R + 1 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   // output pointers of this block's first row (uniform base + lane), advanced by one map row per output row
@@ -545,8 +547,8 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
         }
         slide(uc);
         // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
-        stage_row(j + 2 + R, vb[0], u);
-        load_row(j + 3 + R);
+        stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
+        load_row(j + 2 + R + C, pmq[u], phq[u]);
         if (out) store_row();
         ++j;
         if (__builtin_expect(row_dirty && j < jend, 0)) {  // an invalid cell: this strip needs the other march
@@ -590,10 +592,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
           slide_holes(uc);
         else
           slide(uc);
-        stage_row(j + 2 + R, vb[0], u);
+        stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
         dmask = (dmask >> 1) | (row_dirty ? kTopBit : 0u);
         holes = holes && dmask != 0;  // the last dirty row has left the ring: the table / closed form serves again
-        load_row(j + 3 + R);
+        load_row(j + 2 + R + C, pmq[u], phq[u]);
         if (out) store_row();
         ++j;
       });
