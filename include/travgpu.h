@@ -226,7 +226,10 @@ int te_check_polygon_footprint_paths(te_ctx* ctx, int map, int n_paths, const in
  * polygons otherwise -- e.g. to publish them like publishFootprintPolygon (:527, :558).  Path k owns the polygons
  * polygon_first[k] .. polygon_first[k+1]); polygon p has the vertices vertex_xy[2*vertex_offset[p] .. 2*vertex_offset[p+1])
  * and the area area[p] (Polygon::getArea).  *n_polygons / *n_vertices receive the totals; nothing is written beyond
- * cap_polygons polygons / cap_vertices vertices (TE_ERR_INVALID_ARG then: call once with zero capacities to size). */
+ * cap_polygons polygons / cap_vertices vertices (TE_ERR_INVALID_ARG then: call once with zero capacities to size).
+ * Poses and footprint points must be finite (TE_ERR_INVALID_ARG).  The per-path status of the full check is not reported
+ * here: a path without poses owns no polygon (polygon_first[k] == polygon_first[k+1]); a path whose conservative vertex
+ * lists outgrow 1024 vertices ends with the last polygon that fits (te_check_polygon_footprint_paths reports status 3). */
 int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
                      const unsigned char* conservative, int cap_polygons, int cap_vertices, int* n_polygons, int* n_vertices,
                      int* polygon_first, int* vertex_offset, double* vertex_xy, double* area);

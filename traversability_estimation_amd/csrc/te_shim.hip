@@ -736,10 +736,25 @@ hipError_t copy_circular(te_ctx* c, float* dev, void* host, int si, int sj, bool
 }
 }  // namespace
 
+// expect_rows / expect_cols > 0: the caller laid out its host buffer for that shape (the message entry points read the
+// geometry, drop the lock and come back here): fail instead of copying rows*cols cells of another shape
+static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col,
+                                         int expect_rows, int expect_cols);
+static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
+                                           int expect_rows, int expect_cols);
+
 int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col) {
+  return upload_layer_circular_checked(c, layer, host, map, start_row, start_col, 0, 0);
+}
+
+static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col,
+                                         int expect_rows, int expect_cols) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: NULL");
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer_circular: geometry not set");
+  if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
+    return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
+                c->geo.cols, expect_rows, expect_cols);
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: bad layer %d", layer);
   if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
@@ -756,9 +771,17 @@ int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, i
 }
 
 int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int start_row, int start_col) {
+  return download_layer_circular_checked(c, layer, host, map, start_row, start_col, 0, 0);
+}
+
+static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
+                                           int expect_rows, int expect_cols) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: NULL");
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer_circular: geometry not set");
+  if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
+    return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
+                c->geo.cols, expect_rows, expect_cols);
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: bad layer %d", layer);
   if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
@@ -830,8 +853,8 @@ int te_upload_msg(te_ctx* c, const void* m, size_t len, const char* layer_name, 
   }
   if (info) *info = mi;
   // the payload may be unaligned: it is only ever handed to the copy engine
-  return te_upload_layer_circular(c, layer, reinterpret_cast<const float*>((const uint8_t*)m + l->data_off), 0, mi.start_row,
-                                  mi.start_col);
+  return upload_layer_circular_checked(c, layer, reinterpret_cast<const float*>((const uint8_t*)m + l->data_off), 0, mi.start_row,
+                                       mi.start_col, mi.rows, mi.cols);
 }
 
 int te_download_msg(te_ctx* c, const te_msg_info* info, int n_layers, const int* layers, const char* const* names, int n_basic,
@@ -855,7 +878,8 @@ int te_download_msg(te_ctx* c, const te_msg_info* info, int n_layers, const int*
   std::string err;
   if (!msg::write_skeleton(mi, ln, bn, (uint8_t*)out, out ? cap : 0, off, err)) return fail(TE_ERR_INVALID_ARG, "te_download_msg: %s", err.c_str());
   for (int k = 0; k < n_layers; ++k) {
-    const int rc = te_download_layer_circular(c, layers[k], reinterpret_cast<float*>((uint8_t*)out + off[k]), 0, mi.start_row, mi.start_col);
+    const int rc = download_layer_circular_checked(c, layers[k], reinterpret_cast<float*>((uint8_t*)out + off[k]), 0, mi.start_row, mi.start_col,
+                                                   mi.rows, mi.cols);
     if (rc != TE_OK) return rc;
   }
   return TE_OK;
@@ -1152,6 +1176,11 @@ int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, i
     return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
   for (int k = 0; k < n_paths; ++k)
     if (pose_offset[0] != 0 || pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: bad pose offsets");
+  // the same input checks as te_check_polygon_footprint_paths: a NaN pose would otherwise come back as a degenerate hull
+  for (int k = 0; k < 3 * n_points; ++k)
+    if (!isfinite(points_xyz[k])) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: footprint point %d is not finite", k / 3);
+  for (long k = 0; n_paths > 0 && k < 7L * pose_offset[n_paths]; ++k)
+    if (!isfinite(poses[k])) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: pose %ld is not finite", k / 7);
   PathPolygons pp;
   build_path_polygons(n_paths, pose_offset, poses, n_points, points_xyz, conservative, pp);
   *n_polygons = (int)pp.area.size();
@@ -1159,7 +1188,9 @@ int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, i
   if (*n_polygons > cap_polygons || *n_vertices > cap_vertices)
     return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d polygons / %d vertices do not fit the buffers (%d / %d)", *n_polygons,
                 *n_vertices, cap_polygons, cap_vertices);
-  if (!polygon_first || !vertex_offset || !vertex_xy || !area) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL output");
+  // (nothing to write: a sizing call, or paths without poses -- the buffers may be NULL then)
+  if (!polygon_first || !vertex_offset || (*n_vertices && !vertex_xy) || (*n_polygons && !area))
+    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL output");
   for (int k = 0; k < n_paths; ++k) polygon_first[k] = pp.first[k];
   polygon_first[n_paths] = *n_polygons;
   memcpy(vertex_offset, pp.vertex_offset.data(), pp.vertex_offset.size() * sizeof(int));
