@@ -680,34 +680,51 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
       const double q1 = fma(fma(-q0, dn, St), rnt, q0);
       out = (float)fma(fma(-q1, dn, St), rnt, q1);
     } else {
-      // walk the spiral until the first untraversable cell :687-717
+      // walk the spiral until the first untraversable cell :687-717.  Eight table entries per trip, their ring cells
+      // fetched together (one entry per trip made the lane wait for a table load and an LDS read in turn)
       double t = 0.0;
       int ncells = 0;
       out = qnanf();
-      for (int kk = 0; kk < a.n_spiral; ++kk) {
-        const int di = a.table[4 * kk + 0], dj = a.table[4 * kk + 1];
-        const int ii = i + di, jj = j + dj;
-        if (ii < 0 || ii >= g.rows || jj < 0 || jj >= g.cols) continue;
-        if (a.table[4 * kk + 3]) {
-          const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
-          if (!(dx * dx + dy * dy <= a.r2)) continue;
-        }
-        int sl = slot_j + dj;
-        sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
-        const double v = ring[sl * W + c + di];
-        if (v >= 0.5 * kUOff) {
-          const double ru = (double)a.table[4 * kk + 2] * g.res;  // getCurrentRadius()
-          if (a.rmin == 0.0 || ru <= a.rmin) {
-            out = 0.0f;  // :694-704
-          } else {
-            const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
-            t *= factor / ncells;
-            out = (float)t;
+      bool found = false;
+      const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
+      for (int k0 = 0; k0 < a.n_spiral && !found; k0 += 8) {
+        double v[8];
+        bool in[8];
+        int ring_no[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
+          const unsigned w = ptab[kk];  // uniform: a scalar load
+          const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+          ring_no[q] = (int)((w >> 16) & 0xffu);
+          const int ii = i + di, jj = j + dj;
+          in[q] = k0 + q < a.n_spiral && ii >= 0 && ii < g.rows && jj >= 0 && jj < g.cols;
+          if (in[q] && (w >> 24)) {  // a cell on the circle itself: SpiralIterator::isInside
+            const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+            in[q] = dx * dx + dy * dy <= a.r2;
           }
-          break;
+          int sl = slot_j + dj;
+          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+          v[q] = ring[sl * W + c + (in[q] ? di : 0)];
         }
-        ncells++;
-        t += v;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (found || !in[q]) continue;
+          if (v[q] >= 0.5 * kUOff) {
+            const double ru = (double)ring_no[q] * g.res;  // getCurrentRadius()
+            if (a.rmin == 0.0 || ru <= a.rmin) {
+              out = 0.0f;  // :694-704
+            } else {
+              const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+              t *= factor / ncells;
+              out = (float)t;
+            }
+            found = true;
+          } else {
+            ncells++;
+            t += v[q];
+          }
+        }
       }
       if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
     }
@@ -767,7 +784,9 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     int strips = (int)((per_cu * 256) / (nbx * (g.batch > 0 ? g.batch : 1)));
     strips = strips < 1 ? 1 : strips;
     int rows_per = (g.cols + strips - 1) / strips;
-    a.out_rows = rows_per < 48 ? 48 : (rows_per > 512 ? 512 : rows_per);
+    // (a small map cannot fill the wave slots anyway: short strips, down to 8 rows, cut the latency of the single launch
+    // -- each wave's spiral walks are serial -- at the price of more warm-up rows in total)
+    a.out_rows = rows_per < 8 ? 8 : (rows_per > 512 ? 512 : rows_per);
   }
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
                   (unsigned)g.batch);

@@ -37,7 +37,7 @@ struct F3Args {
 };
 
 constexpr int f3_chunk_rows(int NR) {
-  const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 2};
+  const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 13, 17, 2};
   for (int c : pref)
     if (NR % c == 0) return c;
   return 1;
@@ -134,32 +134,52 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     if (__builtin_expect(__any(blocked), 0)) {
       if (blocked) {
         // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
-        // oldest row of the ring, which is row u of the chunk vb[0] points to
+        // oldest row of the ring, which is row u of the chunk vb[0] points to.  The table is read eight entries at a
+        // time and their eight ring cells are fetched together: one entry per trip made every lane wait for a table
+        // load and an LDS read in turn (230 cycles per entry; a map where most discs hold an untraversable cell spent
+        // its time here).
         const int slot0 = (int)((__builtin_amdgcn_readfirstlane(vb[0])) / RB) + u;
         double t = 0.0;
         int ncells = 0;
         float o = __builtin_nanf("");
-        for (int kk = 0; kk < a.n_spiral; ++kk) {
-          const int di = a.table[4 * kk + 0], dj = a.table[4 * kk + 1];
-          const int ii = icol + di, jj = j + dj;
-          if (ii < 0 || ii >= a.rows || jj < 0 || jj >= a.cols) continue;
-          int sl = slot0 + dj + R;
-          sl = sl >= NR ? sl - NR : sl;
-          sl = sl >= NR ? sl - NR : sl;
-          const double v = ring[sl * W + lane + R + di];
-          if (v >= 0.5 * kUOff3) {
-            const double ru = (double)a.table[4 * kk + 2] * a.res;  // getCurrentRadius()
-            if (drmin == 0.0 || ru <= drmin) {
-              o = 0.0f;  // :694-704
-            } else {
-              const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
-              t *= factor / ncells;
-              o = (float)t;
-            }
-            break;
+        bool found = false;
+        const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
+        const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
+        for (int k0 = 0; k0 < a.n_spiral && !found; k0 += 8) {
+          double v[8];
+          bool in[8];
+          int ring_no[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
+            const unsigned w = ptab[kk];  // uniform: a scalar load
+            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+            ring_no[q] = (int)((w >> 16) & 0xffu);
+            const int ii = icol + di, jj = j + dj;
+            in[q] = k0 + q < a.n_spiral && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
+            int sl = slot0 + dj + R;
+            sl = sl >= NR ? sl - NR : sl;
+            sl = sl >= NR ? sl - NR : sl;
+            v[q] = ring[sl * W + lane + R + (in[q] ? di : 0)];
           }
-          ncells++;
-          t += v;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (found || !in[q]) continue;
+            if (v[q] >= 0.5 * kUOff3) {
+              const double ru = (double)ring_no[q] * a.res;  // getCurrentRadius()
+              if (drmin == 0.0 || ru <= drmin) {
+                o = 0.0f;  // :694-704
+              } else {
+                const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
+                t *= factor / ncells;
+                o = (float)t;
+              }
+              found = true;
+            } else {
+              ncells++;
+              t += v[q];
+            }
+          }
         }
         if (!(o == o)) o = (float)(t / ncells);  // cannot happen (an untraversable cell is in the disc)
         out = o;
@@ -239,7 +259,7 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
   int strips = capacity / per_row;
   strips = strips < 1 ? 1 : strips;
   int sr = (a.cols + strips - 1) / strips;
-  sr = sr < 32 ? 32 : (sr > 512 ? 512 : sr);
+  sr = sr < 8 ? 8 : (sr > 512 ? 512 : sr);  // small maps: short strips for latency, the slots are not full anyway
   a.strip_rows = sr;
   const int nstrips = (a.cols + sr - 1) / sr;
   hipLaunchKernelGGL((k_fp_slide3<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
@@ -252,7 +272,12 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
 #define TE_F3_SHAPES(X) \
   X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
   X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
-  X(89) X(90) X(97) X(98) X(100)
+  X(89) X(90) X(97) X(98) X(100) \
+  /* radii 11 .. 16 (the default footprint, 0.45 m, is 15 cells at 0.03 m): every sum of two squares up to 256 */ \
+  X(101) X(104) X(106) X(109) X(113) X(116) X(117) X(121) X(122) X(125) X(128) X(130) X(136) X(137) X(144) X(145) \
+  X(146) X(148) X(149) X(153) X(157) X(160) X(162) X(164) X(169) X(170) X(173) X(178) X(180) X(181) X(185) X(193) \
+  X(194) X(196) X(197) X(200) X(202) X(205) X(208) X(212) X(218) X(221) X(225) X(226) X(229) X(232) X(233) X(234) \
+  X(241) X(242) X(244) X(245) X(250) X(256)
 #endif
 
 // The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.

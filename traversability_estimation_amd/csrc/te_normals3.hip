@@ -686,7 +686,7 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   static const char* ev = getenv("TE_N3_EDGE_PERCENT");  // measurement aid: strip height of the edge columns in percent
   const int pct = ev && atoi(ev) > 0 ? atoi(ev) : 50;
   auto edge_rows = [&](int h) { return (pct * h + 99) / 100; };
-  for (int h = 24; h <= 512; ++h) {  // smallest strip height whose block count fits
+  for (int h = 8; h <= 512; ++h) {  // smallest strip height whose block count fits (small maps: short strips, low latency)
     const int he = edge_rows(h);
     const int blocks = a.n_int * ((Hf + h - 1) / h) + ne * ((H + he - 1) / he) + a.n_top + n_bottom;
     if (blocks <= capacity) {

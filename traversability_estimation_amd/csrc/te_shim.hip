@@ -242,7 +242,14 @@ int rebuild_footprint_tables_impl(te_ctx* c) {
     std::vector<int> ctab((size_t)(2 * f.reach + 1) * (2 * f.reach + 1) * 6);
     fast::build_clip_table(d, f.reach, ctab.data());
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->d_spiral) HIP_TRY(hipMalloc((void**)&c->d_spiral, sizeof(int16_t) * 4 * kMaxSpiral));
+    // the int16 table, followed by the same entries packed into one word each (di | dj << 8 | ring << 16 | tie << 24):
+    // the kernels' spiral walk reads those with scalar loads, eight entries at a time
+    if (!c->d_spiral) HIP_TRY(hipMalloc((void**)&c->d_spiral, sizeof(int16_t) * 4 * kMaxSpiral + sizeof(uint32_t) * kMaxSpiral));
+    std::vector<uint32_t> packed(f.n_spiral);
+    for (int k = 0; k < f.n_spiral; ++k)
+      packed[k] = ((uint32_t)tab[4 * k] & 0xffu) | (((uint32_t)tab[4 * k + 1] & 0xffu) << 8) | (((uint32_t)tab[4 * k + 2] & 0xffu) << 16) |
+                  (((uint32_t)tab[4 * k + 3] & 0xffu) << 24);
+    HIP_TRY(hipMemcpyAsync(c->d_spiral + 4 * kMaxSpiral, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (!c->fp_clip_table) HIP_TRY(hipMalloc((void**)&c->fp_clip_table, sizeof(int) * 6 * 41 * 41));
     HIP_TRY(hipMemcpyAsync(c->d_spiral, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->fp_clip_table, ctab.data(), ctab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
