@@ -104,7 +104,9 @@ typedef enum te_filter {
   TE_FILTER_SLOPE = 1,     /* in: surface_normal_z                      out: traversability_slope     (SlopeFilter.cpp:59-88) */
   TE_FILTER_STEP = 2,      /* in: elevation                             out: traversability_step      (StepFilter.cpp:102-182) */
   TE_FILTER_ROUGHNESS = 3, /* in: elevation, surface_normal_{x,y,z}     out: traversability_roughness (RoughnessFilter.cpp:73-132) */
-  TE_FILTER_COMBINE = 4    /* in: the three scores                      out: traversability           (MathExpressionFilter) */
+  TE_FILTER_COMBINE = 4,   /* in: the three scores                      out: traversability           (MathExpressionFilter) */
+  TE_FILTER_NORMALS = 5    /* in: elevation                             out: surface_normal_{x,y,z}   (NormalVectorsFilter, area method;
+                              robot_filter_parameter.yaml:3-9; README.md:173 "Surface Normals Filter") */
 } te_filter;
 
 /* Filter parameters: same keys, defaults and validity ranges as the reference's configure()s.

@@ -19,7 +19,7 @@ LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traver
               traversability=4, traversability_footprint=5, surface_normal_x=6, surface_normal_y=7,
               surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11,
               traversability_x=12, traversability_rot=13)
-FILTERS = dict(slope=1, step=2, roughness=3, combine=4)
+FILTERS = dict(slope=1, step=2, roughness=3, combine=4, normals=5)
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
 RUN_GENERIC_KERNELS = 0x4

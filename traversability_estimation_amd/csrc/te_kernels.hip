@@ -490,6 +490,8 @@ int chain_max_reach(const ChainParams& p) {
 }
 
 // One reference plugin at a time (the drop-in SlopeFilter / StepFilter / RoughnessFilter adapters).
+hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags, hipStream_t stream);
+
 hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, int filter, unsigned flags,
                          hipStream_t stream) {
   const Region r = {-1, 0, 0, g.rows, g.cols};
@@ -519,6 +521,13 @@ hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, in
     na.given_normals = 1;
     hipLaunchKernelGGL(k_normals, tile_grid(g, r), blk, tile_bytes(p.rough.reach), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, L.nx, L.ny, L.nz, r);
+  } else if (filter == TE_FILTER_NORMALS) {
+    // the normals pass alone, normals kept: the sliding kernel computes slope and roughness on the way (same disc), the
+    // plugins that want those layers compute them from their own inputs later
+    ChainParams q = p;
+    q.rough = q.normals;
+    q.same_rough_disc = 1;
+    return launch_chain(g, q, L, r, (flags & TE_RUN_GENERIC_KERNELS) | TE_RUN_KEEP_NORMALS | TE_RUN_NORMALS_ONLY, stream);
   } else if (filter == TE_FILTER_COMBINE) {
     const dim3 cgrid((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch);
     hipLaunchKernelGGL(k_combine, cgrid, dim3(256), 0, stream, g, p.w_scale, p.w_slope, p.w_step, p.w_rough, L.slope,

@@ -916,8 +916,8 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
     int rc = rebuild_tables(c);
     if (rc) return rc;
   }
-  if (filter < TE_FILTER_SLOPE || filter > TE_FILTER_COMBINE) return fail(TE_ERR_INVALID_ARG, "te_run_filter: bad filter %d", filter);
-  if ((filter == TE_FILTER_STEP || filter == TE_FILTER_ROUGHNESS) && !c->have_elev)
+  if (filter < TE_FILTER_SLOPE || filter > TE_FILTER_NORMALS) return fail(TE_ERR_INVALID_ARG, "te_run_filter: bad filter %d", filter);
+  if ((filter == TE_FILTER_STEP || filter == TE_FILTER_ROUGHNESS || filter == TE_FILTER_NORMALS) && !c->have_elev)
     return fail(TE_ERR_NOT_READY, "te_run_filter: no elevation uploaded");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));

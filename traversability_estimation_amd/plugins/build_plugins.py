@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(HERE, "libtraversability_estimation_filters.so")
 TEST = os.path.join(HERE, "plugin_chain_test")
 SRCS = ["src/DeviceMap.cpp", "src/SlopeFilter.cpp", "src/StepFilter.cpp", "src/RoughnessFilter.cpp",
-        "src/FusedChainFilter.cpp", "src/TraversabilityMap.cpp", "stubs/pluginlib/registry.cpp"]
+        "src/FusedChainFilter.cpp", "src/SurfaceNormalsFilter.cpp", "src/TraversabilityMap.cpp", "stubs/pluginlib/registry.cpp"]
 
 
 def build(verbose=False):

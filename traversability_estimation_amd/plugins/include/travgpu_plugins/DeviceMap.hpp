@@ -31,6 +31,8 @@ class DeviceMap {
   // `surface_normal_z`.  A device layer is identified by the map's time stamp, geometry and start index plus a hash of
   // the buffer (sampled; TRAVGPU_PLUGIN_HASH=full hashes every cell, TRAVGPU_PLUGIN_CACHE=0 always uploads).
   bool upload(const grid_map::GridMap& map, const std::string& layer, int te_layer);
+  // after a download into `layer`: the device layer and that host buffer are the same thing
+  bool noteResident(const grid_map::GridMap& map, const std::string& layer, int te_layer);
   unsigned long uploads() const { return uploads_; }               // transfers actually made / avoided (tests, logging)
   unsigned long uploadsSkipped() const { return uploads_skipped_; }
   bool runFilter(int filter);

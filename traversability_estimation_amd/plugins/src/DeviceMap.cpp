@@ -102,7 +102,21 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
   return ok;
 }
 
-bool DeviceMap::runFilter(int filter) { return check(te_run_filter(ctx_, filter, 0)); }
+bool DeviceMap::noteResident(const grid_map::GridMap& map, const std::string& layer, int te_layer) {
+  static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
+  static const bool full_hash = getenv("TRAVGPU_PLUGIN_HASH") && !strcmp(getenv("TRAVGPU_PLUGIN_HASH"), "full");
+  if (!cache_on || te_layer < 0 || te_layer >= kLayers || !map.exists(layer)) return true;
+  const size_t n = (size_t)rows_ * cols_;
+  const LayerKey key = {true, (uint64_t)map.getTimestamp(), hash_layer(map.get(layer).data(), n, full_hash), n, start_row_, start_col_};
+  resident_[te_layer] = key;
+  return true;
+}
+
+bool DeviceMap::runFilter(int filter) {
+  if (filter == TE_FILTER_NORMALS)  // writes the normal layers: whatever a plugin uploaded there is gone
+    resident_[TE_LAYER_NORMAL_X].valid = resident_[TE_LAYER_NORMAL_Y].valid = resident_[TE_LAYER_NORMAL_Z].valid = false;
+  return check(te_run_filter(ctx_, filter, 0));
+}
 bool DeviceMap::runChain(unsigned flags) {
   // the fused chain writes the normal layers itself (TE_RUN_KEEP_NORMALS): whatever a plugin uploaded there is gone
   resident_[TE_LAYER_NORMAL_X].valid = resident_[TE_LAYER_NORMAL_Y].valid = resident_[TE_LAYER_NORMAL_Z].valid = false;

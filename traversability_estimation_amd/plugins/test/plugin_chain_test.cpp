@@ -45,6 +45,7 @@ static const char* kSlope = "filters::SlopeFilter<grid_map::GridMap>";
 static const char* kStep = "filters::StepFilter<grid_map::GridMap>";
 static const char* kRough = "filters::RoughnessFilter<grid_map::GridMap>";
 static const char* kFused = "filters::FusedChainFilter<grid_map::GridMap>";
+static const char* kNormals = "filters::SurfaceNormalsFilter<grid_map::GridMap>";
 
 static void test_configure() {
   // same acceptance rules as the reference's configure()s
@@ -71,6 +72,12 @@ static void test_configure() {
   CHECK(r && r->configure("roughnessFilter", ParamMap{{"critical_value", 0.05}, {"estimation_radius", 0.05}, {"map_type", "traversability_roughness"}}));
   CHECK(r && !r->configure("roughnessFilter", ParamMap{{"critical_value", -1.0}, {"estimation_radius", 0.05}, {"map_type", "x"}}));
   CHECK(r && !r->configure("roughnessFilter", ParamMap{{"critical_value", 0.05}, {"map_type", "x"}}));
+  auto nf = make(kNormals);
+  CHECK(!nf->configure("normals", ParamMap{}));                                                    // radius is required
+  CHECK(!nf->configure("normals", ParamMap{{"radius", -0.1}}));
+  CHECK(!nf->configure("normals", ParamMap{{"radius", 0.05}, {"normal_vector_positive_axis", "w"}}));
+  CHECK(nf->configure("normals", ParamMap{{"input_layer", "elevation"}, {"output_layers_prefix", "surface_normal_"}, {"radius", 0.05},
+                                          {"normal_vector_positive_axis", "z"}}));                 // robot_filter_parameter.yaml:3-9
   auto f = make(kFused);
   CHECK(f && f->configure("fused", ParamMap{}));
   CHECK(f && !f->configure("fused", ParamMap{{"slope_critical_value", 3.0}}));
@@ -179,6 +186,24 @@ static void test_device() {
   grid_map::GridMap bare = make_map(rows, cols, res), out;
   CHECK(!s->update(bare, out));
 
+  {  // the whole unchanged-parameter chain on the device: SurfaceNormalsFilter in place of the host NormalVectorsFilter.
+     // One upload (elevation) serves all four plugins: the normals the first one downloads are what the device holds.
+    auto nf = make(kNormals);
+    CHECK(nf->configure("normals", ParamMap{{"radius", p.normals_radius}, {"normal_vector_positive_axis", "z"}}));
+    grid_map::GridMap fresh = make_map(rows, cols, res), n1, n2, n3, n4;
+    fresh.setTimestamp(map0.getTimestamp() + 1000000000ull);
+    const unsigned long up1 = dev.uploads();
+    CHECK(nf->update(fresh, n1));
+    CHECK(s->update(n1, n2) && t->update(n2, n3) && r->update(n3, n4));
+    CHECK(dev.uploads() - up1 == 1);
+    std::printf("SurfaceNormalsFilter -> Slope -> Step -> Roughness:\n");
+    CHECK(compare("surface_normal_x", n4["surface_normal_x"], nx) == 0);
+    CHECK(compare("surface_normal_y", n4["surface_normal_y"], ny) == 0);
+    CHECK(compare("surface_normal_z", n4["surface_normal_z"], nz) == 0);
+    CHECK(compare("traversability_slope", n4["traversability_slope"], sl) == 0);
+    CHECK(compare("traversability_step", n4["traversability_step"], st) == 0);
+    CHECK(compare("traversability_roughness", n4["traversability_roughness"], ro) == 0);
+  }
   auto f = make(kFused);
   CHECK(f->configure("fused", ParamMap{{"normals_radius", p.normals_radius}, {"estimation_radius", p.rough_radius},
                                        {"first_window_radius", p.step_radius1}, {"second_window_radius", p.step_radius2}}));
