@@ -33,7 +33,10 @@
  *   te_check_footprint_paths, te_check_polygon_footprint_paths
  *                        <- TraversabilityMap::checkFootprintPath, TraversabilityMap.cpp:320-342
  *                           (checkCircularFootprintPath :344-462, checkPolygonalFootprintPath :464-584)
+ *   te_check_inclination, te_set_check_robot_inclination
+ *                        <- TraversabilityMap::checkInclination :748-762 and footprint/check_robot_inclination :114
  *   te_polygons_traversable <- TraversabilityMap::isTraversable(polygon, traversability), :586-645
+ *   te_polygon_untraversable_hull <- isTraversable(polygon, computeUntraversablePolygon, ..), :592-645
  *   te_run_polygon_footprint <- TraversabilityMap::traversabilityFootprint(footprintYaw), :239-305
  *   te_upload_msg / te_download_msg / te_msg_* / te_bag_*
  *                        <- GridMapRosConverter::fromMessage / toMessage / loadFromBag / saveToBag as called in
@@ -86,7 +89,9 @@ typedef enum te_layer {
   TE_LAYER_ROUGHNESS_FOOTPRINT = 11,
   TE_LAYER_TRAVERSABILITY_X = 12,   /* traversability_x / traversability_rot: exist after te_run_polygon_footprint */
   TE_LAYER_TRAVERSABILITY_ROT = 13,
-  TE_LAYER_COUNT = 14
+  TE_LAYER_ROBOT_SLOPE = 14,   /* input of checkInclination (robotSlopeType_, TraversabilityMap.cpp:47): optional, exists
+                                  from its first upload on (te_upload_layer / _circular / te_upload_msg / te_device_ptr) */
+  TE_LAYER_COUNT = 15
 } te_layer;
 
 /* te_run_chain flags */
@@ -191,10 +196,24 @@ int te_run_footprint(te_ctx* ctx);
  * Path k has the poses pose_xy[2*pose_offset[k] .. 2*pose_offset[k+1]) (x, y in the map frame; pose_offset[0] == 0).
  * Outputs per path: is_safe and traversability (TraversabilityResult, :352-355), status 0 ok / 1 a pose of a
  * multi-pose path lies outside the map (the reference ignores getIndex()'s failure there: undefined) / 2 no poses
- * (:330-334).  Reference options not covered (their defaults): publishPolygons, compute_untraversable_polygon,
- * footprint/check_robot_inclination.  Host buffers; synchronous. */
+ * (:330-334).  With te_set_check_robot_inclination(ctx, 1) every pose of a one-pose path / every segment first passes
+ * checkInclination (:366-370, :390-394) on the layer robot_slope; a failure leaves the default result (unsafe, 0), and
+ * status 1 also marks a position checkInclination was handed outside the map (atPosition throws there).  Reference
+ * options not covered: publishPolygons (ROS markers) and the untraversable polygon of compute_untraversable_polygon, which
+ * on a complete footprint layer is Polygon::fromCircle of the unsafe centres (:676-678) -- no map data; the result is
+ * the same with and without it.  Host buffers; synchronous. */
 int te_check_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* pose_xy,
                              unsigned char* is_safe, double* traversability, int* status);
+/* footprint/check_robot_inclination (TraversabilityMap.cpp:114, default false): when set, te_check_footprint_paths and
+ * te_check_polygon_footprint_paths run checkInclination before every isTraversable, reading TE_LAYER_ROBOT_SLOPE (the
+ * reference's layer "robot_slope", written by whoever estimates the robot's inclination); TE_ERR_NOT_READY from the
+ * path checks if that layer was never uploaded. */
+int te_set_check_robot_inclination(te_ctx* ctx, int enabled);
+/* Batched TraversabilityMap::checkInclination(start, end) (:748-762) on the layer robot_slope of map `map`: segment k =
+ * start_end_xy[4k .. 4k+4) = start x y, end x y.  start == end: ok = the cell's value != 0; otherwise a LineIterator from
+ * the start index to the end index, cells that are not valid skipped, ok = no cell is 0.  status 0 / 1 a position lies
+ * outside the map (ok = 0 then).  Host buffers; synchronous. */
+int te_check_inclination(te_ctx* ctx, int map, int n_segments, const double* start_end_xy, unsigned char* ok, int* status);
 /* TraversabilityMap::traversabilityFootprint(footprintYaw) (TraversabilityMap.cpp:239-305): for every cell of every map the
  * footprint polygon (n_points vertices points_xy = x0 y0 x1 y1 .. in the footprint frame, footprint/footprint_polygon
  * :91-103) centred on the cell, as given -> layer traversability_x, and turned by `yaw` about z -> traversability_rot;
@@ -211,6 +230,17 @@ int te_run_polygon_footprint(te_ctx* ctx, int n_points, const double* points_xy,
  * precondition as above.  Host buffers; synchronous. */
 int te_polygons_traversable(te_ctx* ctx, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
                             unsigned char* is_traversable, double* traversability);
+/* TraversabilityMap::isTraversable(polygon, computeUntraversablePolygon = true, traversability, untraversablePolygon)
+ * (:592-645; FootprintPath.compute_untraversable_polygon) for ONE polygon on map `map`: is_traversable / traversability as
+ * te_polygons_traversable, plus the untraversable polygon = grid_map::Polygon::monotoneChainConvexHullOfPoints of the
+ * positions of every untraversable cell inside the polygon (*n_hull = 0 when traversable; the points as collected when
+ * there are at most three).  hull_xy holds cap_vertices vertices (x y); TE_ERR_INVALID_ARG with *n_hull set if the hull
+ * has more.  The device reduces every row of the bounding box to its outermost untraversable cells, the chain runs on
+ * the host.  For circular footprints on a complete footprint layer the reference's untraversable polygon is just
+ * Polygon::fromCircle(center, radius + offset) of an unsafe centre (:676-678): no map data, left to the caller.
+ * Same precondition as te_polygons_traversable.  Host buffers; synchronous. */
+int te_polygon_untraversable_hull(te_ctx* ctx, int map, int n_vertices, const double* vertex_xy, unsigned char* is_traversable,
+                                  double* traversability, int cap_vertices, int* n_hull, double* hull_xy);
 /* Batched TraversabilityMap::checkFootprintPath for polygonal footprints (checkPolygonalFootprintPath, :464-584).
  * Path k has the poses poses[7*pose_offset[k] .. 7*pose_offset[k+1]) -- position x y z, orientation x y z w, as in
  * geometry_msgs/Pose; the footprint is n_points points x y z (path.footprint.polygon.points) in the footprint frame;
@@ -218,8 +248,11 @@ int te_polygons_traversable(te_ctx* ctx, int map, int n_polygons, const int* ver
  * conservative extensions, the convex hull of consecutive ones (grid_map::Polygon::convexHull) and the areas are computed
  * on the host, every polygon's isTraversable on the device in one launch.  Outputs per path = TraversabilityResult:
  * is_safe, traversability, area (a path that fails keeps the values of the segments before, as the reference's result
- * does).  status: 0 ok, 2 no poses (:330-334), 3 the conservative vertex lists outgrew 1024 vertices.  Not covered (their
- * defaults): publishPolygons, compute_untraversable_polygon, check_robot_inclination.  Host buffers; synchronous. */
+ * does).  status: 0 ok, 1 check_robot_inclination is set and a position handed to checkInclination lies outside the map,
+ * 2 no poses (:330-334), 3 the conservative vertex lists outgrew 1024 vertices.  With te_set_check_robot_inclination
+ * checkInclination runs before every polygon (:526-528, :553-557).  Not covered: publishPolygons (ROS markers); the
+ * untraversable polygon of compute_untraversable_polygon is te_polygon_untraversable_hull on the polygons
+ * te_path_polygons returns (it is only ever published, :531-533, :559-561; the result is the same).  Host buffers; synchronous. */
 int te_check_polygon_footprint_paths(te_ctx* ctx, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
                                      const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
                                      double* traversability, double* area, int* status);

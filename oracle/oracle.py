@@ -64,6 +64,12 @@ def lib():
                                                C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         ip = C.POINTER(C.c_int)
         dp_ = C.POINTER(C.c_double)
+        L.teo_polygon_untraversable_hull.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, dp_, C.POINTER(C.c_ubyte), dp_, C.c_int,
+                                                     ip, dp_]
+        L.teo_check_circular_paths_incl.argtypes = [gp, fp, C.c_double, fp, C.c_int, ip, dp_, C.POINTER(C.c_ubyte), dp_, ip]
+        L.teo_check_inclination.argtypes = [gp, fp, C.c_int, dp_, C.POINTER(C.c_ubyte), ip]
+        L.teo_check_polygon_paths_incl.argtypes = [gp, pp, fp, fp, fp, fp, fp, fp, C.c_int, ip, dp_, C.c_int, dp_,
+                                                   C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), dp_, dp_, ip]
         L.teo_polygons_traversable.argtypes = [gp, pp, fp, fp, fp, fp, fp, C.c_int, C.POINTER(C.c_int), dp_,
                                                C.POINTER(C.c_ubyte), dp_]
         L.teo_rotate_footprint.argtypes = [C.c_int, dp_, C.c_double, dp_]
@@ -156,8 +162,23 @@ def footprint(g, p, elev, layers, want_memo=False):
     return fp
 
 
-def check_circular_paths(g, footprint, fp_default, paths):
-    """TraversabilityMap::checkFootprintPath (circular footprints) for a list of (n_i, 2) pose arrays."""
+def check_inclination(g, robot_slope, segments):
+    """Batched TraversabilityMap::checkInclination(start, end): segments (n, 4) = sx sy ex ey -> (ok[bool], status)."""
+    seg = np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 4)
+    k = len(seg)
+    ok = np.zeros(max(k, 1), np.uint8)
+    st = np.zeros(max(k, 1), np.int32)
+    rs = _flat(robot_slope, g.rows * g.cols)
+    rc = lib().teo_check_inclination(C.byref(g), _f(rs), k, seg.ctypes.data_as(C.POINTER(C.c_double)),
+                                     ok.ctypes.data_as(C.POINTER(C.c_ubyte)), st.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc:
+        raise RuntimeError(f"teo_check_inclination failed: {rc}")
+    return ok[:k].astype(bool), st[:k]
+
+
+def check_circular_paths(g, footprint, fp_default, paths, robot_slope=None):
+    """TraversabilityMap::checkFootprintPath (circular footprints) for a list of (n_i, 2) pose arrays; robot_slope:
+    the layer checkInclination reads when footprint/check_robot_inclination is set (None: off)."""
     n = g.rows * g.cols
     fp = _flat(footprint, n)
     paths = [np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in paths]
@@ -169,7 +190,8 @@ def check_circular_paths(g, footprint, fp_default, paths):
     safe = np.zeros(max(k, 1), np.uint8)
     trav = np.zeros(max(k, 1), np.float64)
     st = np.zeros(max(k, 1), np.int32)
-    rc = lib().teo_check_circular_paths(C.byref(g), _f(fp), C.c_double(fp_default), k,
+    rs = None if robot_slope is None else _flat(robot_slope, n)
+    rc = lib().teo_check_circular_paths_incl(C.byref(g), _f(fp), C.c_double(fp_default), _f(rs), k,
                                         off.ctypes.data_as(C.POINTER(C.c_int)), xy.ctypes.data_as(C.POINTER(C.c_double)),
                                         safe.ctypes.data_as(C.POINTER(C.c_ubyte)), trav.ctypes.data_as(C.POINTER(C.c_double)),
                                         st.ctypes.data_as(C.POINTER(C.c_int)))
@@ -197,6 +219,23 @@ def polygons_traversable(g, p, elev, slope, step, rough, trav, polygons):
     return ok.astype(bool), out
 
 
+def polygon_untraversable_hull(g, p, elev, slope, step, rough, trav, polygon, cap=4096):
+    """isTraversable(polygon, computeUntraversablePolygon=True): (is_traversable, traversability, hull (k, 2))."""
+    n = g.rows * g.cols
+    v = np.ascontiguousarray(polygon, dtype=np.float64).reshape(-1, 2)
+    ok = C.c_ubyte()
+    val = C.c_double()
+    nh = C.c_int()
+    hull = np.zeros((cap, 2), np.float64)
+    dp_ = C.POINTER(C.c_double)
+    rc = lib().teo_polygon_untraversable_hull(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
+                                              _f(_flat(rough, n)), _f(_flat(trav, n)), len(v), v.ctypes.data_as(dp_),
+                                              C.byref(ok), C.byref(val), cap, C.byref(nh), hull.ctypes.data_as(dp_))
+    if rc:
+        raise RuntimeError(f"teo_polygon_untraversable_hull failed: {rc}")
+    return bool(ok.value), val.value, hull[:nh.value].copy()
+
+
 def rotate_footprint(points_xy, yaw):
     pts = np.ascontiguousarray(points_xy, dtype=np.float64).reshape(-1, 2)
     out = np.empty_like(pts)
@@ -219,7 +258,7 @@ def polygon_footprint(g, p, elev, slope, step, rough, trav, points_xy, yaw):
     return tx, tr
 
 
-def check_polygon_paths(g, p, elev, slope, step, rough, trav, paths, points_xyz, conservative=None):
+def check_polygon_paths(g, p, elev, slope, step, rough, trav, paths, points_xyz, conservative=None, robot_slope=None):
     """checkPolygonalFootprintPath for a list of (n_i, 7) pose arrays (position xyz, orientation xyzw)."""
     n = g.rows * g.cols
     paths = [np.asarray(q, dtype=np.float64).reshape(-1, 7) for q in paths]
@@ -235,8 +274,9 @@ def check_polygon_paths(g, p, elev, slope, step, rough, trav, paths, points_xyz,
     area = np.zeros(max(k, 1), np.float64)
     st = np.zeros(max(k, 1), np.int32)
     dp_ = C.POINTER(C.c_double)
-    rc = lib().teo_check_polygon_paths(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
-                                       _f(_flat(rough, n)), _f(_flat(trav, n)), k, off.ctypes.data_as(C.POINTER(C.c_int)),
+    rs = None if robot_slope is None else _flat(robot_slope, n)
+    rc = lib().teo_check_polygon_paths_incl(C.byref(g), C.byref(p), _f(_flat(elev, n)), _f(_flat(slope, n)), _f(_flat(step, n)),
+                                       _f(_flat(rough, n)), _f(_flat(trav, n)), _f(rs), k, off.ctypes.data_as(C.POINTER(C.c_int)),
                                        poses.ctypes.data_as(dp_), len(pts), pts.ctypes.data_as(dp_),
                                        None if cons is None else cons.ctypes.data_as(C.POINTER(C.c_ubyte)),
                                        safe.ctypes.data_as(C.POINTER(C.c_ubyte)), out.ctypes.data_as(dp_),

@@ -788,6 +788,50 @@ int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, con
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* N2  checkInclination :748-762 (footprint/check_robot_inclination == true, :114) on a layer   */
+/*     robot_slope.  start == end: atPosition(robot_slope, start) == 0 -> false; otherwise a     */
+/*     LineIterator from the start index to the end index, cells that are not valid (not finite) */
+/*     skipped, any 0 -> false.  *outside = 1 when a position is outside the map: atPosition     */
+/*     throws there and getIndex()'s failure is ignored (undefined indices); callers report      */
+/*     status 1.                                                                                  */
+/* ------------------------------------------------------------------------------------------- */
+static int inclination_ok(const teo_geom* g, const float* robot_slope, double sx, double sy, double ex, double ey,
+                          int* outside) {
+  int si, sj, ei, ej;
+  *outside = 0;
+  if (ex == sx && ey == sy) { /* Eigen operator== on the two positions */
+    if (!pos_inside(g, sx, sy) || !pos_to_index(g, sx, sy, &si, &sj)) {
+      *outside = 1;
+      return 0;
+    }
+    return !((double)robot_slope[IDX(g, si, sj)] == 0.0);
+  }
+  if (!pos_to_index(g, sx, sy, &si, &sj) || !pos_to_index(g, ex, ey, &ei, &ej)) {
+    *outside = 1;
+    return 0;
+  }
+  line_it L;
+  for (line_init(&L, si, sj, ei, ej); L.icell < L.ncells; line_next(&L)) {
+    const float v = robot_slope[IDX(g, L.i, L.j)];
+    if (!finitef(v)) continue;
+    if ((double)v == 0.0) return 0;
+  }
+  return 1;
+}
+
+/* batched: segment k = start_end_xy[4k .. 4k+4) = sx sy ex ey; ok[k] = checkInclination's result, status[k] 0 / 1 outside */
+int teo_check_inclination(const teo_geom* g, const float* robot_slope, int n, const double* start_end_xy, unsigned char* ok,
+                          int* status) {
+  for (int k = 0; k < n; ++k) {
+    const double* q = start_end_xy + 4 * (size_t)k;
+    int outside;
+    ok[k] = (unsigned char)inclination_ok(g, robot_slope, q[0], q[1], q[2], q[3], &outside);
+    status[k] = outside;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* N2  checkCircularFootprintPath :344-462 for a batch of paths, with publishPolygons == false,   */
 /*     compute_untraversable_polygon == false and footprint/check_robot_inclination == false     */
 /*     (robot_footprint_parameter.yaml:10), on a map whose traversability_footprint layer is     */
@@ -797,9 +841,9 @@ int teo_footprint(const teo_geom* g, const teo_params* p, const float* elev, con
 /*     start/end index); here such a path gets status 1 and is reported unsafe.                   */
 /*     A single pose outside the map uses traversabilityDefault_ (:663-665).                      */
 /* ------------------------------------------------------------------------------------------- */
-int teo_check_circular_paths(const teo_geom* g, const float* footprint, double fp_default, int n_paths,
-                             const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
-                             double* traversability, int* status) {
+int teo_check_circular_paths_incl(const teo_geom* g, const float* footprint, double fp_default, const float* robot_slope,
+                                  int n_paths, const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                                  double* traversability, int* status) {
   for (int k = 0; k < n_paths; ++k) {
     const int n = pose_offset[k + 1] - pose_offset[k];
     const double* xy = pose_xy + 2 * (size_t)pose_offset[k];
@@ -818,6 +862,16 @@ int teo_check_circular_paths(const teo_geom* g, const float* footprint, double f
       sy = ey;
       ex = xy[2 * i];
       ey = xy[2 * i + 1];
+      if (robot_slope && (n == 1 || i > 0)) { /* :366-370, :390-394 checkRobotInclination_ */
+        int outside;
+        const int good = n == 1 ? inclination_ok(g, robot_slope, ex, ey, ex, ey, &outside)
+                                : inclination_ok(g, robot_slope, sx, sy, ex, ey, &outside);
+        if (!good) {
+          status[k] = outside;
+          ok = 0;
+          break;
+        }
+      }
       if (n == 1) { /* :365-385 */
         double t;
         int trav;
@@ -877,6 +931,13 @@ int teo_check_circular_paths(const teo_geom* g, const float* footprint, double f
     }
   }
   return 0;
+}
+
+int teo_check_circular_paths(const teo_geom* g, const float* footprint, double fp_default, int n_paths,
+                             const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                             double* traversability, int* status) {
+  return teo_check_circular_paths_incl(g, footprint, fp_default, NULL, n_paths, pose_offset, pose_xy, is_safe, traversability,
+                                       status);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -1060,12 +1121,101 @@ static double polygon_area(int n, const pt2* v) { /* Polygon::getArea */
   return fabs(area / 2.0);
 }
 
+/* isTraversable(polygon, computeUntraversablePolygon = true, traversability, untraversablePolygon) :592-645
+ * (FootprintPath.compute_untraversable_polygon): every cell of the polygon is visited, the positions of the untraversable
+ * ones are collected in PolygonIterator order, and the untraversable polygon is their monotoneChainConvexHullOfPoints
+ * (no vertices when the polygon is traversable).  *traversability as in polygon_traversable (0 when untraversable: the
+ * reference leaves the partial sum, which every caller discards).  Returns -3 when the hull has more than cap vertices. */
+int teo_polygon_untraversable_hull(const teo_geom* g, const teo_params* p, const float* elev, const float* slope,
+                                   const float* step, const float* rough, const float* trav, int n, const double* v,
+                                   unsigned char* is_traversable, double* traversability, int cap, int* n_hull,
+                                   double* hull_xy) {
+  if (n < 1) return -1;
+  const size_t N = (size_t)g->rows * g->cols;
+  unsigned char* untrav = (unsigned char*)malloc(N);
+  if (!untrav) return -2;
+  untraversable_cells(g, p, elev, slope, step, rough, untrav, NULL, NULL, NULL);
+  double tlx = v[0], tly = v[1], brx = v[0], bry = v[1];
+  for (int k = 1; k < n; ++k) {
+    tlx = tlx < v[2 * k] ? v[2 * k] : tlx;
+    tly = tly < v[2 * k + 1] ? v[2 * k + 1] : tly;
+    brx = v[2 * k] < brx ? v[2 * k] : brx;
+    bry = v[2 * k + 1] < bry ? v[2 * k + 1] : bry;
+  }
+  tlx = bound_axis(tlx, g->len_x, g->pos_x);
+  tly = bound_axis(tly, g->len_y, g->pos_y);
+  brx = bound_axis(brx, g->len_x, g->pos_x);
+  bry = bound_axis(bry, g->len_y, g->pos_y);
+  int ti, tj, bi, bj;
+  pos_to_index(g, tlx, tly, &ti, &tj);
+  pos_to_index(g, brx, bry, &bi, &bj);
+  ti = clampi(ti, 0, g->rows - 1);
+  bi = clampi(bi, 0, g->rows - 1);
+  tj = clampi(tj, 0, g->cols - 1);
+  bj = clampi(bj, 0, g->cols - 1);
+  const size_t box = (size_t)(bi - ti + 1) * (size_t)(bj - tj + 1);
+  pt2* pts = (pt2*)malloc(sizeof(pt2) * (4 * box + 4));
+  if (!pts) {
+    free(untrav);
+    return -2;
+  }
+  pt2 *sorted = pts + box, *hull = pts + 2 * box;
+  unsigned ncells = 0;
+  int nbad = 0;
+  double t = 0.0;
+  for (int a = ti; a <= bi; ++a) {
+    const double px = cell_x(g, a);
+    for (int b = tj; b <= bj; ++b) {
+      if (!polygon_inside(n, v, px, cell_y(g, b))) continue;
+      const size_t o = IDX(g, a, b);
+      if (untrav[o]) { /* :603-609 getPosition of the cell */
+        pts[nbad].x = px;
+        pts[nbad].y = cell_y(g, b);
+        nbad++;
+      } else {
+        ncells++;
+        t += finitef(trav[o]) ? (double)trav[o] : p->fp_default;
+      }
+    }
+  }
+  int ok = nbad == 0;
+  double value = 0.0;
+  if (ok) { /* :624-632 */
+    if (ncells == 0) {
+      value = p->fp_default;
+      ok = p->fp_default != 0.0;
+    } else {
+      value = t / ncells;
+    }
+  }
+  *is_traversable = (unsigned char)ok;
+  *traversability = ok ? value : 0.0;
+  int rc = 0;
+  *n_hull = 0;
+  if (!ok) { /* :634-640 */
+    const int nh = convex_hull(nbad, pts, sorted, hull);
+    if (nh > cap) {
+      rc = -3;
+    } else {
+      *n_hull = nh;
+      for (int k = 0; k < nh; ++k) {
+        hull_xy[2 * k] = hull[k].x;
+        hull_xy[2 * k + 1] = hull[k].y;
+      }
+    }
+  }
+  free(pts);
+  free(untrav);
+  return rc;
+}
+
 #define TEO_MAX_PATH_VERTS 1024 /* vertices of one (conservative) pose polygon */
 
-int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
-                            const float* rough, const float* trav, int n_paths, const int* pose_offset, const double* poses,
-                            int n_points, const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
-                            double* traversability, double* area, int* status) {
+int teo_check_polygon_paths_incl(const teo_geom* g, const teo_params* p, const float* elev, const float* slope,
+                                 const float* step, const float* rough, const float* trav, const float* robot_slope,
+                                 int n_paths, const int* pose_offset, const double* poses, int n_points,
+                                 const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                                 double* traversability, double* area, int* status) {
   if (n_points < 1 || n_points > 32) return -1;
   unsigned char* untrav = (unsigned char*)malloc((size_t)g->rows * g->cols);
   if (!untrav) return -2;
@@ -1120,6 +1270,16 @@ int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float*
           n1++;
         }
       }
+      if (robot_slope && (n == 1 || i > 0)) { /* :526-528, :553-557 checkRobotInclination_ */
+        int outside;
+        const int good = n == 1 ? inclination_ok(g, robot_slope, ex, ey, ex, ey, &outside)
+                                : inclination_ok(g, robot_slope, sx, sy, ex, ey, &outside);
+        if (!good) {
+          status[k] = outside;
+          ok = 0;
+          break;
+        }
+      }
       if (n == 1) { /* :524-546 */
         if (!polygon_traversable(g, untrav, trav, p->fp_default, n2, (const double*)poly2, &t)) {
           ok = 0;
@@ -1157,4 +1317,12 @@ int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float*
   }
   free(untrav);
   return 0;
+}
+
+int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
+                            const float* rough, const float* trav, int n_paths, const int* pose_offset, const double* poses,
+                            int n_points, const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                            double* traversability, double* area, int* status) {
+  return teo_check_polygon_paths_incl(g, p, elev, slope, step, rough, trav, NULL, n_paths, pose_offset, poses, n_points,
+                                      points_xyz, conservative, is_safe, traversability, area, status);
 }

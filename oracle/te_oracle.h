@@ -104,13 +104,28 @@ int teo_spiral_offsets(const teo_geom* g, int ci, int cj, double radius, int* di
 int teo_check_circular_paths(const teo_geom* g, const float* footprint, double fp_default, int n_paths,
                              const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
                              double* traversability, int* status);
-
+/* the same with footprint/check_robot_inclination == true (:114, :366-370, :390-394): robot_slope is the layer
+ * "robot_slope" (NULL: option off); a path whose checkInclination (:748-762) fails is unsafe with the default result.
+ * status 1 also when a position handed to checkInclination lies outside the map (atPosition throws / getIndex ignored). */
+int teo_check_circular_paths_incl(const teo_geom* g, const float* footprint, double fp_default, const float* robot_slope,
+                                  int n_paths, const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+                                  double* traversability, int* status);
+/* batched TraversabilityMap::checkInclination(start, end) (:748-762): segment k = start_end_xy[4k .. 4k+4) = sx sy ex ey */
+int teo_check_inclination(const teo_geom* g, const float* robot_slope, int n, const double* start_end_xy, unsigned char* ok,
+                          int* status);
 
 /* N3: batched TraversabilityMap::isTraversable(polygon, traversability) (:586-645); polygon k has the vertices
  * vertex_xy[2*vertex_offset[k] .. 2*vertex_offset[k+1]).  Returns -1 for a polygon without vertices. */
 int teo_polygons_traversable(const teo_geom* g, const teo_params* p, const float* elev, const float* slope, const float* step,
                              const float* rough, const float* trav, int n_polygons, const int* vertex_offset,
                              const double* vertex_xy, unsigned char* is_traversable, double* traversability);
+/* isTraversable(polygon, computeUntraversablePolygon = true, ..) (:592-645): additionally the untraversable polygon = convex
+ * hull (monotoneChainConvexHullOfPoints) of the positions of the polygon's untraversable cells; n_hull = 0 when traversable.
+ * Returns -3 when the hull has more than cap vertices. */
+int teo_polygon_untraversable_hull(const teo_geom* g, const teo_params* p, const float* elev, const float* slope,
+                                   const float* step, const float* rough, const float* trav, int n_vertices,
+                                   const double* vertex_xy, unsigned char* is_traversable, double* traversability, int cap,
+                                   int* n_hull, double* hull_xy);
 /* the footprint points turned by yaw about z exactly as :250-283 does it (kindr angle-axis -> Eigen quaternion -> matrix) */
 void teo_rotate_footprint(int n_points, const double* points_xy, double yaw, double* out_xy);
 /* traversabilityFootprint(footprintYaw) (:239-305): layers traversability_x / traversability_rot */
@@ -126,6 +141,13 @@ int teo_check_polygon_paths(const teo_geom* g, const teo_params* p, const float*
                             const float* rough, const float* trav, int n_paths, const int* pose_offset, const double* poses,
                             int n_points, const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
                             double* traversability, double* area, int* status);
+/* with footprint/check_robot_inclination == true (:526-528, :553-557); robot_slope NULL: option off; status 1: a
+ * position handed to checkInclination lies outside the map */
+int teo_check_polygon_paths_incl(const teo_geom* g, const teo_params* p, const float* elev, const float* slope,
+                                 const float* step, const float* rough, const float* trav, const float* robot_slope,
+                                 int n_paths, const int* pose_offset, const double* poses, int n_points,
+                                 const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
+                                 double* traversability, double* area, int* status);
 
 #ifdef __cplusplus
 }

@@ -38,8 +38,29 @@ def py_line(si, sj, ei, ej):
     return cells
 
 
-def py_check_path(g, fp, default, poses):
-    """checkCircularFootprintPath on a complete footprint layer (memo branch of isTraversable)."""
+def py_inclination(g, rs, sx, sy, ex, ey):
+    """checkInclination(start, end) :748-762 -> (ok, outside)."""
+    if ex == sx and ey == sy:
+        ok, inside, i, j = py_index(g, sx, sy)
+        if not ok:
+            return False, True
+        return not (float(rs[j * g.rows + i]) == 0.0), False
+    ok_s, _, si, sj = py_index(g, sx, sy)
+    ok_e, _, ei, ej = py_index(g, ex, ey)
+    if not (ok_s and ok_e):
+        return False, True
+    for a, b in py_line(si, sj, ei, ej):  # from the start index to the end index
+        v = float(rs[b * g.rows + a])
+        if not math.isfinite(v):
+            continue
+        if v == 0.0:
+            return False, False
+    return True, False
+
+
+def py_check_path(g, fp, default, poses, rs=None):
+    """checkCircularFootprintPath on a complete footprint layer (memo branch of isTraversable); rs: the layer
+    robot_slope when footprint/check_robot_inclination is set."""
     n = len(poses)
     if n == 0:
         return False, 0.0, 2
@@ -48,6 +69,10 @@ def py_check_path(g, fp, default, poses):
     for i in range(n):
         sx, sy = ex, ey
         ex, ey = float(poses[i][0]), float(poses[i][1])
+        if rs is not None and (n == 1 or i > 0):
+            good, outside = py_inclination(g, rs, ex, ey, ex, ey) if n == 1 else py_inclination(g, rs, sx, sy, ex, ey)
+            if not good:
+                return False, 0.0, int(outside)
         if n == 1:
             ok, inside, ci, cj = py_index(g, ex, ey)
             t = float(fp[cj * g.rows + ci]) if inside else default

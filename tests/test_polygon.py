@@ -292,7 +292,8 @@ def py_area(v):
     return abs(area / 2.0)
 
 
-def py_check_polygon_path(g, untrav, trav, default, poses, points, conservative):
+def py_check_polygon_path(g, untrav, trav, default, poses, points, conservative, rs=None):
+    from tests.test_paths import py_inclination
     n = len(poses)
     if n == 0:
         return False, 0.0, 0.0, 2
@@ -313,6 +314,10 @@ def py_check_polygon_path(g, untrav, trav, default, poses, points, conservative)
             v1, v2 = list(poly1), list(poly2)
             poly2 += [(vx + dx, vy + dy) for vx, vy in v1]
             poly1 += [(vx - dx, vy - dy) for vx, vy in v2]
+        if rs is not None and (n == 1 or i > 0):  # checkRobotInclination_ :526-528, :553-557
+            good, outside = py_inclination(g, rs, ex, ey, ex, ey) if n == 1 else py_inclination(g, rs, sx, sy, ex, ey)
+            if not good:
+                return False, res_t, res_a, int(outside)
         if n == 1:
             ok, t = py_polygon(g, untrav, trav, default, poly2)
             if not ok:

@@ -18,7 +18,7 @@ TE_ERR_INVALID_ARG, TE_ERR_BAD_PARAM, TE_ERR_NOT_READY, TE_ERR_HIP, TE_ERR_NO_DE
 LAYERS = dict(elevation=0, traversability_slope=1, traversability_step=2, traversability_roughness=3,
               traversability=4, traversability_footprint=5, surface_normal_x=6, surface_normal_y=7,
               surface_normal_z=8, slope_footprint=9, step_footprint=10, roughness_footprint=11,
-              traversability_x=12, traversability_rot=13)
+              traversability_x=12, traversability_rot=13, robot_slope=14)
 FILTERS = dict(slope=1, step=2, roughness=3, combine=4, normals=5)
 RUN_KEEP_NORMALS = 0x1
 RUN_FOOTPRINT = 0x2
@@ -36,7 +36,8 @@ SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_cre
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
            "te_bag_write", "te_run_polygon_footprint", "te_polygons_traversable",
            "te_check_polygon_footprint_paths", "te_pin_host", "te_unpin_host", "te_path_polygons",
-           "te_shard_range", "te_bcast_params", "te_run_chain_multi", "te_sync_multi"]
+           "te_shard_range", "te_bcast_params", "te_run_chain_multi", "te_sync_multi",
+           "te_set_check_robot_inclination", "te_check_inclination", "te_polygon_untraversable_hull"]
 MSG_MAX_NAME = 64
 
 
@@ -134,6 +135,10 @@ def load():
         L.te_run_chain.argtypes = [vp, C.c_uint]
         L.te_run_chain_region.argtypes = [vp, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_run_footprint.argtypes = [vp]
+        L.te_polygon_untraversable_hull.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ubyte),
+                                                    C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.te_set_check_robot_inclination.argtypes = [vp, C.c_int]
+        L.te_check_inclination.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
         L.te_check_footprint_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                C.POINTER(C.c_ubyte), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.te_run_polygon_footprint.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_double]
@@ -406,6 +411,30 @@ class Context:
                                                trav.ctypes.data_as(C.POINTER(C.c_double)),
                                                st.ctypes.data_as(C.POINTER(C.c_int))))
         return safe[:n].astype(bool), trav[:n], st[:n]
+
+    def polygon_untraversable_hull(self, polygon, map_index=0, cap=4096):
+        """isTraversable(polygon, computeUntraversablePolygon=True): (is_traversable, traversability, hull (k, 2))."""
+        v = np.ascontiguousarray(polygon, dtype=np.float64).reshape(-1, 2)
+        ok, val, nh = C.c_ubyte(), C.c_double(), C.c_int()
+        hull = np.zeros((max(cap, 1), 2), np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(load().te_polygon_untraversable_hull(self._h, int(map_index), len(v), v.ctypes.data_as(dp), C.byref(ok),
+                                                    C.byref(val), int(cap), C.byref(nh), hull.ctypes.data_as(dp)))
+        return bool(ok.value), val.value, hull[:nh.value].copy()
+
+    def set_check_robot_inclination(self, enabled):
+        """footprint/check_robot_inclination: the path checks then run checkInclination on the layer robot_slope."""
+        _check(load().te_set_check_robot_inclination(self._h, int(bool(enabled))))
+
+    def check_inclination(self, segments, map_index=0):
+        """Batched TraversabilityMap::checkInclination: segments (n, 4) = start x y, end x y -> (ok[bool], status)."""
+        seg = np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 4)
+        n = len(seg)
+        ok = np.zeros(max(n, 1), np.uint8)
+        st = np.zeros(max(n, 1), np.int32)
+        _check(load().te_check_inclination(self._h, int(map_index), n, seg.ctypes.data_as(C.POINTER(C.c_double)),
+                                           ok.ctypes.data_as(C.POINTER(C.c_ubyte)), st.ctypes.data_as(C.POINTER(C.c_int))))
+        return ok[:n].astype(bool), st[:n]
 
     def upload_msg(self, msg, layer_name="elevation", layer="elevation"):
         """fromMessage + upload: geometry from the message, layer `layer_name` into device layer `layer`."""

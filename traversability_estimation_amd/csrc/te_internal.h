@@ -114,6 +114,12 @@ hipError_t launch_polygons_traversable(const Geo& g, double def, int n_polygons,
                                        const float* trav, const uint8_t* untrav, unsigned char* is_traversable,
                                        double* traversability, hipStream_t stream);
 
+// isTraversable(polygon, computeUntraversablePolygon = true): per row index of the map (x, y first, y last, y between,
+// count) of the polygon's untraversable cells (rows5: 5 doubles x g.rows), and the hull the host builds from them
+hipError_t launch_polygon_untraversable_rows(const Geo& g, int n, const double* vertex_xy, const uint8_t* untrav, double* rows5,
+                                             hipStream_t stream);
+void untraversable_hull_from_rows(int rows, const double* rows5, std::vector<double>& hull_xy);
+
 // the polygons checkPolygonalFootprintPath evaluates for a batch of paths (host side), in path order
 constexpr int kMaxPathPolygonVertices = 1024;
 struct PathPolygons {
@@ -146,10 +152,14 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
                             const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
-// te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map
-hipError_t launch_check_circular_paths(const Geo& g, const float* footprint, double fp_default, int n_paths,
-                                       const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
+// te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map;
+// robot_slope: the layer checkInclination reads (nullptr: footprint/check_robot_inclination off)
+hipError_t launch_check_circular_paths(const Geo& g, const float* footprint, double fp_default, const float* robot_slope,
+                                       int n_paths, const int* pose_offset, const double* pose_xy, unsigned char* is_safe,
                                        double* traversability, int* status, hipStream_t stream);
+// batched checkInclination(start, end): segment k = start_end_xy[4k .. 4k+4)
+hipError_t launch_check_inclination(const Geo& g, const float* robot_slope, int n, const double* start_end_xy,
+                                    unsigned char* ok, int* status, hipStream_t stream);
 
 // shape-specialised kernels (te_fast_*.hip); return false when the shape Q is not instantiated
 namespace fast {

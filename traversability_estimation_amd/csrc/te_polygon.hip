@@ -309,6 +309,54 @@ __global__ __launch_bounds__(256) void k_polygons_traversable(Geo g, double def,
   }
 }
 
+// isTraversable(polygon, computeUntraversablePolygon = true, ..) :592-645: the untraversable polygon is the convex hull of the
+// positions of the polygon's untraversable cells.  Cells of one row index share x, so only a row's first and last such
+// cell can be hull vertices (the cells between are popped by monotoneChainConvexHullOfPoints with a cross product of
+// exactly 0): one wavefront per row of the bounding box reduces the row to (x, y of the first, y of the last, y of the
+// one between when there are three, count); the host runs the chain over those.  rows5[5 * i ..]: row index i.
+__global__ __launch_bounds__(256) void k_polygon_untraversable_rows(Geo g, int n, const double* __restrict__ v,
+                                                                   const uint8_t* __restrict__ untrav,
+                                                                   double* __restrict__ rows5) {
+  const int lane = threadIdx.x & 63;
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a >= g.rows) return;  // the whole wavefront
+  auto vert = [&](int m, double& x, double& y) {
+    x = v[2 * m];
+    y = v[2 * m + 1];
+  };
+  int ti, bi, tj, bj;
+  polygon_bbox(g, n, vert, ti, bi, tj, bj);
+  int lo = 0x7fffffff, hi = -1, cnt = 0, sum = 0;
+  if (a >= ti && a <= bi) {
+    const double px = cell_x(g, a);
+    for (int b = tj + lane; b <= bj; b += 64) {
+      if (!untrav[(size_t)b * g.rows + a]) continue;
+      if (!polygon_inside(n, vert, px, cell_y(g, b))) continue;
+      lo = b < lo ? b : lo;
+      hi = b > hi ? b : hi;
+      cnt++;
+      sum += b;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+    cnt += __shfl_xor(cnt, d);
+    sum += __shfl_xor(sum, d);
+  }
+  if (lane != 0) return;
+  double* o = rows5 + 5 * (size_t)a;
+  o[4] = (double)cnt;
+  if (cnt > 0) {
+    o[0] = cell_x(g, a);
+    o[1] = cell_y(g, lo);
+    o[2] = cell_y(g, hi);
+    o[3] = cell_y(g, cnt == 3 ? sum - lo - hi : lo);
+  }
+}
+
 }  // namespace
 
 // The rotation part of  toPosition * orientation * positionToVertex  (TraversabilityMap.cpp:250-283) for a yaw-only
@@ -333,12 +381,9 @@ struct P2 {
 };
 
 // grid_map::Polygon::monotoneChainConvexHullOfPoints (sortVertices: x then y; vectorsMakeClockwiseTurn: cross <= 0)
-void convex_hull(const std::vector<P2>& points, std::vector<P2>& hull) {
+// the chain proper (sort, lower hull, upper hull) for n >= 2 points
+void monotone_chain(const std::vector<P2>& points, std::vector<P2>& hull) {
   const size_t n = points.size();
-  if (n <= 3) {
-    hull = points;
-    return;
-  }
   std::vector<P2> sorted(points);
   std::sort(sorted.begin(), sorted.end(), [](const P2& a, const P2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
   auto clockwise = [](const P2& o, const P2& a, const P2& b) {
@@ -356,6 +401,14 @@ void convex_hull(const std::vector<P2>& points, std::vector<P2>& hull) {
     hull[k++] = sorted[i];
   }
   hull.resize(k - 1);
+}
+
+void convex_hull(const std::vector<P2>& points, std::vector<P2>& hull) {
+  if (points.size() <= 3) {
+    hull = points;
+    return;
+  }
+  monotone_chain(points, hull);
 }
 
 double polygon_area(const std::vector<P2>& v) {  // Polygon::getArea
@@ -546,6 +599,37 @@ hipError_t launch_polygon_footprint(const Geo& g, const PolygonArgs& a, const fl
   hipLaunchKernelGGL(k_polygon_footprint, dim3((unsigned)((g.rows + 255) / 256), (unsigned)g.cols, (unsigned)g.batch), dim3(256),
                      0, stream, g, a, trav, untrav, out_x, out_rot);
   return hipGetLastError();
+}
+
+hipError_t launch_polygon_untraversable_rows(const Geo& g, int n, const double* vertex_xy, const uint8_t* untrav, double* rows5,
+                                             hipStream_t stream) {
+  hipLaunchKernelGGL(k_polygon_untraversable_rows, dim3((unsigned)((g.rows + 3) / 4)), dim3(256), 0, stream, g, n, vertex_xy,
+                     untrav, rows5);
+  return hipGetLastError();
+}
+
+// host half: the hull over what k_polygon_untraversable_rows left (rows5, g.rows entries)
+void untraversable_hull_from_rows(int rows, const double* rows5, std::vector<double>& hull_xy) {
+  std::vector<P2> pts, hull;
+  long total = 0;
+  for (int a = 0; a < rows; ++a) total += (long)rows5[5 * (size_t)a + 4];
+  for (int a = 0; a < rows; ++a) {  // PolygonIterator order: row index outer, column index ascending
+    const double* r = rows5 + 5 * (size_t)a;
+    const int cnt = (int)r[4];
+    if (cnt <= 0) continue;
+    pts.push_back(P2{r[0], r[1]});
+    if (cnt == 3 && total <= 3) pts.push_back(P2{r[0], r[3]});
+    if (cnt >= 2) pts.push_back(P2{r[0], r[2]});
+  }
+  if (total <= 3)
+    hull = pts;  // monotoneChainConvexHullOfPoints' "points.size() <= 3": Polygon(points) as collected
+  else
+    monotone_chain(pts, hull);  // more than three cells, even when they sit in one or two rows: sorted, collinear ones dropped
+  hull_xy.clear();
+  for (const P2& q : hull) {
+    hull_xy.push_back(q.x);
+    hull_xy.push_back(q.y);
+  }
 }
 
 hipError_t launch_polygons_traversable(const Geo& g, double def, int n_polygons, const int* vertex_offset, const double* vertex_xy,

@@ -123,6 +123,8 @@ struct te_ctx {
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
   float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
   float* poly_rot = nullptr;
+  float* robot_slope = nullptr;  // layer robot_slope (checkInclination); allocated by its first upload, NaN until written
+  bool have_robot_slope = false, check_inclination = false;  // footprint/check_robot_inclination (:114)
   unsigned* poly_stream = nullptr;        // offset tables of the two footprint polygons (device copy)
   size_t poly_stream_cap = 0;             // in words
   std::vector<unsigned> poly_stream_host;  // stays alive until the asynchronous upload has been consumed
@@ -318,6 +320,9 @@ void free_layers(te_ctx* c) {
   if (c->poly_stream) (void)hipFree(c->poly_stream);
   c->poly_stream = nullptr;
   c->poly_stream_cap = 0;
+  if (c->robot_slope) (void)hipFree(c->robot_slope);
+  c->robot_slope = nullptr;
+  c->have_robot_slope = false;
   memset(&c->L, 0, sizeof(c->L));
   c->layer_elems = 0;
   c->have_elev = false;
@@ -341,8 +346,24 @@ float* layer_ptr(te_ctx* c, int layer) {
     case TE_LAYER_ROUGHNESS_FOOTPRINT: return c->L.rough_fp;
     case TE_LAYER_TRAVERSABILITY_X: return c->poly_x;
     case TE_LAYER_TRAVERSABILITY_ROT: return c->poly_rot;
+    case TE_LAYER_ROBOT_SLOPE: return c->robot_slope;
     default: return nullptr;
   }
+}
+
+// the optional input layer robot_slope exists from its first upload on (every cell NaN = not valid until written)
+int ensure_input_layer(te_ctx* c, int layer) {
+  if (layer != TE_LAYER_ROBOT_SLOPE || c->robot_slope) return TE_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, c->layer_elems * sizeof(float)));
+  const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)p, 0x7fc00000, c->layer_elems, c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(TE_ERR_HIP, "robot_slope layer: %s", hipGetErrorString(e));
+  }
+  c->robot_slope = (float*)p;
+  return TE_OK;
 }
 
 int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
@@ -690,6 +711,8 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   if (!c || !dptr) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: NULL");
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_device_ptr: geometry not set");
+  if (const int rc = ensure_input_layer(c, layer)) return rc;
+  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;  // the caller fills it in place
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
   *dptr = p;
@@ -707,6 +730,7 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
   if (layer == TE_LAYER_ELEVATION) return te_upload_elevation(c, host, map0, nmaps);
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer: geometry not set");
+  if (const int rc = ensure_input_layer(c, layer)) return rc;
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: bad layer %d", layer);
   if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
@@ -715,6 +739,7 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
   HIP_TRY(hipMemcpyAsync(p + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
   return TE_OK;
 }
 
@@ -762,6 +787,7 @@ static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host
   if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
     return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
                 c->geo.cols, expect_rows, expect_cols);
+  if (const int rc = ensure_input_layer(c, layer)) return rc;
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: bad layer %d", layer);
   if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
@@ -774,6 +800,7 @@ static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host
     c->chain_done = false;
     c->footprint_done = false;
   }
+  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
   return TE_OK;
 }
 
@@ -957,6 +984,8 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: run the chain with the footprint pass first");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: map %d of %d", map, c->geo.batch);
+  if (c->check_inclination && !c->have_robot_slope)
+    return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: check_robot_inclination is set but the layer robot_slope was never uploaded");
   if (n_paths == 0) return TE_OK;
   const int n_poses = pose_offset[n_paths];
   if (pose_offset[0] != 0 || n_poses < 0) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: bad pose offsets");
@@ -978,7 +1007,8 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
   if (e == hipSuccess && n_poses > 0) e = hipMemcpyAsync(d_xy, pose_xy, (size_t)2 * n_poses * sizeof(double), hipMemcpyHostToDevice, c->stream);
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
   if (e == hipSuccess)
-    e = launch_check_circular_paths(c->geo, c->L.footprint + per * map, c->params.fp_default, n_paths, d_off, d_xy, d_safe,
+    e = launch_check_circular_paths(c->geo, c->L.footprint + per * map, c->params.fp_default,
+                                    c->check_inclination ? c->robot_slope + per * map : nullptr, n_paths, d_off, d_xy, d_safe,
                                     d_trav, d_st, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(is_safe, d_safe, b_safe, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
@@ -987,6 +1017,47 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
   (void)hipFree(d);
   if (e != hipSuccess) return fail(TE_ERR_HIP, "te_check_footprint_paths: %s", hipGetErrorString(e));
   return TE_OK;
+}
+
+int te_set_check_robot_inclination(te_ctx* c, int enabled) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_check_robot_inclination: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->check_inclination = enabled != 0;
+  return TE_OK;
+}
+
+namespace {
+// batched checkInclination on the resident robot_slope layer of map `map`; c->mu held
+int check_inclination_locked(te_ctx* c, int map, int n, const double* start_end_xy, unsigned char* ok, int* status,
+                             const char* who) {
+  if (!c->have_geo || !c->have_robot_slope) return fail(TE_ERR_NOT_READY, "%s: upload the layer robot_slope first", who);
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "%s: map %d of %d", who, map, c->geo.batch);
+  if (n == 0) return TE_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t b_seg = (size_t)4 * n * sizeof(double), b_ok = (size_t)n, b_st = (size_t)n * sizeof(int);
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, up(b_seg) + up(b_st) + up(b_ok)));
+  double* d_seg = (double*)d;
+  int* d_st = (int*)(d + up(b_seg));
+  unsigned char* d_ok = (unsigned char*)(d + up(b_seg) + up(b_st));
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  hipError_t e = hipMemcpyAsync(d_seg, start_end_xy, b_seg, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_check_inclination(c->geo, c->robot_slope + per * map, n, d_seg, d_ok, d_st, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ok, d_ok, b_ok, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, b_st, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+  return TE_OK;
+}
+}  // namespace
+
+int te_check_inclination(te_ctx* c, int map, int n_segments, const double* start_end_xy, unsigned char* ok, int* status) {
+  if (!c || n_segments < 0 || (n_segments > 0 && (!start_end_xy || !ok || !status)))
+    return fail(TE_ERR_INVALID_ARG, "te_check_inclination: NULL argument");
+  std::lock_guard<std::mutex> lk(c->mu);
+  return check_inclination_locked(c, map, n_segments, start_end_xy, ok, status, "te_check_inclination");
 }
 
 int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, double yaw) {
@@ -1095,6 +1166,46 @@ int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* verte
                                      "te_polygons_traversable");
 }
 
+int te_polygon_untraversable_hull(te_ctx* c, int map, int n_vertices, const double* vertex_xy, unsigned char* is_traversable,
+                                  double* traversability, int cap_vertices, int* n_hull, double* hull_xy) {
+  if (!c || !vertex_xy || !is_traversable || !traversability || !n_hull || cap_vertices < 0 || (cap_vertices > 0 && !hull_xy))
+    return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: NULL argument");
+  if (n_vertices < 1) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: a polygon needs at least one vertex");
+  for (long k = 0; k < 2L * n_vertices; ++k)
+    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: vertex %ld is not finite", k / 2);
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_geo || !c->footprint_done)
+    return fail(TE_ERR_NOT_READY, "te_polygon_untraversable_hull: run the chain with the footprint pass first (it marks the untraversable cells)");
+  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: map %d of %d", map, c->geo.batch);
+  *n_hull = 0;
+  const int off[2] = {0, n_vertices};
+  const int rc = polygons_traversable_locked(c, map, 1, off, vertex_xy, is_traversable, traversability, "te_polygon_untraversable_hull");
+  if (rc != TE_OK || *is_traversable) return rc;  // :635-636 traversable: the empty polygon
+  // untraversable: the rows of the bounding box that hold untraversable cells, then the hull on the host
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t b_xy = (size_t)2 * n_vertices * sizeof(double), b_rows = (size_t)5 * c->geo.rows * sizeof(double);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, up(b_xy) + b_rows));
+  double* d_xy = (double*)d;
+  double* d_rows = (double*)(d + up(b_xy));
+  std::vector<double> rows5((size_t)5 * c->geo.rows);
+  const size_t per = (size_t)c->geo.rows * c->geo.cols;
+  hipError_t e = hipMemcpyAsync(d_xy, vertex_xy, b_xy, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_polygon_untraversable_rows(c->geo, n_vertices, d_xy, c->L.untrav + per * map, d_rows, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(rows5.data(), d_rows, b_rows, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_polygon_untraversable_hull: %s", hipGetErrorString(e));
+  std::vector<double> hull;
+  untraversable_hull_from_rows(c->geo.rows, rows5.data(), hull);
+  *n_hull = (int)(hull.size() / 2);
+  if (*n_hull > cap_vertices)
+    return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: the hull has %d vertices, room for %d", *n_hull, cap_vertices);
+  if (!hull.empty()) memcpy(hull_xy, hull.data(), hull.size() * sizeof(double));
+  return TE_OK;
+}
+
 int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
                                      const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
                                      double* traversability, double* area, int* status) {
@@ -1109,6 +1220,8 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: run the chain with the footprint pass first (it marks the untraversable cells)");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: map %d of %d", map, c->geo.batch);
+  if (c->check_inclination && !c->have_robot_slope)
+    return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: check_robot_inclination is set but the layer robot_slope was never uploaded");
   if (n_paths == 0) return TE_OK;
   if (pose_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
   for (int k = 0; k < n_paths; ++k)
@@ -1129,6 +1242,30 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
       });
     build_path_polygons(first_of(1), pose_offset, poses, n_points, points_xyz, conservative, chunk[0]);
     for (std::thread& w : workers) w.join();
+  }
+  // checkRobotInclination_ (:526-528, :553-557): one checkInclination per pose of a one-pose path / per segment
+  // otherwise, all of them in one launch; incl_first[k] = index of path k's first test
+  std::vector<unsigned char> incl_ok;
+  std::vector<int> incl_st, incl_first;
+  if (c->check_inclination) {
+    incl_first.assign((size_t)n_paths + 1, 0);
+    std::vector<double> seg;
+    for (int k = 0; k < n_paths; ++k) {
+      const int n = pose_offset[k + 1] - pose_offset[k];
+      const double* q = poses + 7 * (size_t)pose_offset[k];
+      if (n == 1) {
+        seg.insert(seg.end(), {q[0], q[1], q[0], q[1]});
+      } else {
+        for (int i = 1; i < n; ++i) seg.insert(seg.end(), {q[7 * (i - 1)], q[7 * (i - 1) + 1], q[7 * i], q[7 * i + 1]});
+      }
+      incl_first[k + 1] = (int)(seg.size() / 4);
+    }
+    const int n_seg = incl_first[n_paths];
+    incl_ok.assign(n_seg > 0 ? n_seg : 1, 0);
+    incl_st.assign(n_seg > 0 ? n_seg : 1, 0);
+    const int rc = check_inclination_locked(c, map, n_seg, seg.data(), incl_ok.data(), incl_st.data(),
+                                            "te_check_polygon_footprint_paths");
+    if (rc != TE_OK) return rc;
   }
   std::vector<unsigned char> ok;
   std::vector<double> val;
@@ -1154,6 +1291,11 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
       bool good = true;
       for (int s = 0; s < pp.count[kk] && good; ++s) {
         const int g = pp.first[kk] + s;
+        if (c->check_inclination && !incl_ok[incl_first[k] + s]) {  // before isTraversable (:553-557); the partial result stays
+          status[k] = incl_st[incl_first[k] + s];
+          good = false;
+          break;
+        }
         if (!ok[g]) {
           good = false;
           break;

@@ -35,7 +35,10 @@ class TraversabilityMap {
   /*! footprint/footprint_polygon (TraversabilityMap.cpp:91-103). */
   void setFootprintPolygon(const std::vector<geometry_msgs::Point32>& points) { footprintPoints_ = points; }
 
-  /*! setElevationMap (:135-154): needs the layer "elevation"; any start index. */
+  /*! footprint/check_robot_inclination (:114): checkFootprintPath then runs checkInclination (:748-762) on the layer
+   *  "robot_slope" of the elevation map handed to setElevationMap (the path checks fail if it had none). */
+  bool setCheckRobotInclination(bool enabled);
+  /*! setElevationMap (:135-154): needs the layer "elevation"; any start index.  A layer "robot_slope" goes along. */
   bool setElevationMap(const grid_map::GridMap& elevationMap);
   /*! computeTraversability (:202-237): the filter chain; false if no elevation map has been set. */
   bool computeTraversability();
@@ -64,6 +67,7 @@ class TraversabilityMap {
   std::vector<geometry_msgs::Point32> footprintPoints_;
   grid_map::GridMap geometry_;  // geometry and start index of the last elevation map (no layers)
   bool elevationMapInitialized_, traversabilityMapInitialized_, footprintLayer_, polygonLayers_;
+  bool checkRobotInclination_, robotSlopeLayer_;
   double footprintRadius_, footprintOffset_;
   double circularFootprintOffset_;  // :348 "TODO: get this with FootprintPath msg" = 0.15
   std::string error_;

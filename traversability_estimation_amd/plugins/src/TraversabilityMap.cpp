@@ -13,6 +13,8 @@ TraversabilityMap::TraversabilityMap(int device)
       traversabilityMapInitialized_(false),
       footprintLayer_(false),
       polygonLayers_(false),
+      checkRobotInclination_(false),
+      robotSlopeLayer_(false),
       footprintRadius_(-1.0),
       footprintOffset_(-1.0),
       circularFootprintOffset_(0.15) {
@@ -40,6 +42,13 @@ bool TraversabilityMap::setParameters(const te_params& params) {
   return true;
 }
 
+bool TraversabilityMap::setCheckRobotInclination(bool enabled) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (!ctx_ || !check(te_set_check_robot_inclination(ctx_, enabled ? 1 : 0))) return false;
+  checkRobotInclination_ = enabled;
+  return true;
+}
+
 bool TraversabilityMap::setElevationMap(const grid_map::GridMap& elevationMap) {
   std::lock_guard<std::mutex> lock(mutex_);
   if (!ctx_) return false;
@@ -53,6 +62,12 @@ bool TraversabilityMap::setElevationMap(const grid_map::GridMap& elevationMap) {
     return false;
   const auto start = elevationMap.getStartIndex();
   if (!check(te_upload_layer_circular(ctx_, TE_LAYER_ELEVATION, elevationMap.get("elevation").data(), 0, start(0), start(1))))
+    return false;
+  // robot_slope (robotSlopeType_ :47) is nowhere computed by the reference: checkInclination reads it off whatever map
+  // the node was handed, so it travels with the elevation map when it is there
+  robotSlopeLayer_ = elevationMap.exists("robot_slope");
+  if (robotSlopeLayer_ &&
+      !check(te_upload_layer_circular(ctx_, TE_LAYER_ROBOT_SLOPE, elevationMap.get("robot_slope").data(), 0, start(0), start(1))))
     return false;
   geometry_ = grid_map::GridMap();
   geometry_.setGeometry(elevationMap.getLength(), elevationMap.getResolution(), elevationMap.getPosition());

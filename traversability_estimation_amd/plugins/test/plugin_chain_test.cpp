@@ -421,6 +421,59 @@ static void test_traversability_map() {
   std::printf("  checkFootprintPaths: %zu paths, %d safe, %d mismatches\n", paths.size(), n_safe, n_bad);
   CHECK(n_bad == 0);
   CHECK(n_safe > 5 && n_safe < (int)paths.size() - 5);
+  // footprint/check_robot_inclination (:114): the layer robot_slope travels with the elevation map
+  {
+    std::vector<float> rs(n, 1.0f);
+    for (size_t k = 0; k < n; ++k) {
+      const double u = rnd();
+      if (u < 0.004) rs[k] = 0.0f;
+      else if (u < 0.05) rs[k] = NAN;
+    }
+    grid_map::GridMap flat2 = flat;
+    flat2.add("robot_slope");
+    std::memcpy(flat2["robot_slope"].data(), rs.data(), n * 4);
+    CHECK(tm.setCheckRobotInclination(true));
+    CHECK(!tm.checkFootprintPaths(paths, results));  // no such layer on the device yet: refused, not skipped
+    CHECK(tm.setElevationMap(rolled(flat2, si, sj)) && tm.computeTraversability());
+    CHECK(tm.checkFootprintPaths(paths, results) && results.size() == paths.size());
+    int n_safe_incl = 0, n_bad_incl = 0;
+    for (size_t k = 0; k < paths.size() && k < results.size(); ++k) {
+      const int np = (int)paths[k].poses.poses.size();
+      const int off[2] = {0, np};
+      unsigned char safe = 0;
+      double trav = 0, area = 0;
+      int status = 0;
+      if (paths[k].footprint.polygon.points.empty()) {
+        teo_params q = p;
+        q.fp_radius = paths[k].radius;
+        q.fp_offset = 0.15;
+        std::vector<float> layer(n);
+        teo_footprint(&g, &q, elev, sl.data(), st.data(), ro.data(), tr.data(), layer.data(), nullptr, nullptr, nullptr);
+        std::vector<double> xy;
+        for (const auto& pose : paths[k].poses.poses) {
+          xy.push_back(pose.position.x);
+          xy.push_back(pose.position.y);
+        }
+        teo_check_circular_paths_incl(&g, layer.data(), q.fp_default, rs.data(), 1, off, xy.data(), &safe, &trav, &status);
+      } else {
+        std::vector<double> poses;
+        for (const auto& pose : paths[k].poses.poses) {
+          const double v[7] = {pose.position.x,    pose.position.y,    pose.position.z,   pose.orientation.x,
+                               pose.orientation.y, pose.orientation.z, pose.orientation.w};
+          poses.insert(poses.end(), v, v + 7);
+        }
+        teo_check_polygon_paths_incl(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), rs.data(), 1, off, poses.data(),
+                                     4, foot3, &paths[k].conservative, &safe, &trav, &area, &status);
+      }
+      if (results[k].is_safe != safe || results[k].traversability != trav || results[k].area != area) ++n_bad_incl;
+      n_safe_incl += safe;
+    }
+    std::printf("  checkFootprintPaths with check_robot_inclination: %d safe (of %d without), %d mismatches\n", n_safe_incl,
+                n_safe, n_bad_incl);
+    CHECK(n_bad_incl == 0);
+    CHECK(n_safe_incl > 0 && n_safe_incl < n_safe);
+    CHECK(tm.setCheckRobotInclination(false));
+  }
   // a request with a path without poses stops there (TraversabilityEstimation.cpp:290)
   paths[4].poses.poses.clear();
   CHECK(!tm.checkFootprintPaths(paths, results) && results.size() == 4);
