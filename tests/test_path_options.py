@@ -10,6 +10,13 @@ from tests.test_polygon import (POINTS_XYZ, chain_layers, gpu_setup, py_check_po
                                 untraversable_mask)
 
 
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    return capi
+
+
 def robot_slope_layer(rng, g, zero_fraction=0.004, nan_fraction=0.05):
     """What an inclination estimator leaves behind: mostly 1, a few 0 (too steep for the robot), holes."""
     rs = np.ones(g.rows * g.cols, np.float32)
