@@ -16,6 +16,8 @@
 //             lane walks the host-built spiral table (SpiralIterator order) over the rows already staged
 //             in LDS until the first untraversable cell, exactly like isTraversable().
 #include "te_internal.h"
+
+#include <cstdlib>
 #include "te_geom.h"
 #include "te_march.h"
 
@@ -63,18 +65,18 @@ __device__ __forceinline__ bool submap_fails(const Geo& g, int edge_fail, int a,
          ((edge_fail & 8) && b == g.cols - 1);
 }
 
-// A layer seen through the LDS tile of the block (64x32 cells + halo); cells outside the tile are
+// A layer seen through the LDS tile of the block (64 x MY cells + halo, MY = 32 or 8); cells outside the tile are
 // read from global memory (only the rare long Bresenham walks of checkForStep leave the tile).
-constexpr int MX = 64, MY = 32, MBY = 4, MH = 3;  // tile, threads along j, halo (>= reach of both windows + 1)
-constexpr int MTW = MX + 2 * MH, MTH = MY + 2 * MH;
+constexpr int MX = 64, MBY = 4, MH = 3;  // tile width, threads along j, halo (>= reach of both windows + 1)
+constexpr int MTW = MX + 2 * MH;
 
 struct TileView {
   const float* lds;
   const float* glob;
-  int i0, j0, rows;
+  int i0, j0, rows, th;  // th: rows of the tile (MY + 2 * MH)
   __device__ __forceinline__ float at(int a, int b) const {
     const int la = a - i0 + MH, lb = b - j0 + MH;
-    if (lds && (unsigned)la < (unsigned)MTW && (unsigned)lb < (unsigned)MTH) return lds[lb * MTW + la];
+    if (lds && (unsigned)la < (unsigned)MTW && (unsigned)lb < (unsigned)th) return lds[lb * MTW + la];
     return glob[(size_t)b * rows + a];
   }
 };
@@ -248,7 +250,10 @@ struct MaskArgs {
   float w_scale, w_slope, w_step, w_rough;
 };
 
-// isTraversableForFilters :774-792 for every cell of a 64x16 tile
+// isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
+// for maps too small to fill the GPU with 64 x 32 tiles: a thread's cells that need the full checkForStep are serial,
+// and on the reference's own 100 x 133 map (where half of the cells do) ten workgroups took 0.32 ms.
+template <int MY>
 __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
                                                      const float* __restrict__ slope, const float* __restrict__ step,
                                                      const float* __restrict__ rough, uint8_t* __restrict__ untrav,
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // t_elev = elevation; t_key / t_kl: see check_step_screen (NaN outside the map).  Slope / roughness scores
   // are only needed at the centre cell (plus, for the rare zero scores, their window): they are read
   // straight from global memory.
+  constexpr int MTH = MY + 2 * MH;
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
   const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
   const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
@@ -343,8 +349,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
   }
   __syncthreads();
-  const TileView ve = {t_elev, elev + mo, i0, j0, g.rows}, vs = {nullptr, step + mo, i0, j0, g.rows},
-                 vl = {nullptr, slope + mo, i0, j0, g.rows}, vr = {nullptr, rough + mo, i0, j0, g.rows};
+  const TileView ve = {t_elev, elev + mo, i0, j0, g.rows, MTH}, vs = {nullptr, step + mo, i0, j0, g.rows, MTH},
+                 vl = {nullptr, slope + mo, i0, j0, g.rows, MTH}, vr = {nullptr, rough + mo, i0, j0, g.rows, MTH};
   if (i >= g.rows) return;
   // Every thread walks MY/MBY consecutive rows of its column.  For the 21-cell window of circle(2.5*res)
   // (di^2+dj^2 <= 5: rows dj=0,+-1 span |di|<=2, rows dj=+-2 span |di|<=1) the two window maxima slide:
@@ -463,6 +469,7 @@ struct SpiralArgs {
 // both the per-cell value and the disc sum  sum(T') + kUOff * sum(U)  are exact in double and split
 // back exactly:  sum(U) = floor((S + kUOff/2) / kUOff).
 constexpr double kUOff = 4096.0;
+constexpr int kFpHead = 24;  // spiral entries every lane walks on its own before the wavefront takes the long walks over
 constexpr int kFpWaves = 2;  // waves per SIMD k_fp_slide is compiled for; the launcher fills exactly these slots
 
 // Q >= 0: the (tie-free) disc shape is the compile-time shape fast::Shape<Q> (R == Shape<Q>::R): the ring
@@ -518,9 +525,20 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     }
   };
 
+  // the spiral table, entry ch * 64 + lane in register ch of lane `lane` (the wavefront-wide walk below)
+  constexpr bool kRegTab = R <= 16;
+  constexpr int NTAB = kRegTab ? (int)(3.2 * (R + 1) * (R + 1) / kLanes) + 1 : 1;  // >= cells of a disc of radius R + 1
+  unsigned tabreg[NTAB];
+  if (kRegTab) {
+    const unsigned* __restrict__ ptab0 = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);
+#pragma unroll
+    for (int ch = 0; ch < NTAB; ++ch) tabreg[ch] = ch * kLanes + lane < a.n_spiral ? ptab0[ch * kLanes + lane] : 0u;
+  }
+
   double S = 0.0;
-  constexpr int WU = ((2 * R + 1 + kAhead - 1) / kAhead) * kAhead;  // warm-up steps: whole groups of kAhead
-  const int jstart = js - WU;
+  // The strip starts with its first disc summed directly (rows js-R .. js+1+R staged first): sliding in from an empty
+  // disc cost 2R+1 full steps per strip, which on a small map is most of the launch.
+  const int jstart = js;
   int slot_j = 0;
   // ring offsets (in doubles) of the leading (j+1+h) / trailing (j-h) row of disc column |di| = d for the
   // NEXT fetch; a column outside the tie-free disc (h < 0: only tie offsets reach it) reads the same row
@@ -604,25 +622,45 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
     slot_j = slot_j + 1 >= NR ? 0 : slot_j + 1;
   };
   Vals va, vb;
-  {  // rows <= jstart+R are virtual zeros (ring cleared); row jstart+1+R is the first real one
-    float pt0[NX];
-    int pu0[NX];
-    load_row(jstart + 1 + R, pt0, pu0);
-    store_row(jstart + 1 + R, (1 + R) % NR, pt0, pu0);
+  {  // rows js-R .. js+1+R into the slots (row - js) mod NR (slot_j == 0 belongs to row js), kAhead loads in flight
+    float pt0[kAhead][NX];
+    int pu0[kAhead][NX];
+#pragma unroll 1
+    for (int b = 0; b < 2 * R + 2; b += kAhead) {
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k)
+        if (b + k < 2 * R + 2) load_row(js - R + b + k, pt0[k], pu0[k]);
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k)
+        if (b + k < 2 * R + 2) {
+          const int sl = b + k - R;
+          store_row(js - R + b + k, sl < 0 ? sl + NR : sl, pt0[k], pu0[k]);
+        }
+    }
+    // the tie-free disc of row js, column by column (every term is exact: the same number the slide would reach)
+    auto add_column = [&](int d, int h) __attribute__((always_inline)) {
+      if (h < 0) return;
+      double col = 0.0;
+      const int dm = d ? -d : d;  // column 0 once
+#pragma unroll 8
+      for (int dj = -h; dj <= h; ++dj) {  // (unrolled: the reads of eight rows in flight, not one round trip per cell)
+        const double* row = ring + (dj < 0 ? dj + NR : dj) * W + c;
+        col += row[d];
+        col += d ? row[dm] : 0.0;
+      }
+      S += col;
+    };
+    if constexpr (kStatic) {
+      fast::static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        add_column(d, fast::Shape<Q>::hw(d));
+      });
+    } else {
+      for (int d = 0; d <= R; ++d) add_column(d, a.h[d]);
+    }
     if (kPipe) fetch(va);
   }
   static_assert(kAhead % 2 == 0, "the value buffers alternate with the queue slots");
-
-#pragma unroll 1
-  for (int j0 = jstart; j0 < js; j0 += kAhead) {  // warm-up: fill the disc
-#pragma unroll
-    for (int qs = 0; qs < kAhead; ++qs) {
-      if (qs % 2 == 0)
-        advance(j0 + qs, ptq[qs], puq[qs], vb, va);
-      else
-        advance(j0 + qs, ptq[qs], puq[qs], va, vb);
-    }
-  }
 
   int nt_next = a.gtab[(((js < R) ? (R - js) : ((g.cols - 1 - js < R) ? -(R - (g.cols - 1 - js)) : 0)) + R) * (2 * R + 1) * 6 +
                        (kx + R) * 6];
@@ -630,10 +668,11 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
   double rnt = 0.0;
 #pragma unroll 1
   for (int j0 = js; j0 < jend; j0 += kAhead) {
-#pragma unroll
-  for (int qs = 0; qs < kAhead; ++qs) {
+  // (a lambda per queue slot: a rolled loop would index the load queue dynamically and put it into scratch)
+  fast::static_for<kAhead>([&](auto qc) __attribute__((always_inline)) {
+    constexpr int qs = decltype(qc)::value;
     const int j = j0 + qs;
-    if (j >= jend) break;
+    if (j >= jend) return;
     double St = S;
     int nt = nt_next;
     if (g.rows < 2 * R + 1 || g.cols < 2 * R + 1) {
@@ -666,7 +705,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
       }
     }
     const int Ut = (int)floor((St + 0.5 * kUOff) * (1.0 / kUOff));
-    float out;
+    float out = qnanf();
     if (Ut == 0) {
       // :732-735 no untraversable cell in the footprint: mean = St / nt.  nt is constant away from the map
       // border, so the division is a multiplication by the cached RN(1/nt) plus two residual corrections
@@ -679,61 +718,121 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
       const double q0 = St * rnt;
       const double q1 = fma(fma(-q0, dn, St), rnt, q0);
       out = (float)fma(fma(-q1, dn, St), rnt, q1);
-    } else {
-      // walk the spiral until the first untraversable cell :687-717.  Eight table entries per trip, their ring cells
-      // fetched together (one entry per trip made the lane wait for a table load and an LDS read in turn)
-      double t = 0.0;
-      int ncells = 0;
-      out = qnanf();
-      bool found = false;
+    }
+    if (__builtin_expect(__any(Ut != 0), 0)) {
+      // walk the spiral until the first untraversable cell :687-717
       const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
-      for (int k0 = 0; k0 < a.n_spiral && !found; k0 += 8) {
-        double v[8];
-        bool in[8];
-        int ring_no[8];
+      auto slot_of = [&](int dj) __attribute__((always_inline)) {
+        const int sl = slot_j + dj;
+        return sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
+      };
+      auto value_at = [&](int ring_no, double t, int ncells) __attribute__((always_inline)) {
+        const double ru = (double)ring_no * g.res;  // getCurrentRadius()
+        if (a.rmin == 0.0 || ru <= a.rmin) return 0.0f;  // :694-704
+        const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+        t *= factor / ncells;
+        return (float)t;
+      };
+      // (1) every lane walks the head of its own spiral: eight table entries per trip, their ring cells fetched
+      // together (one entry per trip made the lane wait for a table load and an LDS read in turn)
+      bool found = Ut == 0;
+      if (!found) {
+        double t = 0.0;
+        int ncells = 0;
+        const int n_head = a.n_spiral < kFpHead ? a.n_spiral : kFpHead;
+        for (int k0 = 0; k0 < n_head && !found; k0 += 8) {
+          double v[8];
+          bool in[8];
+          int ring_no[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
-          const unsigned w = ptab[kk];  // uniform: a scalar load
-          const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-          ring_no[q] = (int)((w >> 16) & 0xffu);
-          const int ii = i + di, jj = j + dj;
-          in[q] = k0 + q < a.n_spiral && ii >= 0 && ii < g.rows && jj >= 0 && jj < g.cols;
-          if (in[q] && (w >> 24)) {  // a cell on the circle itself: SpiralIterator::isInside
-            const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
-            in[q] = dx * dx + dy * dy <= a.r2;
-          }
-          int sl = slot_j + dj;
-          sl = sl >= NR ? sl - NR : (sl < 0 ? sl + NR : sl);
-          v[q] = ring[sl * W + c + (in[q] ? di : 0)];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (found || !in[q]) continue;
-          if (v[q] >= 0.5 * kUOff) {
-            const double ru = (double)ring_no[q] * g.res;  // getCurrentRadius()
-            if (a.rmin == 0.0 || ru <= a.rmin) {
-              out = 0.0f;  // :694-704
-            } else {
-              const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
-              t *= factor / ncells;
-              out = (float)t;
+          for (int q = 0; q < 8; ++q) {
+            const int kk = k0 + q < n_head ? k0 + q : n_head - 1;
+            const unsigned w = ptab[kk];  // uniform: a scalar load
+            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+            ring_no[q] = (int)((w >> 16) & 0xffu);
+            const int ii = i + di, jj = j + dj;
+            in[q] = k0 + q < n_head && ii >= 0 && ii < g.rows && jj >= 0 && jj < g.cols;
+            if (in[q] && (w >> 24)) {  // a cell on the circle itself: SpiralIterator::isInside
+              const double dx = cell_x(g, ii) - cell_x(g, i), dy = cell_y(g, jj) - cell_y(g, j);
+              in[q] = dx * dx + dy * dy <= a.r2;
             }
-            found = true;
-          } else {
-            ncells++;
-            t += v[q];
+            v[q] = ring[slot_of(dj) * W + c + (in[q] ? di : 0)];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (found || !in[q]) continue;
+            if (v[q] >= 0.5 * kUOff) {
+              out = value_at(ring_no[q], t, ncells);
+              found = true;
+            } else {
+              ncells++;
+              t += v[q];
+            }
           }
         }
       }
-      if (!(out == out)) out = (float)(t / ncells);  // cannot happen (Ut > 0), kept for safety
+      // (2) the discs whose first untraversable cell lies further out, one at a time with the whole wavefront: lane q
+      // takes entry 64 ch + q (held in registers since the kernel started for radii up to 16 cells: a table load per
+      // chunk was a memory round trip on the critical path), the first untraversable entry comes from a ballot, the sum
+      // of the cells before it from one reduction (a lane walking 700 entries on its own kept the other 63 waiting; the
+      // reference's own 100 x 133 map at 0.03 m spent 1.1 ms in this kernel)
+      unsigned long long rest = __ballot(!found);
+      while (rest != 0ull) {
+        const int l = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        const int ic = i0 + l;
+        double acc = 0.0;
+        int cnt = 0;
+        float oc = qnanf();
+        bool done = false;
+        auto chunk = [&](unsigned w, int k0) __attribute__((always_inline)) {
+          const bool valid = k0 + lane < a.n_spiral;
+          const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+          const int ii = ic + di, jj = j + dj;
+          bool in = valid && ii >= 0 && ii < g.rows && jj >= 0 && jj < g.cols;
+          if (in && (w >> 24)) {  // a cell on the circle itself: SpiralIterator::isInside
+            const double dx = cell_x(g, ii) - cell_x(g, ic), dy = cell_y(g, jj) - cell_y(g, j);
+            in = dx * dx + dy * dy <= a.r2;
+          }
+          const double v = ring[slot_of(dj) * W + l + R + di];
+          const unsigned long long bm = __ballot(in && v >= 0.5 * kUOff);
+          if (bm != 0ull) {
+            const int first = __builtin_ctzll(bm);
+            const int ring_first = __builtin_amdgcn_readlane((int)((w >> 16) & 0xffu), first);
+            done = true;
+            if (a.rmin == 0.0 || (double)ring_first * g.res <= a.rmin) {  // :694-704: no sum needed
+              oc = 0.0f;
+              return;
+            }
+            const bool before = in && lane < first;
+            acc += before ? v : 0.0;
+            cnt += __popcll(__ballot(before));
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);  // exact terms: any order
+            oc = value_at(ring_first, acc, cnt);
+            return;
+          }
+          acc += in ? v : 0.0;
+          cnt += __popcll(__ballot(in));
+        };
+        if (kRegTab && a.n_spiral <= NTAB * kLanes) {
+          fast::static_for<NTAB>([&](auto chc) __attribute__((always_inline)) {
+            constexpr int ch = decltype(chc)::value;
+            if (done || ch * kLanes >= a.n_spiral) return;  // uniform
+            chunk(tabreg[ch], ch * kLanes);
+          });
+        } else {
+          for (int k0 = 0; k0 < a.n_spiral && !done; k0 += kLanes) chunk(ptab[k0 + lane < a.n_spiral ? k0 + lane : 0], k0);
+        }
+        if (lane == l) out = oc;  // an untraversable cell is in the disc (Ut > 0), so oc was set
+      }
     }
     if (qs % 2 == 0)
       advance(j, ptq[qs], puq[qs], vb, va);
     else
       advance(j, ptq[qs], puq[qs], va, vb);
     if (i < g.rows) footprint[mo + (size_t)j * g.rows + i] = out;
-  }
+  });
   }
 }
 
@@ -756,8 +855,17 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.w_slope = combine ? combine->w_slope : 0.0f;
   m.w_step = combine ? combine->w_step : 0.0f;
   m.w_rough = combine ? combine->w_rough : 0.0f;
-  hipLaunchKernelGGL(k_fp_mask, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + MY - 1) / MY), (unsigned)g.batch),
-                     dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+  {
+    const long tiles32 = (long)((g.rows + MX - 1) / MX) * ((g.cols + 31) / 32) * (g.batch > 0 ? g.batch : 1);
+    static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
+    const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
+    if (small)
+      hipLaunchKernelGGL(k_fp_mask<8>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 7) / 8), (unsigned)g.batch),
+                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+    else
+      hipLaunchKernelGGL(k_fp_mask<32>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 31) / 32), (unsigned)g.batch),
+                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+  }
   SpiralArgs a;
   const Disc& d = p.fp_disc;
   for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = (k <= d.R) ? d.hw[k] : -1;
@@ -784,9 +892,11 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     int strips = (int)((per_cu * 256) / (nbx * (g.batch > 0 ? g.batch : 1)));
     strips = strips < 1 ? 1 : strips;
     int rows_per = (g.cols + strips - 1) / strips;
-    // (a small map cannot fill the wave slots anyway: short strips, down to 8 rows, cut the latency of the single launch
-    // -- each wave's spiral walks are serial -- at the price of more warm-up rows in total)
-    a.out_rows = rows_per < 8 ? 8 : (rows_per > 512 ? 512 : rows_per);
+    // (a small map cannot fill the wave slots anyway: every block is resident at once and the launch takes one warm-up
+    // plus the rows of one strip, so the shortest strips win -- each wave's spiral walks are serial)
+    static const int min_rows = getenv("TE_FP_MIN_STRIP") ? atoi(getenv("TE_FP_MIN_STRIP")) : 1;
+    a.out_rows = rows_per < min_rows ? min_rows : (rows_per > 512 ? 512 : rows_per);
+    a.out_rows = a.out_rows < 1 ? 1 : a.out_rows;
   }
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
                   (unsigned)g.batch);

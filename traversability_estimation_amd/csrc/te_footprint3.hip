@@ -21,6 +21,7 @@ namespace fast {
 namespace {
 
 constexpr int kF3Waves = 3;
+constexpr int kF3Head = 24;  // spiral entries every lane walks on its own before the wavefront takes the long walks over
 constexpr double kUOff3 = 4096.0;  // as in te_footprint.hip: sums of T' stay below it, so sum(T') and sum(U) split exactly
 
 struct F3Args {
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   const int jend = js + a.strip_rows < a.cols ? js + a.strip_rows : a.cols;
   const size_t mo = (size_t)blockIdx.z * (size_t)a.map_cells;
 
-  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = 0.0;
   unsigned vb[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) vb[c] = (unsigned)(c * C * RB + lane * 8);
@@ -78,6 +78,15 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   const int icol = i0 + lane;
   const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
   const int nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
+
+  // the spiral table, entry ch * 64 + lane in register ch of lane `lane`: what the wavefront-wide walk below hands out
+  constexpr int NTAB = (int)(3.2 * (R + 1) * (R + 1) / kLanes) + 1;  // >= cells of a disc of radius R + 1
+  unsigned tabreg[NTAB];
+  {
+    const unsigned* __restrict__ ptab0 = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);
+#pragma unroll
+    for (int ch = 0; ch < NTAB; ++ch) tabreg[ch] = ch * kLanes + lane < a.n_spiral ? ptab0[ch * kLanes + lane] : 0u;
+  }
 
   // rows are loaded C steps before they are staged (a queue slot per unrolled position): with one step of lead the
   // wave waited for memory 38 % of its time (SQ_WAIT_ANY, profiles/r02_sq_counters.json)
@@ -108,14 +117,34 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     *reinterpret_cast<double*>(ringb + vbase + (ro * RB + R * 8)) = rin ? vm : 0.0;  // cells outside the map: nothing
     *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0.0;
   };
-  const int jstart = js - (2 * R + 1);
+  // The strip starts with its first disc summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1 (the layout
+  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, column by column.  Sliding in
+  // from an empty disc cost 2R+1 full steps per strip (a fifth of the kernel on the 4096^2 map, all of it on a small
+  // one); the direct sum is about three steps' worth of instructions.  Every term is exact, so S is the same number.
   __syncthreads();
-  load_row(js - R, pmq[0], phq[0], umq[0], uhq[0]);
-  stage_row(js - R, vb[NC - 1], C - 1, pmq[0], phq[0], umq[0], uhq[0]);
+  static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
 #pragma unroll
-  for (int k = 0; k < C; ++k) load_row(js - R + 1 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
+    for (int k = 0; k < C; ++k) load_row(js - R + c * C + k, pmq[k], phq[k], umq[k], uhq[k]);
+#pragma unroll
+    for (int k = 0; k < C; ++k) stage_row(js - R + c * C + k, vb[c], k, pmq[k], phq[k], umq[k], uhq[k]);
+  });
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
 
   double S = 0.0;
+  static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+    constexpr int d = decltype(dc)::value;
+    constexpr int h = Shape<Q>::hw(d);
+    double col = 0.0;
+    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int p = R - h + decltype(rc)::value;  // ring row of map row js - h + rc
+      const char* row = ringb + vb[p / C] + (p % C) * RB;
+      col += *reinterpret_cast<const double*>(row + (R + d) * 8);
+      if (d != 0) col += *reinterpret_cast<const double*>(row + (R - d) * 8);
+    });
+    S += col;
+  });
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
   float out = 0.0f;
   double rnt = 1.0 / (double)nt_mid;
@@ -132,48 +161,50 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     out = (float)(S * rn);  // :732-735 no untraversable cell in the footprint: the mean
     const bool blocked = S >= 0.5 * kUOff3;
     if (__builtin_expect(__any(blocked), 0)) {
+      // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
+      // oldest row of the ring, which is row u of the chunk vb[0] points to.
+      const int slot0 = (int)((__builtin_amdgcn_readfirstlane(vb[0])) / RB) + u;
+      const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
+      auto slot_of = [&](int dj) __attribute__((always_inline)) {
+        int sl = slot0 + dj + R;
+        sl = sl >= NR ? sl - NR : sl;
+        return sl >= NR ? sl - NR : sl;
+      };
+      auto value_at = [&](int ring_no, double t, int ncells) __attribute__((always_inline)) {
+        const double ru = (double)ring_no * a.res;  // getCurrentRadius()
+        if (drmin == 0.0 || ru <= drmin) return 0.0f;  // :694-704
+        const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
+        t *= factor / ncells;
+        return (float)t;
+      };
+      // (1) every lane walks the head of its own spiral, eight entries per trip with their eight ring cells fetched
+      // together (one entry per trip made every lane wait for a table load and an LDS read in turn).  On a map full
+      // of untraversable cells nearly every disc ends here.
+      bool found = !blocked;
       if (blocked) {
-        // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
-        // oldest row of the ring, which is row u of the chunk vb[0] points to.  The table is read eight entries at a
-        // time and their eight ring cells are fetched together: one entry per trip made every lane wait for a table
-        // load and an LDS read in turn (230 cycles per entry; a map where most discs hold an untraversable cell spent
-        // its time here).
-        const int slot0 = (int)((__builtin_amdgcn_readfirstlane(vb[0])) / RB) + u;
         double t = 0.0;
         int ncells = 0;
-        float o = __builtin_nanf("");
-        bool found = false;
-        const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
         const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
-        for (int k0 = 0; k0 < a.n_spiral && !found; k0 += 8) {
+        const int n_head = a.n_spiral < kF3Head ? a.n_spiral : kF3Head;
+        for (int k0 = 0; k0 < n_head && !found; k0 += 8) {
           double v[8];
           bool in[8];
           int ring_no[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
+            const int kk = k0 + q < n_head ? k0 + q : n_head - 1;
             const unsigned w = ptab[kk];  // uniform: a scalar load
             const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
             ring_no[q] = (int)((w >> 16) & 0xffu);
             const int ii = icol + di, jj = j + dj;
-            in[q] = k0 + q < a.n_spiral && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
-            int sl = slot0 + dj + R;
-            sl = sl >= NR ? sl - NR : sl;
-            sl = sl >= NR ? sl - NR : sl;
-            v[q] = ring[sl * W + lane + R + (in[q] ? di : 0)];
+            in[q] = k0 + q < n_head && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
+            v[q] = ring[slot_of(dj) * W + lane + R + (in[q] ? di : 0)];
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             if (found || !in[q]) continue;
             if (v[q] >= 0.5 * kUOff3) {
-              const double ru = (double)ring_no[q] * a.res;  // getCurrentRadius()
-              if (drmin == 0.0 || ru <= drmin) {
-                o = 0.0f;  // :694-704
-              } else {
-                const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
-                t *= factor / ncells;
-                o = (float)t;
-              }
+              out = value_at(ring_no[q], t, ncells);
               found = true;
             } else {
               ncells++;
@@ -181,8 +212,50 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
             }
           }
         }
-        if (!(o == o)) o = (float)(t / ncells);  // cannot happen (an untraversable cell is in the disc)
-        out = o;
+      }
+      // (2) the discs whose first untraversable cell lies further out, one at a time with the whole wavefront: lane q
+      // takes entry 64 ch + q (held in registers since the kernel started: a table load per chunk was a memory round
+      // trip on the critical path), the first untraversable entry comes from a ballot, the sum of the cells before it
+      // from one reduction.  A lane walking 700 entries on its own kept the other 63 waiting.
+      unsigned long long rest = __ballot(!found);
+      while (rest != 0ull) {
+        const int l = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        const int ic = i0 + l;
+        double acc = 0.0;
+        int cnt = 0;
+        float oc = __builtin_nanf("");
+        bool done = false;
+        static_for<NTAB>([&](auto chc) __attribute__((always_inline)) {
+          constexpr int ch = decltype(chc)::value;
+          if (done || ch * kLanes >= a.n_spiral) return;  // uniform
+          const unsigned w = tabreg[ch];
+          const bool valid = ch * kLanes + lane < a.n_spiral;
+          const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+          const int ii = ic + di, jj = j + dj;
+          const bool in = valid && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
+          const double v = ring[slot_of(dj) * W + l + R + di];
+          const unsigned long long bm = __ballot(in && v >= 0.5 * kUOff3);
+          if (bm != 0ull) {
+            const int first = __builtin_ctzll(bm);
+            const int ring_first = __builtin_amdgcn_readlane((int)((w >> 16) & 0xffu), first);
+            done = true;
+            if (drmin == 0.0 || (double)ring_first * a.res <= drmin) {  // :694-704: no sum needed
+              oc = 0.0f;
+              return;
+            }
+            const bool before = in && lane < first;
+            acc += before ? v : 0.0;
+            cnt += __popcll(__ballot(before));
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);  // exact terms (see slide): any order
+            oc = value_at(ring_first, acc, cnt);
+            return;
+          }
+          acc += in ? v : 0.0;
+          cnt += __popcll(__ballot(in));
+        });
+        if (lane == l) out = oc;  // an untraversable cell is in the disc, so oc was set
       }
     }
   };
@@ -210,7 +283,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     S += acc;  // every term is exact (multiples of the float quantum below 2^53), so is any order
   };
 
-  int j = jstart;
+  int j = js;
 #pragma unroll 1
   while (true) {
     bool finished = false;
@@ -221,15 +294,12 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
         finished = true;
         return;
       }
-      const bool emit = j >= js;
-      if (emit) tail(j, u);
+      tail(j, u);
       slide(uc);
       stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u], umq[u], uhq[u]);
       load_row(j + 2 + R + C, pmq[u], phq[u], umq[u], uhq[u]);
-      if (emit) {
-        p_out[lane] = out;
-        p_out += a.rows;
-      }
+      p_out[lane] = out;
+      p_out += a.rows;
       ++j;
     });
     if (finished) break;
@@ -259,7 +329,11 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
   int strips = capacity / per_row;
   strips = strips < 1 ? 1 : strips;
   int sr = (a.cols + strips - 1) / strips;
-  sr = sr < 8 ? 8 : (sr > 512 ? 512 : sr);  // small maps: short strips for latency, the slots are not full anyway
+  // small maps cannot fill the wave slots: every resident block runs at once, so the launch takes one warm-up plus the
+  // rows of one strip -- the shortest strips win (the spiral walks of a row are serial within its wavefront)
+  static const int min_strip = getenv("TE_F3_MIN_STRIP") ? atoi(getenv("TE_F3_MIN_STRIP")) : 1;
+  sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
+  sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
   const int nstrips = (a.cols + sr - 1) / sr;
   hipLaunchKernelGGL((k_fp_slide3<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
@@ -288,6 +362,7 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
   if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
     return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
+  if (p.n_spiral > ((int)(3.2 * (d.R + 1) * (d.R + 1) / kLanes) + 1) * kLanes) return false;  // the kernel's table registers
   F3Args a;
   a.trav = L.trav;
   a.untrav = L.untrav;

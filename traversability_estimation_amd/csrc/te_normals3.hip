@@ -119,12 +119,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   }
   const double zref = (double)zref32;
 
-  // ---- ring: zero, then the first real row (js - R) in the newest slot --------------------------------------------
-  // An invalid cell -- and a cell that is not there: outside the map, above the strip's first disc -- is held as the
-  // smallest denormal: it adds nothing to the z-sums (absorbed by rounding, and 0 when squared) and can be told from every
-  // valid dz, which is a difference of two float32 values (a multiple of 2^-149, or exactly 0).
-  const double kAbsent = __builtin_bit_cast(double, 1ull);
-  for (int idx = lane; idx < NR * W; idx += kLanes) ring[idx] = HOLES ? kAbsent : 0.0;
+  // ---- ring ----------------------------------------------------------------------------------------------------------
+  // An invalid cell -- and a cell that is not there: outside the map -- is held as the smallest denormal (stage_row): it
+  // adds nothing to the z-sums (absorbed by rounding, and 0 when squared) and can be told from every valid dz, which is
+  // a difference of two float32 values (a multiple of 2^-149, or exactly 0).
   // chunk base registers: byte address of the chunk + the lane's own column
   unsigned vb[NC];
 #pragma unroll
@@ -177,17 +175,44 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
     *reinterpret_cast<u32x2*>(ringb + (vbase + vhd) + ro * RB) = bh;
     row_dirty = rin && __any(!__builtin_isfinite(pm) || (!__builtin_isfinite(ph) && halo_in));
   };
-  const int jstart = js - (2 * R + 1);  // the march starts with an EMPTY disc: rows above js-R count as zeros
+  // The march starts with the disc of its first row summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1
+  // (the layout step j = js, u = 0 expects), C rows in flight at a time, then every lane adds up the four moments of its
+  // disc column by column.  (Sliding in from an empty disc took 2R+1 full steps per strip -- a sixth of the kernel on the
+  // 4096^2 map; the direct sums cost about four steps' worth of instructions.)
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < C; ++k) pmq[k] = phq[k] = 0.0f;
-  load_row(js - R, pmq[0], phq[0]);
-  stage_row(js - R, vb[NC - 1], C - 1, pmq[0], phq[0]);  // row jstart + R + 1 = slot NR - 1
-  dmask = row_dirty ? kTopBit : 0u;
+  static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
 #pragma unroll
-  for (int k = 0; k < C; ++k) load_row(js - R + 1 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
+    for (int k = 0; k < C; ++k) load_row(js - R + c * C + k, pmq[k], phq[k]);
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      stage_row(js - R + c * C + k, vb[c], k, pmq[k], phq[k]);
+      dmask |= row_dirty ? 1u << (c * C + k) : 0u;
+    }
+  });
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
+  if (!HOLES && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
+  static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
+    constexpr int e = decltype(ec)::value - R;  // column offset
+    constexpr int h = Shape<Q>::hw(e < 0 ? -e : e);
+    double cs = 0.0, cj = 0.0;
+    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int dj = decltype(rc)::value - h;
+      constexpr int p = R + dj;  // ring row of map row js + dj
+      const double z = *reinterpret_cast<const double*>(ringb + vb[p / C] + ((p % C) * RB + (R + e) * 8));
+      cs += z;
+      if (dj != 0) cj = fma((double)dj, z, cj);
+      Szz = fma(z, z, Szz);
+    });
+    Sz += cs;
+    if (e != 0) Siz = fma((double)e, cs, Siz);
+    Sjz += cj;
+  });
   // output pointers of this block's first row (uniform base + lane), advanced by one map row per output row
   gfloat* p_slope = (gfloat*)(a.slope + mo + (size_t)js * a.rows + i0);
   gfloat* p_rough = (gfloat*)(a.rough + mo + (size_t)js * a.rows + i0);
@@ -514,7 +539,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   };
 
   // ---- the march ---------------------------------------------------------------------------------------------------
-  int j = jstart;
+  int j = js;
   auto rotate = [&]() __attribute__((always_inline)) {
     if (NC > 1) {  // the chunk that held the oldest rows now holds the newest
       const unsigned v0 = vb[0];
@@ -524,7 +549,6 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
     }
   };
   if constexpr (!HOLES) {
-    if (__builtin_expect(dmask != 0, 0)) return false;
     bool aborted = false;
 #pragma unroll 1
     while (true) {
@@ -536,7 +560,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
           leave = true;
           return;
         }
-        const bool out = j >= js;  // (uniform) the warm-up rows have no output
+        constexpr bool out = true;
         if (out) {
           if (GENERAL) {
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
@@ -571,7 +595,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
           done = true;
           return;
         }
-        const bool out = j >= js;
+        constexpr bool out = true;
         if (dmask != 0 && !holes) {  // a dirty row has entered the ring (it leads in this step's slide)
           count_moments(u);
           holes = true;
