@@ -21,6 +21,9 @@ LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-ldl"]
 # (MI355X_MICROARCH.md, LDS table) and the kernel sits at 60 % LDS occupancy with them (4 % slower, same-box A/B)
 _SINGLE_DS_READS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
 EXTRA_CFLAGS = {"csrc/te_normals3.hip": _SINGLE_DS_READS, "csrc/te_footprint3.hip": _SINGLE_DS_READS}
+# sources compiled in several parts (-DTE_PARTS=n -DTE_PART=k, one object each): their shape-specialised kernels take
+# minutes in one translation unit, and the parts compile side by side
+PARTS = {"csrc/te_normals3.hip": 6, "csrc/te_footprint3.hip": 5}
 
 
 def hipcc():
@@ -41,17 +44,27 @@ def stale():
     return any(_mtime(f) > t for f in SOURCES + HEADERS)
 
 
-def _obj(src):
-    return os.path.join(OBJDIR, os.path.basename(src) + ".o")
+def _units():
+    """(source, part or None) for every object of the library."""
+    return [(s, k) for s in SOURCES for k in (range(PARTS[s]) if s in PARTS else [None])]
 
 
-def _compile(src, verbose):
-    cmd = [hipcc()] + CFLAGS + EXTRA_CFLAGS.get(src, []) + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
-                               os.path.join(_HERE, src), "-o", _obj(src) + ".tmp"]
+def _obj(src, part=None):
+    base = os.path.basename(src)
+    if part is not None:
+        base = base[:-len(".hip")] + ".p%d.hip" % part
+    return os.path.join(OBJDIR, base + ".o")
+
+
+def _compile(unit, verbose):
+    src, part = unit
+    defs = [] if part is None else ["-DTE_PARTS=%d" % PARTS[src], "-DTE_PART=%d" % part]
+    cmd = [hipcc()] + CFLAGS + EXTRA_CFLAGS.get(src, []) + defs + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
+                               os.path.join(_HERE, src), "-o", _obj(src, part) + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(_obj(src) + ".tmp", _obj(src))
+    os.replace(_obj(src, part) + ".tmp", _obj(src, part))
 
 
 def build_lib(force=False, verbose=False):
@@ -59,11 +72,12 @@ def build_lib(force=False, verbose=False):
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
-    todo = [s for s in SOURCES
-            if not os.path.exists(_obj(s)) or os.path.getmtime(_obj(s)) < max(_mtime(s), newest_header)]
+    todo = [u for u in _units()
+            if not os.path.exists(_obj(*u)) or os.path.getmtime(_obj(*u)) < max(_mtime(u[0]), newest_header)]
+    todo.sort(key=lambda u: u[0] not in PARTS)  # the long ones first
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
-        list(pool.map(lambda s: _compile(s, verbose), todo))
-    cmd = [hipcc()] + LDFLAGS + [_obj(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+        list(pool.map(lambda u: _compile(u, verbose), todo))
+    cmd = [hipcc()] + LDFLAGS + [_obj(*u) for u in _units()] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -900,22 +900,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   }
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
                   (unsigned)g.batch);
-  if (d.n_ties == 0 && d.Q >= 1) {  // tie-free disc of an instantiated shape: compile-time run table
-    switch (d.Q) {
-#define X(q)                                                                                                       \
-  case q:                                                                                                          \
-    if constexpr (q >= 1) {                                                                                        \
-      hipLaunchKernelGGL((k_fp_slide<fast::Shape<q>::R, q>), grid, dim3(kLanes), 0, stream, g, a, L.trav, L.untrav, \
-                         L.footprint);                                                                             \
-      return hipGetLastError();                                                                                    \
-    }                                                                                                              \
-    break;
-      TE_DISC_SHAPES(X)
-#undef X
-      default:
-        break;
-    }
-  }
+  // (the compile-time run tables of this kernel, Q >= 0, are no longer instantiated: tie-free discs of the instantiated
+  // shapes go to k_fp_slide3 above unless the map is narrower than a wavefront, where speed is not a concern)
   switch (p.reach) {
 #define X(q) \
   case q:    \

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0.0;
   };
   // The strip starts with its first disc summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1 (the layout
-  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, column by column.  Sliding in
+  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, row by row.  Sliding in
   // from an empty disc cost 2R+1 full steps per strip (a fifth of the kernel on the 4096^2 map, all of it on a small
   // one); the direct sum is about three steps' worth of instructions.  Every term is exact, so S is the same number.
   __syncthreads();
@@ -133,18 +133,19 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
 
   double S = 0.0;
-  static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
-    constexpr int d = decltype(dc)::value;
-    constexpr int h = Shape<Q>::hw(d);
-    double col = 0.0;
-    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
-      constexpr int p = R - h + decltype(rc)::value;  // ring row of map row js - h + rc
-      const char* row = ringb + vb[p / C] + (p % C) * RB;
-      col += *reinterpret_cast<const double*>(row + (R + d) * 8);
-      if (d != 0) col += *reinterpret_cast<const double*>(row + (R - d) * 8);
-    });
-    S += col;
-  });
+  {
+    // (rolled: fully unrolled for every shape it multiplied the compile time; the ring still has its initial layout)
+    const char* const rbase = ringb + lane * 8 + R * 8;
+#pragma unroll 1
+    for (int dj = -R; dj <= R; ++dj) {
+      const int hw = isqrt_c(Q - dj * dj);
+      const double* row = reinterpret_cast<const double*>(rbase + (R + dj) * RB);
+      double rs = 0.0;
+#pragma unroll 8
+      for (int e = -hw; e <= hw; ++e) rs += row[e];
+      S += rs;
+    }
+  }
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
   float out = 0.0f;
   double rnt = 1.0 / (double)nt_mid;
@@ -341,17 +342,56 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
 
 }  // namespace
 
+// Shapes: every disc shape up to radius 10 (te_march.h) except the single cell, and for radii 11 .. 16 (the default
+// footprint, 0.45 m, is 15 cells at 0.03 m) every sum of two squares up to 256.  Compiled in TE_PARTS parts like
+// te_normals3.hip (build.py): part k instantiates its list and exports one launcher, part 0 also holds footprint_slide3.
+#define TE_F3_P0(X) X(4) X(16) X(26) X(37) X(50) X(65) X(73) X(85) X(100) X(121) X(136) X(148) X(162) X(178) X(193) X(202) X(212) X(229) X(256)
+#define TE_F3_P1(X) X(10) X(13) X(25) X(36) X(49) X(64) X(82) X(98) X(109) X(117) X(130) X(146) X(160) X(173) X(185) X(200) X(226) X(241) X(250)
+#define TE_F3_P2(X) X(9) X(20) X(34) X(45) X(58) X(61) X(81) X(97) X(106) X(116) X(128) X(145) X(157) X(170) X(181) X(197) X(225) X(234) X(245)
+#define TE_F3_P3(X) X(2) X(8) X(18) X(32) X(41) X(53) X(72) X(80) X(90) X(104) X(113) X(125) X(144) X(153) X(169) X(196) X(208) X(221) X(233) X(244)
+#define TE_F3_P4(X) X(1) X(5) X(17) X(29) X(40) X(52) X(68) X(74) X(89) X(101) X(122) X(137) X(149) X(164) X(180) X(194) X(205) X(218) X(232) X(242)
+#if !defined(TE_PARTS) || defined(TE_F3_SHAPES)
+#undef TE_PARTS
+#undef TE_PART
+#define TE_PARTS 1
+#define TE_PART 0
+#endif
+#if TE_PARTS != 1 && TE_PARTS != 5
+#error "te_footprint3.hip is cut into 1 or 5 parts"
+#endif
 #ifndef TE_F3_SHAPES
-// every disc shape up to radius 10 (te_march.h) except the single cell
-#define TE_F3_SHAPES(X) \
-  X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
-  X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
-  X(89) X(90) X(97) X(98) X(100) \
-  /* radii 11 .. 16 (the default footprint, 0.45 m, is 15 cells at 0.03 m): every sum of two squares up to 256 */ \
-  X(101) X(104) X(106) X(109) X(113) X(116) X(117) X(121) X(122) X(125) X(128) X(130) X(136) X(137) X(144) X(145) \
-  X(146) X(148) X(149) X(153) X(157) X(160) X(162) X(164) X(169) X(170) X(173) X(178) X(180) X(181) X(185) X(193) \
-  X(194) X(196) X(197) X(200) X(202) X(205) X(208) X(212) X(218) X(221) X(225) X(226) X(229) X(232) X(233) X(234) \
-  X(241) X(242) X(244) X(245) X(250) X(256)
+#if TE_PARTS == 1
+#define TE_F3_SHAPES(X) TE_F3_P0(X) TE_F3_P1(X) TE_F3_P2(X) TE_F3_P3(X) TE_F3_P4(X)
+#else
+#define TE_F3_CAT2(a, b) a##b
+#define TE_F3_CAT(a, b) TE_F3_CAT2(a, b)
+#define TE_F3_SHAPES(X) TE_F3_CAT(TE_F3_P, TE_PART)(X)
+#endif
+#endif
+#define TE_F3_NAME2(k) f3_launch_part##k
+#define TE_F3_NAME(k) TE_F3_NAME2(k)
+
+// launches shape Q if it belongs to this part (args: the F3Args block of part 0 -- the same struct in every part)
+bool TE_F3_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
+  const F3Args& a = *static_cast<const F3Args*>(args);
+  switch (Q) {
+#define X(q)                  \
+  case q:                     \
+    launch_f3<q>(a, batch, s); \
+    return true;
+    TE_F3_SHAPES(X)
+#undef X
+    default:
+      return false;
+  }
+}
+
+#if TE_PART == 0
+#if TE_PARTS > 1
+bool f3_launch_part1(int Q, const void* args, int batch, hipStream_t s);
+bool f3_launch_part2(int Q, const void* args, int batch, hipStream_t s);
+bool f3_launch_part3(int Q, const void* args, int batch, hipStream_t s);
+bool f3_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
 // The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.
@@ -379,17 +419,15 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.rmax = p.rmax;
   a.def = p.def;
   a.res = g.res;
-  switch (d.Q) {
-#define X(q)                          \
-  case q:                             \
-    launch_f3<q>(a, g.batch, s);      \
+  if (f3_launch_part0(d.Q, &a, g.batch, s)) return true;
+#if TE_PARTS > 1
+  if (f3_launch_part1(d.Q, &a, g.batch, s) || f3_launch_part2(d.Q, &a, g.batch, s) || f3_launch_part3(d.Q, &a, g.batch, s) ||
+      f3_launch_part4(d.Q, &a, g.batch, s))
     return true;
-    TE_F3_SHAPES(X)
-#undef X
-    default:
-      return false;
-  }
+#endif
+  return false;
 }
+#endif  // TE_PART == 0
 
 }  // namespace fast
 }  // namespace te

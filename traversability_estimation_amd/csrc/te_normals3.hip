@@ -177,7 +177,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   };
   // The march starts with the disc of its first row summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1
   // (the layout step j = js, u = 0 expects), C rows in flight at a time, then every lane adds up the four moments of its
-  // disc column by column.  (Sliding in from an empty disc took 2R+1 full steps per strip -- a sixth of the kernel on the
+  // disc row by row.  (Sliding in from an empty disc took 2R+1 full steps per strip -- a sixth of the kernel on the
   // 4096^2 map; the direct sums cost about four steps' worth of instructions.)
   __syncthreads();
 #pragma unroll
@@ -197,22 +197,28 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   if (!HOLES && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
-  static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
-    constexpr int e = decltype(ec)::value - R;  // column offset
-    constexpr int h = Shape<Q>::hw(e < 0 ? -e : e);
-    double cs = 0.0, cj = 0.0;
-    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
-      constexpr int dj = decltype(rc)::value - h;
-      constexpr int p = R + dj;  // ring row of map row js + dj
-      const double z = *reinterpret_cast<const double*>(ringb + vb[p / C] + ((p % C) * RB + (R + e) * 8));
-      cs += z;
-      if (dj != 0) cj = fma((double)dj, z, cj);
-      Szz = fma(z, z, Szz);
-    });
-    Sz += cs;
-    if (e != 0) Siz = fma((double)e, cs, Siz);
-    Sjz += cj;
-  });
+  {
+    // (rolled loops over the rows and the cells of a row: fully unrolled for every shape and march variant this
+    // multiplied the compile time; the ring still has its initial layout -- row p at p * RB -- so no chunk registers)
+    const char* const rbase = ringb + lane * 8 + R * 8;
+#pragma unroll 1
+    for (int dj = -R; dj <= R; ++dj) {
+      const int hw = isqrt_c(Q - dj * dj);
+      const double* row = reinterpret_cast<const double*>(rbase + (R + dj) * RB);
+      double rs = 0.0, ri = 0.0, de = (double)(-hw);
+#pragma unroll 4
+      for (int e = -hw; e <= hw; ++e) {
+        const double z = row[e];
+        rs += z;
+        ri = fma(de, z, ri);
+        Szz = fma(z, z, Szz);
+        de += 1.0;
+      }
+      Sz += rs;
+      Siz += ri;
+      Sjz = fma((double)dj, rs, Sjz);
+    }
+  }
   // output pointers of this block's first row (uniform base + lane), advanced by one map row per output row
   gfloat* p_slope = (gfloat*)(a.slope + mo + (size_t)js * a.rows + i0);
   gfloat* p_rough = (gfloat*)(a.rough + mo + (size_t)js * a.rows + i0);
@@ -734,13 +740,59 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
 
 }  // namespace
 
-// shapes this file is instantiated for
+// Shapes this file is instantiated for: every disc shape up to radius 10 (te_march.h) except the single cell.  The file
+// is compiled in TE_PARTS parts (build.py: -DTE_PARTS=6 -DTE_PART=k, one object each, side by side) -- the 43 shapes x
+// 2 x 4 marches take 13 minutes in one translation unit.  Part k instantiates the shapes of its list and exports one
+// function that launches them; part 0 also holds normals_fast3.  -DTE_N3_SHAPES=... (tools) compiles one part with that list.
+#define TE_N3_P0(X) X(9) X(20) X(32) X(52) X(61) X(72) X(100)
+#define TE_N3_P1(X) X(8) X(18) X(29) X(50) X(58) X(82) X(98)
+#define TE_N3_P2(X) X(5) X(17) X(26) X(49) X(53) X(81) X(97)
+#define TE_N3_P3(X) X(4) X(16) X(37) X(45) X(68) X(80) X(90)
+#define TE_N3_P4(X) X(10) X(13) X(36) X(41) X(65) X(74) X(89)
+#define TE_N3_P5(X) X(1) X(2) X(25) X(34) X(40) X(64) X(73) X(85)
+#if !defined(TE_PARTS) || defined(TE_N3_SHAPES)
+#undef TE_PARTS
+#undef TE_PART
+#define TE_PARTS 1
+#define TE_PART 0
+#endif
+#if TE_PARTS != 1 && TE_PARTS != 6
+#error "te_normals3.hip is cut into 1 or 6 parts"
+#endif
 #ifndef TE_N3_SHAPES
-// every disc shape up to radius 10 (te_march.h) except the single cell
-#define TE_N3_SHAPES(X) \
-  X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
-  X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
-  X(89) X(90) X(97) X(98) X(100)
+#if TE_PARTS == 1
+#define TE_N3_SHAPES(X) TE_N3_P0(X) TE_N3_P1(X) TE_N3_P2(X) TE_N3_P3(X) TE_N3_P4(X) TE_N3_P5(X)
+#else
+#define TE_N3_CAT2(a, b) a##b
+#define TE_N3_CAT(a, b) TE_N3_CAT2(a, b)
+#define TE_N3_SHAPES(X) TE_N3_CAT(TE_N3_P, TE_PART)(X)
+#endif
+#endif
+#define TE_N3_NAME2(k) n3_launch_part##k
+#define TE_N3_NAME(k) TE_N3_NAME2(k)
+
+// launches shape Q if it belongs to this part (args: the N3Args block of part 0 -- the same struct in every part)
+bool TE_N3_NAME(TE_PART)(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok) {
+  const N3Args& a = *static_cast<const N3Args*>(args);
+  switch (Q) {
+#define X(q)                                      \
+  case q:                                         \
+    *ok = launch3<q>(g, a, keep_normals, maps, s); \
+    return true;
+    TE_N3_SHAPES(X)
+#undef X
+    default:
+      return false;
+  }
+}
+
+#if TE_PART == 0
+#if TE_PARTS > 1
+bool n3_launch_part1(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
+bool n3_launch_part2(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
+bool n3_launch_part3(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
+bool n3_launch_part4(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
+bool n3_launch_part5(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
 #endif
 
 // The normals / slope / roughness pass over region r (discs clipped by the map border included); returns false
@@ -804,16 +856,17 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.nty = fg.nty;
   a.fix_groups = fix_groups(fg.ntx * fg.nty * fg.nbz);
   const int maps = r.map >= 0 ? 1 : g.batch;
-  switch (d.Q) {
-#define X(q) \
-  case q:    \
-    return launch3<q>(g, a, keep_normals, maps, s);
-    TE_N3_SHAPES(X)
-#undef X
-    default:
-      return false;
-  }
+  bool ok = false;
+  if (n3_launch_part0(d.Q, g, &a, keep_normals, maps, s, &ok)) return ok;
+#if TE_PARTS > 1
+  if (n3_launch_part1(d.Q, g, &a, keep_normals, maps, s, &ok) || n3_launch_part2(d.Q, g, &a, keep_normals, maps, s, &ok) ||
+      n3_launch_part3(d.Q, g, &a, keep_normals, maps, s, &ok) || n3_launch_part4(d.Q, g, &a, keep_normals, maps, s, &ok) ||
+      n3_launch_part5(d.Q, g, &a, keep_normals, maps, s, &ok))
+    return ok;
+#endif
+  return false;
 }
+#endif  // TE_PART == 0
 
 }  // namespace fast
 }  // namespace te
