@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
     *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0.0;
   };
   // The strip starts with its first disc summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1 (the layout
-  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, row by row.  Sliding in
+  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, column by column (unrolled; as rolled loops the sum waited for every LDS read).  Sliding in
   // from an empty disc cost 2R+1 full steps per strip (a fifth of the kernel on the 4096^2 map, all of it on a small
   // one); the direct sum is about three steps' worth of instructions.  Every term is exact, so S is the same number.
   __syncthreads();
@@ -133,19 +133,18 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
 
   double S = 0.0;
-  {
-    // (rolled: fully unrolled for every shape it multiplied the compile time; the ring still has its initial layout)
-    const char* const rbase = ringb + lane * 8 + R * 8;
-#pragma unroll 1
-    for (int dj = -R; dj <= R; ++dj) {
-      const int hw = isqrt_c(Q - dj * dj);
-      const double* row = reinterpret_cast<const double*>(rbase + (R + dj) * RB);
-      double rs = 0.0;
-#pragma unroll 8
-      for (int e = -hw; e <= hw; ++e) rs += row[e];
-      S += rs;
-    }
-  }
+  static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+    constexpr int d = decltype(dc)::value;
+    constexpr int h = Shape<Q>::hw(d);
+    double col = 0.0;
+    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int p = R - h + decltype(rc)::value;  // ring row of map row js - h + rc
+      const char* row = ringb + vb[p / C] + (p % C) * RB;
+      col += *reinterpret_cast<const double*>(row + (R + d) * 8);
+      if (d != 0) col += *reinterpret_cast<const double*>(row + (R - d) * 8);
+    });
+    S += col;
+  });
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
   float out = 0.0f;
   double rnt = 1.0 / (double)nt_mid;

@@ -177,7 +177,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   };
   // The march starts with the disc of its first row summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1
   // (the layout step j = js, u = 0 expects), C rows in flight at a time, then every lane adds up the four moments of its
-  // disc row by row.  (Sliding in from an empty disc took 2R+1 full steps per strip -- a sixth of the kernel on the
+  // disc column by column (unrolled: as rolled loops the sums waited for every LDS read and cost what they saved).  (Sliding in from an empty disc took 2R+1 full steps per strip -- a sixth of the kernel on the
   // 4096^2 map; the direct sums cost about four steps' worth of instructions.)
   __syncthreads();
 #pragma unroll
@@ -197,28 +197,22 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   if (!HOLES && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
-  {
-    // (rolled loops over the rows and the cells of a row: fully unrolled for every shape and march variant this
-    // multiplied the compile time; the ring still has its initial layout -- row p at p * RB -- so no chunk registers)
-    const char* const rbase = ringb + lane * 8 + R * 8;
-#pragma unroll 1
-    for (int dj = -R; dj <= R; ++dj) {
-      const int hw = isqrt_c(Q - dj * dj);
-      const double* row = reinterpret_cast<const double*>(rbase + (R + dj) * RB);
-      double rs = 0.0, ri = 0.0, de = (double)(-hw);
-#pragma unroll 4
-      for (int e = -hw; e <= hw; ++e) {
-        const double z = row[e];
-        rs += z;
-        ri = fma(de, z, ri);
-        Szz = fma(z, z, Szz);
-        de += 1.0;
-      }
-      Sz += rs;
-      Siz += ri;
-      Sjz = fma((double)dj, rs, Sjz);
-    }
-  }
+  static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
+    constexpr int e = decltype(ec)::value - R;  // column offset
+    constexpr int h = Shape<Q>::hw(e < 0 ? -e : e);
+    double cs = 0.0, cj = 0.0;
+    static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int dj = decltype(rc)::value - h;
+      constexpr int p = R + dj;  // ring row of map row js + dj
+      const double z = *reinterpret_cast<const double*>(ringb + vb[p / C] + ((p % C) * RB + (R + e) * 8));
+      cs += z;
+      if (dj != 0) cj = fma((double)dj, z, cj);
+      Szz = fma(z, z, Szz);
+    });
+    Sz += cs;
+    if (e != 0) Siz = fma((double)e, cs, Siz);
+    Sjz += cj;
+  });
   // output pointers of this block's first row (uniform base + lane), advanced by one map row per output row
   gfloat* p_slope = (gfloat*)(a.slope + mo + (size_t)js * a.rows + i0);
   gfloat* p_rough = (gfloat*)(a.rough + mo + (size_t)js * a.rows + i0);
