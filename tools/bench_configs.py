@@ -195,7 +195,8 @@ def run_n2p(capi, synth, res, out):
     assert np.array_equal(ws, safe[:m]) and np.array_equal(wt, trav[:m]) and np.array_equal(wa, area[:m])
     out["N2 checkFootprintPath (polygonal 0.9 x 0.6 m footprint), 100000 paths of 2-5 poses on 4096x4096"] = {
         "gpu_paths_per_s": len(paths) / best, "gpu_ms": best * 1e3, "safe_fraction": float(safe.mean()),
-        "cpu_oracle_paths_per_s": 2 * m / max(dt_cpu3 - dt_cpu, 1e-9),
+        # (null when the difference drowns in the run-to-run variation of the mask pass)
+        "cpu_oracle_paths_per_s": 2 * m / (dt_cpu3 - dt_cpu) if dt_cpu3 - dt_cpu > 0.05 * dt_cpu else None,
         "what": "te_check_polygon_footprint_paths on packed host arrays: hulls and areas on the host (1 thread), one launch for "
                 "all segment polygons, results back; the oracle (1 thread) timed as the difference of a 900-path and a 300-path "
                 "call (each also recomputes the untraversable-cell mask of the whole map); first 300 results bit-identical"}
