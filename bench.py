@@ -55,8 +55,8 @@ def kernel_sources_sha16():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--size", type=int, default=4096, help="map is size x size cells")
     ap.add_argument("--radius-cells", type=float, default=9.0)
     ap.add_argument("--res", type=float, default=0.05)
