@@ -134,8 +134,10 @@ void build_path_polygons(int n_paths, const int* pose_offset, const double* pose
 
 // k_normals_fixup: every workgroup owns kFixTiles tiles that are fix_groups() apart (flagged tiles come in runs
 // and must spread over many workgroups) and whose flags are adjacent in memory (one coalesced load).
+// Up to 2048 tiles (a 1024 x 512 map) every tile has a workgroup of its own: a handful of flagged tiles queueing up in
+// three workgroups was half of the chain's latency on the reference's own 100 x 133 map.
 constexpr int kFixTiles = 8;
-inline int fix_groups(int ntiles) { return (ntiles + kFixTiles - 1) / kFixTiles; }
+inline int fix_groups(int ntiles) { return ntiles <= 2048 ? ntiles : (ntiles + kFixTiles - 1) / kFixTiles; }
 
 struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
   int ntx, nty, nbz;

@@ -587,7 +587,12 @@ void build_clip_table(const Disc& d, int R, int* out) {
 }
 
 int normals_fast_max_blocks(const Geo& g) {
-  return ((g.rows + kLanes - 1) / kLanes) * ((g.cols + 15) / 16) * g.batch;  // one flag per 64x16 tile
+  const int ntiles = ((g.rows + kLanes - 1) / kLanes) * ((g.cols + 15) / 16) * g.batch;  // one flag per 64x16 tile ...
+  // ... at (t % groups) * kFixTiles + t / groups; a region run has the tile count of its region, so the largest need of
+  // any count up to ntiles
+  const int small = ntiles < 2048 ? ntiles : 2048;
+  const int a = fix_groups(ntiles) * kFixTiles, b = fix_groups(small) * kFixTiles;
+  return a > b ? a : b;
 }
 
 }  // namespace fast
