@@ -462,6 +462,7 @@ struct SpiralArgs {
   const int* gtab;            // clip table of the tie-free part: {n, ...} per (ky, kx)
   double rmin, rmax, def;
   int out_rows;
+  int inner_q;  // see k_fp_slide, step (0)
 };
 
 // Ring encoding: one double per cell, T' + kUOff * U with T' = traversability (NaN -> default) and
@@ -733,10 +734,32 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
         t *= factor / ncells;
         return (float)t;
       };
-      // (1) every lane walks the head of its own spiral: eight table entries per trip, their ring cells fetched
-      // together (one entry per trip made the lane wait for a table load and an LDS read in turn)
       bool found = Ut == 0;
-      if (!found) {
+      // (0) An untraversable cell within the inner radius makes the footprint 0 whatever comes before it (:694-704; the
+      // spiral visits the rings in order), so a disc is first searched for one directly: all lanes at once, a few hundred
+      // ring reads, no table.  inner_q: largest di^2 + dj^2 of the rings that lie within the inner radius and are taken
+      // whole by the SpiralIterator (-1: none).  On a map full of obstacles most discs end here.
+      if (!found && a.rmin == 0.0) {
+        out = 0.0f;
+        found = true;
+      }
+      if (!found && a.inner_q >= 0) {
+        const int dm = (int)__builtin_sqrtf((float)a.inner_q);
+        int hits = 0;
+        for (int dj = -dm; dj <= dm; ++dj) {
+          const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
+          const double* row = ring + slot_of(dj) * W + c;
+#pragma unroll 8
+          for (int di = -hwi; di <= hwi; ++di) hits += row[di] >= 0.5 * kUOff ? 1 : 0;
+        }
+        if (hits > 0) {
+          out = 0.0f;
+          found = true;
+        }
+      }
+      // (1) every lane walks the head of its own spiral: eight table entries per trip, their ring cells fetched
+      // together (one entry per trip made the lane wait for a table load and an LDS read in turn).  Pointless after (0).
+      if (!found && a.inner_q < 8) {
         double t = 0.0;
         int ncells = 0;
         const int n_head = a.n_spiral < kFpHead ? a.n_spiral : kFpHead;
@@ -881,6 +904,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.rmin = p.rmin;
   a.rmax = p.rmax;
   a.def = p.def;
+  a.inner_q = fast::footprint_inner_q(g.res, p.rmin, p.rmax);
   // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
   if (fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream)) return hipGetLastError();
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit

@@ -35,6 +35,7 @@ struct F3Args {
   const int16_t* table;  // [n_spiral][4]: di, dj, ring (integer norm), tie flag (never set here: tie-free discs only)
   const int* gtab;       // clip table of the disc: {n, ...} per (ky, kx)
   double rmin, rmax, def, res;
+  int inner_q;  // see the tail, step (0)
 };
 
 constexpr int f3_chunk_rows(int NR) {
@@ -177,11 +178,32 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
         t *= factor / ncells;
         return (float)t;
       };
-      // (1) every lane walks the head of its own spiral, eight entries per trip with their eight ring cells fetched
-      // together (one entry per trip made every lane wait for a table load and an LDS read in turn).  On a map full
-      // of untraversable cells nearly every disc ends here.
       bool found = !blocked;
-      if (blocked) {
+      // (0) An untraversable cell within the inner radius makes the footprint 0 whatever comes before it (:694-704; the
+      // spiral visits the rings in order), so a disc is first searched for one directly: all lanes at once, a few hundred
+      // ring reads, no table.  inner_q: largest di^2 + dj^2 of the rings that lie within the inner radius and are taken
+      // whole by the SpiralIterator (-1: none).  On a map full of obstacles most discs end here.
+      if (!found && drmin == 0.0) {
+        out = 0.0f;
+        found = true;
+      }
+      if (!found && a.inner_q >= 0) {
+        const int dm = (int)__builtin_sqrtf((float)a.inner_q);
+        int hits = 0;
+        for (int dj = -dm; dj <= dm; ++dj) {
+          const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
+          const double* row = ring + slot_of(dj) * W + lane + R;
+#pragma unroll 8
+          for (int di = -hwi; di <= hwi; ++di) hits += row[di] >= 0.5 * kUOff3 ? 1 : 0;
+        }
+        if (hits > 0) {
+          out = 0.0f;
+          found = true;
+        }
+      }
+      // (1) every lane walks the head of its own spiral, eight entries per trip with their eight ring cells fetched
+      // together (one entry per trip made every lane wait for a table load and an LDS read in turn).  Pointless after (0).
+      if (!found && a.inner_q < 8) {
         double t = 0.0;
         int ncells = 0;
         const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
@@ -393,6 +415,15 @@ bool f3_launch_part3(int Q, const void* args, int batch, hipStream_t s);
 bool f3_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
+// Largest di^2 + dj^2 of the spiral rings that lie within the inner radius (ring * res <= rmin, getCurrentRadius()'s
+// integer norm) and that SpiralIterator takes without its circle test (all but the two outermost); -1: no such ring.
+int footprint_inner_q(double res, double rmin, double rmax) {
+  const int nrings = (int)ceil(rmax / res);
+  int d = -1;
+  while (d + 1 <= nrings - 2 && (double)(d + 1) * res <= rmin) ++d;
+  return d < 0 ? -1 : (d + 1) * (d + 1) - 1;
+}
+
 // The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.
 bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       hipStream_t s) {
@@ -418,6 +449,7 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.rmax = p.rmax;
   a.def = p.def;
   a.res = g.res;
+  a.inner_q = footprint_inner_q(g.res, p.rmin, p.rmax);
   if (f3_launch_part0(d.Q, &a, g.batch, s)) return true;
 #if TE_PARTS > 1
   if (f3_launch_part1(d.Q, &a, g.batch, s) || f3_launch_part2(d.Q, &a, g.batch, s) || f3_launch_part3(d.Q, &a, g.batch, s) ||

@@ -174,6 +174,7 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
                   const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s, bool* combined);
 // te_normals3.hip: the cells whose disc lies inside the map (false: shape / region not taken)
+int footprint_inner_q(double res, double rmin, double rmax);  // te_footprint3.hip
 bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags,
                    FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
