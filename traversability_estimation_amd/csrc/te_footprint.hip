@@ -65,7 +65,7 @@ __device__ __forceinline__ bool submap_fails(const Geo& g, int edge_fail, int a,
          ((edge_fail & 8) && b == g.cols - 1);
 }
 
-// A layer seen through the LDS tile of the block (64 x MY cells + halo, MY = 32 or 8); cells outside the tile are
+// A layer seen through the LDS tile of the block (64 x MY cells + halo, MY = 32, 8 or 4); cells outside the tile are
 // read from global memory (only the rare long Bresenham walks of checkForStep leave the tile).
 constexpr int MX = 64, MBY = 4, MH = 3;  // tile width, threads along j, halo (>= reach of both windows + 1)
 constexpr int MTW = MX + 2 * MH;
@@ -251,7 +251,7 @@ struct MaskArgs {
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
-// for maps too small to fill the GPU with 64 x 32 tiles: a thread's cells that need the full checkForStep are serial,
+// (4 for very small maps) for maps too small to fill the GPU with 64 x 32 tiles: a thread's cells that need the full checkForStep are serial,
 // and on the reference's own 100 x 133 map (where half of the cells do) ten workgroups took 0.32 ms.
 template <int MY>
 __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
@@ -882,7 +882,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     const long tiles32 = (long)((g.rows + MX - 1) / MX) * ((g.cols + 31) / 32) * (g.batch > 0 ? g.batch : 1);
     static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
     const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
-    if (small)
+    if (small && tiles32 < 128 && small_env != 8)  // a very small map: one cell per thread
+      hipLaunchKernelGGL(k_fp_mask<4>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 3) / 4), (unsigned)g.batch),
+                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+    else if (small)
       hipLaunchKernelGGL(k_fp_mask<8>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 7) / 8), (unsigned)g.batch),
                          dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else
