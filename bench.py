@@ -17,7 +17,12 @@ launches, one event pair per launch); `roofline.dominant_kernel` is the normals/
 alone the same way (12 B/cell); `roofline_issue` prices the same launch against the double-precision
 issue rate, which is what bounds these kernels.
 `cpu_baseline` times the CPU oracle (our restatement of the reference; kind "port") on one host thread
-over a bounded crop of the same map.
+over a bounded crop of the same map; `cpu_baseline_all_cores` the same oracle with OpenMP over rows on every host core.
+`parity_check` (every run, rank 0): the layers the timed launches left on the device are compared with the oracle on a
+corner crop and on one full-width band of the map; a mismatch fails the run (exit code 1) after the line is printed.
+
+Order of the run: upload -> event-timed samples of the launch (they also bring the GPU to its working clocks) -> W
+warm-up steps -> barrier + sync -> K timed steps -> sync + barrier -> parity check -> host path -> CPU baselines.
 """
 import argparse
 import json
@@ -66,7 +71,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive measurement (for profiler runs: "
                     "its kernels wait for a pageable H2D copy and would skew the per-kernel averages)")
-    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the oracle with OpenMP on all host cores")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the OpenMP all-core run of the oracle")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle parity check of the timed result (profiler runs)")
     ap.add_argument("--holes", type=float, default=0.0, help="fraction of invalid (NaN) cells: speckle if < 0.5, else "
                     "solid unobserved regions covering about (value - 0.5) of the map (not the BASELINE workload)")
     ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
@@ -74,7 +81,7 @@ def parse():
                     help="cfg3 (default): BASELINE.json configs[2], one 4096^2 map per GPU, radius 9, footprint pass (weak scaling). "
                          "cfg4: configs[3], a batch of 512 maps of 512^2, radius 5, cut into contiguous blocks over the ranks "
                          "(dist.shard_range; strong scaling, params broadcast over RCCL)")
-    ap.add_argument("--check", action="store_true", help="also check a crop of the GPU result against the oracle")
+    ap.add_argument("--check", action="store_true", help="(default now; kept for old command lines)")
     return ap.parse_args()
 
 
@@ -93,7 +100,7 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     for f, _ in op._fields_:
         setattr(op, f, getattr(p, f))
     O.set_threads(threads)
-    n = 128 if threads == 1 else 512
+    n = 128 if threads == 1 else 384
     g = O.geom(n, n, args.res)
     crop = np.ascontiguousarray(elev_full[:n, :n])
     t0 = time.perf_counter()
@@ -103,7 +110,8 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     dt = time.perf_counter() - t0
     rate = n * n / dt
     # scale the sample so that it takes about cpu_seconds, at most the whole map
-    n = int(min(args.size, max(128, (rate * args.cpu_seconds) ** 0.5)))
+    seconds = args.cpu_seconds if threads == 1 else min(args.cpu_seconds, 8.0)
+    n = int(min(args.size, max(128, (rate * seconds) ** 0.5)))
     n -= n % 64
     n = max(n, 128)
     g = O.geom(n, n, args.res)
@@ -113,10 +121,62 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     if with_footprint:
         O.footprint(g, op, crop, out)
     dt = time.perf_counter() - t0
+    O.set_threads(1)
     return {"value": n * n / dt, "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"{n}x{n} crop of the same map, full chain{'+footprint' if with_footprint else ''}, "
                       f"{dt:.1f} s on {threads} of {os.cpu_count()} host cores (oracle/te_oracle.c, -O3"
                       f"{', OpenMP over rows' if threads > 1 else ''})"}
+
+
+def parity_check(args, ctx, elev, p, with_fp, n):
+    """The layers on the device (map 0 of this rank) against the oracle: a corner crop (two map borders) and one
+    full-width band (every block column and strip seam of the marching kernels).  Cells closer to a cut edge of the
+    crop than the reach of the chain (+ the footprint's) see a cut neighbourhood in the crop and are left out."""
+    from oracle import oracle as O
+    from tests.helpers import OUT_LAYERS, TOL, compare_layer
+    names = list(OUT_LAYERS) + (["traversability_footprint"] if with_fp else [])
+    op = O.default_params()
+    for f, _ in op._fields_:
+        setattr(op, f, getattr(p, f))
+    per = n * n
+    got = {k: ctx.download(k).reshape(-1)[:per].reshape(n, n) for k in names}  # [col j][row i]
+    R = int(args.radius_cells + 1)
+    margin = 2 * R + (R + 4 if with_fp else 0) + 2
+    crop_n = min(n, 320)
+    band = min(n, 2 * margin + 40)
+    windows = [("corner crop %dx%d" % (crop_n, crop_n), (slice(0, crop_n), slice(0, crop_n)))]
+    if n > crop_n:
+        j0 = (n // 2 // 64) * 64 + 17  # not aligned with anything
+        j0 = min(j0, n - band)
+        windows.append(("full-width band, rows %d..%d" % (j0, j0 + band), (slice(j0, j0 + band), slice(0, n))))
+    O.set_threads(min(os.cpu_count() or 1, 64))
+    rep = {"tolerance": TOL, "windows": [], "layers": {k: {"mismatches": 0, "max_abs_err": 0.0, "cells": 0} for k in names}, "ok": True}
+    try:
+        for label, sl in windows:
+            sub = np.ascontiguousarray(elev.reshape(n, n)[sl])
+            g = O.geom(sub.shape[1], sub.shape[0], args.res)  # rows = extent along i (the fast axis)
+            want = O.chain(g, op, sub)
+            if with_fp:
+                want["traversability_footprint"] = O.footprint(g, op, sub, want)
+            keep = []
+            for ax, s1 in enumerate(sl):
+                lo = 0 if s1.start == 0 else margin
+                hi = (s1.stop - s1.start) if s1.stop == n else (s1.stop - s1.start) - margin
+                keep.append(slice(lo, hi))
+            keep = tuple(keep)
+            rep["windows"].append(label)
+            for k in names:
+                a = got[k][sl][keep]
+                b = want[k].reshape(sub.shape)[keep]
+                n_bad, mx, _ = compare_layer(k, a, b)
+                L = rep["layers"][k]
+                L["mismatches"] += n_bad
+                L["max_abs_err"] = max(L["max_abs_err"], mx)
+                L["cells"] += int(a.size)
+                rep["ok"] = rep["ok"] and n_bad == 0
+    finally:
+        O.set_threads(1)
+    return rep
 
 
 def main():
@@ -135,14 +195,14 @@ def main():
     torch.cuda.set_device(local_rank)
     capi.load()
 
-    # filter parameters: rank 0 decides, every other rank receives the te_params blob over RCCL
-    p = tdist.broadcast_params(capi, make_params(capi, synth, args), src=0)
-
     total_maps = None
-    if args.config == "cfg4":
+    if args.config == "cfg4":  # (before the parameters are built: they carry the radius)
         args.size, args.radius_cells, total_maps = 512, 5.0, 512
         a, b = tdist.shard_range(total_maps, rank, world)
         args.maps_per_gpu = b - a
+
+    # filter parameters: rank 0 decides, every other rank receives the te_params blob over RCCL
+    p = tdist.broadcast_params(capi, make_params(capi, synth, args), src=0)
     with_fp = not args.no_footprint
     flags = capi.RUN_FOOTPRINT if with_fp else 0
     if args.sequential:
@@ -176,6 +236,17 @@ def main():
 
     barrier = tdist.barrier
 
+    # kernel-only duration of the chain: HIP events on the context's own stream, one pair per launch, median of >= 100.
+    # Taken BEFORE the host-timed loop: the same launches, and they leave the GPU at its working clocks (the driver's
+    # 5 warm-up + 20 timed steps alone start on an idle device).
+    n_samples = max(100, args.steps)
+    chain_samples = ctx.time_chain_samples(flags, warmup=20, iters=n_samples)
+    ms_chain = float(np.median(chain_samples))
+    # the dominant kernel alone (normals/slope/roughness + its fix-up pass: TE_RUN_NORMALS_ONLY), the same way
+    normals_samples = ctx.time_chain_samples(capi.RUN_NORMALS_ONLY, warmup=5, iters=n_samples)
+    ms_normals = float(np.median(normals_samples))
+    ctx.run_chain(flags)  # (the normals-only launches overwrote two layers with the same values; keep the state simple)
+
     for _ in range(args.warmup):
         ctx.run_chain(flags)
     ctx.sync()
@@ -190,13 +261,10 @@ def main():
     dt = time.perf_counter() - t0
     dt = tdist.max_over_ranks(dt)
 
-    # kernel-only duration of the chain: HIP events on the context's own stream, one pair per launch, median of >= 100
-    n_samples = max(100, args.steps)
-    chain_samples = ctx.time_chain_samples(flags, warmup=20, iters=n_samples)
-    ms_chain = float(np.median(chain_samples))
-    # the dominant kernel alone (normals/slope/roughness + its fix-up pass: TE_RUN_NORMALS_ONLY), the same way
-    normals_samples = ctx.time_chain_samples(capi.RUN_NORMALS_ONLY, warmup=5, iters=n_samples)
-    ms_normals = float(np.median(normals_samples))
+    # parity of what the timed launches left on the device (rank 0, map 0)
+    check = None
+    if rank == 0 and not args.no_check:
+        check = parity_check(args, ctx, elevs[0], p, with_fp, n)
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None
@@ -274,29 +342,6 @@ def main():
             except (capi.TeError, KeyError, TypeError, ValueError) as e:
                 host_path["three_plugins_error"] = str(e)
 
-    check = None
-    if args.check and rank == 0:
-        from oracle import oracle as O
-        from tests.helpers import OUT_LAYERS, compare_layer
-        m = 192
-        with capi.Context(local_rank) as c2:
-            c2.set_params(p)
-            c2.set_geometry(m, m, 1, args.res)
-            crop = np.ascontiguousarray(elevs[0][:m, :m])
-            c2.upload_elevation(crop)
-            c2.run_chain(flags)
-            c2.sync()
-            op = O.default_params()
-            for f, _ in op._fields_:
-                setattr(op, f, getattr(p, f))
-            g = O.geom(m, m, args.res)
-            want = O.chain(g, op, crop)
-            names = list(OUT_LAYERS)
-            if with_fp:
-                want["traversability_footprint"] = O.footprint(g, op, crop, want)
-                names.append("traversability_footprint")
-            check = {k: compare_layer(k, c2.download(k), want[k])[:2] for k in names}
-
     if rank == 0:
         cells_per_step = (total_maps if total_maps is not None else world * B) * n * n
         bytes_per_cell = 24 if with_fp else 20
@@ -309,6 +354,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # what the host-timed loop carries on top of K event-timed launches (first-launch latency, the final sync)
+            "sync_overhead_ms": dt * 1e3 - args.steps * ms_chain,
             "higher_is_better": True,
             "scaling": "strong" if total_maps is not None else "weak",
             "vs_baseline": None,
@@ -354,11 +401,15 @@ def main():
             out["host_path"] = host_path
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, elevs[0], p, with_fp)
-            if args.cpu_all_cores:  # extra, not part of the contract: the same oracle on every host core
+            if not args.no_cpu_all_cores:  # single thread AND OpenMP over rows on all host cores
                 out["cpu_baseline_all_cores"] = cpu_baseline(args, elevs[0], p, with_fp, threads=os.cpu_count() or 1)
         if check is not None:
-            out["parity_check"] = {k: {"mismatches": v[0], "max_abs_err": v[1]} for k, v in check.items()}
-        print(json.dumps(out))
+            out["parity_check"] = check
+        print(json.dumps(out), flush=True)
+        if check is not None and not check["ok"]:
+            print("parity check FAILED: " + json.dumps(check), file=sys.stderr)
+            ctx.close()
+            sys.exit(1)
     ctx.close()
     if world > 1:
         barrier()  # rank 0 is still timing the CPU baseline: leave the group together

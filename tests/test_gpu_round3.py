@@ -1,0 +1,129 @@
+"""Round-3 kernels and entry points against the oracle, through the C-ABI:
+the fixed-point footprint kernel (k_fp_slide4) over footprint radii and obstacle densities, the double kernel it falls
+back to for a traversability layer that was not written by the chain, the step filter's nCells shortcut, and
+te_run_chain_region refusing a footprint flag it does not implement."""
+import numpy as np
+import pytest
+
+from tests.helpers import OUT_LAYERS, assert_layers_match, compare_layer, to_te_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1
+    return capi
+
+
+def obstacle_map(synth, rows, cols, seed, boxes, amplitude=0.12):
+    return synth.with_steps(synth.perlin_elevation(rows, cols, seed=seed, amplitude=amplitude), boxes, seed=seed + 7)
+
+
+@pytest.mark.parametrize("fp_cells,off_cells,boxes", [(2, 1, 6), (4, 2, 10), (6, 3, 14), (6, 3, 0), (7.3, 2.4, 12), (9, 4, 10), (11, 4, 8)])
+def test_fixed_point_footprint_over_radii(capi, oracle, fp_cells, off_cells, boxes):
+    """k_fp_slide4: discs of 29 .. 709 cells (the fixed-point scale drops from 2^21 to 2^18 with the radius), clean maps
+    and maps with boxes (spiral walks, inner-radius hits), borders on all sides (the map is 1.2 x the widest disc)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 230, 190, 0.05
+    elev = obstacle_map(synth, rows, cols, 300 + int(10 * fp_cells), boxes)
+    elev[100:104, 60:75] = np.nan
+    r = synth.benchmark_radius(3, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                               fp_radius=synth.benchmark_radius(fp_cells, res), fp_offset=synth.benchmark_radius(off_cells, res))
+    g = oracle.geom(rows, cols, res, (1.5, -2.0))
+    want = oracle.chain(g, op, elev)
+    want["traversability_footprint"] = oracle.footprint(g, op, elev, want)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, (1.5, -2.0))
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS + ("traversability_footprint",)}
+    assert_layers_match(got, want, layers=list(OUT_LAYERS) + ["traversability_footprint"], ctx=f"footprint {fp_cells}+{off_cells} cells, {boxes} boxes")
+    fp = got["traversability_footprint"]
+    assert not np.isnan(fp).any()
+    if boxes:
+        assert (fp == 0).sum() > 20 and ((fp > 0) & (fp < 1)).sum() > 1000
+
+
+def test_footprint_of_an_uploaded_traversability_layer(capi, oracle):
+    """A traversability layer that does not come from the chain is not bounded by the weights: values above 1 (and
+    NaN) must go through the double kernel, same result as the oracle's isTraversable on that layer."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 200, 170, 0.05
+    elev = obstacle_map(synth, rows, cols, 77, 8)
+    r = synth.benchmark_radius(3, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                               fp_radius=synth.benchmark_radius(5, res), fp_offset=synth.benchmark_radius(2, res))
+    g = oracle.geom(rows, cols, res)
+    layers = oracle.chain(g, op, elev)
+    rng = np.random.default_rng(5)
+    t = (layers["traversability"].astype(np.float64) * 40.0 + rng.uniform(0.0, 3.0, size=rows * cols)).astype(np.float32)
+    t[rng.random(rows * cols) < 0.01] = np.nan
+    layers["traversability"] = t
+    want = oracle.footprint(g, op, elev, layers)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(0)
+        ctx.upload_layer("traversability", t)
+        ctx.run_footprint()
+        ctx.sync()
+        got = ctx.download("traversability_footprint")
+        n_bad, mx, _ = compare_layer("traversability_footprint", got, want, tol=1e-5 * 45.0)  # values reach 43
+        assert n_bad == 0, (n_bad, mx)
+        assert np.nanmax(got) > 5.0
+        # the chain writes the layer again: back to the bounded (fixed-point) path, same answer as a fresh context
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        again = ctx.download("traversability_footprint")
+    layers2 = oracle.chain(g, op, elev)
+    want2 = oracle.footprint(g, op, elev, layers2)
+    n_bad, mx, _ = compare_layer("traversability_footprint", again, want2)
+    assert n_bad == 0, (n_bad, mx)
+
+
+@pytest.mark.parametrize("ncrit,crit", [(1, 0.12), (4, 0.12), (9, 0.05), (40, 0.02), (4, 0.0)])
+def test_step_filter_cell_count_cases(capi, oracle, ncrit, crit):
+    """StepFilter.cpp:165-176: nCells == 0, 0 < nCells < nCellCritical, nCells >= nCellCritical -- the kernel computes
+    the score arithmetic only in the middle case; every case must stay bit-identical."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 192, 160, 0.05
+    elev = synth.with_steps(synth.perlin_elevation(rows, cols, seed=9, amplitude=0.04), 5, seed=10)
+    elev[30:33, 100:140] = np.nan
+    for cells in (2, 5):
+        r = synth.benchmark_radius(cells, res)
+        op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, step_critical=crit, step_ncrit=ncrit)
+        want = oracle.chain(oracle.geom(rows, cols, res), op, elev)
+        with capi.Context(0) as ctx:
+            ctx.set_params(to_te_params(capi, op))
+            ctx.set_geometry(rows, cols, 1, res)
+            ctx.upload_elevation(elev)
+            ctx.run_chain(0)
+            ctx.sync()
+            got = ctx.download("traversability_step")
+        w = want["traversability_step"]
+        assert np.array_equal(np.isnan(got), np.isnan(w))
+        assert np.array_equal(got[~np.isnan(got)].view(np.uint32), w[~np.isnan(w)].view(np.uint32)), (ncrit, crit, cells)
+        if crit > 0 and ncrit > 1:
+            assert ((w > 0) & (w < 1)).sum() > 0  # the middle case occurs
+
+
+def test_region_run_refuses_the_footprint_flag(capi):
+    from traversability_estimation_amd import synth
+    rows, cols, res = 128, 128, 0.05
+    with capi.Context(0) as ctx:
+        ctx.set_params(capi.default_params())
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(synth.perlin_elevation(rows, cols, seed=1))
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.run_chain_region(0, 10, 10, 32, 32)
+        with pytest.raises(capi.TeError):
+            ctx.run_chain_region(0, 10, 10, 32, 32, flags=capi.RUN_FOOTPRINT)
+        ctx.run_footprint()  # the whole-map pass refreshes the layer
+        ctx.sync()

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Quick A/B timing of one chain launch on the bench workload, without torch (a fresh GPU box pays 1-2 minutes for the
+first `import torch`; this starts in seconds).  The kernels' measurement switches are environment variables read once
+per process (TE_NO_F4, TE_NO_N3, TE_F4_BLOCKS_PER_CU, ...), so a variant is one process:
+
+    TE_NO_F4=1 python tools/ab_chain.py --tag no_f4
+
+Prints one JSON line: median / p10 / p90 of the event-timed launch (te_time_chain_samples) and, with --loops, the
+host-timed loop of K launches + te_sync for several K (what bench.py's timed region does): its slope is the per-step
+time, its intercept the fixed cost of the first launch and the final synchronisation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--radius-cells", type=float, default=9.0)
+    ap.add_argument("--res", type=float, default=0.05)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--sequential", action="store_true")
+    ap.add_argument("--no-footprint", action="store_true")
+    ap.add_argument("--normals-only", action="store_true")
+    ap.add_argument("--footprint-only", action="store_true", help="time te_run_footprint alone (mask + slide) after one chain")
+    ap.add_argument("--holes", type=float, default=0.0)
+    ap.add_argument("--loops", type=str, default="", help="comma-separated K: host-timed loops of K launches + sync")
+    ap.add_argument("--tag", type=str, default="")
+    a = ap.parse_args()
+    from traversability_estimation_amd import capi, synth
+    capi.load()
+    n, B = a.size, a.batch
+    r = synth.benchmark_radius(a.radius_cells, a.res)
+    p = capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                            fp_radius=synth.benchmark_radius(6.0, a.res), fp_offset=synth.benchmark_radius(3.0, a.res))
+    elevs = [synth.perlin_elevation(n, n, seed=1235 + b) for b in range(B)]
+    if a.holes > 0:
+        elevs = [synth.with_holes(e, a.holes, seed=99 + b) for b, e in enumerate(elevs)]
+    flags = 0 if a.no_footprint else capi.RUN_FOOTPRINT
+    if a.sequential:
+        flags |= capi.RUN_SEQUENTIAL
+    if a.normals_only:
+        flags = capi.RUN_NORMALS_ONLY
+    out = {"tag": a.tag, "size": n, "batch": B, "radius_cells": a.radius_cells, "flags": flags, "holes": a.holes,
+           "env": {k: v for k, v in os.environ.items() if k.startswith("TE_")}}
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(n, n, B, a.res)
+        ctx.upload_elevation(np.stack(elevs))
+        if a.footprint_only:
+            ctx.run_chain(flags)
+            ctx.sync()
+            ts = []
+            for _ in range(a.iters + 10):
+                t0 = time.perf_counter()
+                ctx.run_footprint()
+                ctx.sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            s = np.array(ts[10:])
+            out["what"] = "te_run_footprint + te_sync, host-timed"
+        else:
+            s = ctx.time_chain_samples(flags, warmup=20, iters=a.iters)
+        out.update(ms_median=float(np.median(s)), ms_p10=float(np.percentile(s, 10)), ms_p90=float(np.percentile(s, 90)),
+                   cells_per_s=B * n * n / (float(np.median(s)) * 1e-3))
+        if a.loops:
+            loops = {}
+            for K in [int(k) for k in a.loops.split(",")]:
+                best = None
+                for _ in range(5):
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(K):
+                        ctx.run_chain(flags)
+                    ctx.sync()
+                    d = (time.perf_counter() - t0) * 1e3
+                    best = d if best is None or d < best else best
+                loops[str(K)] = {"ms_total_best_of_5": best, "ms_per_step": best / K}
+            out["host_loops"] = loops
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,19 @@
   X(39, "v_add_f32", "v_add_f32 %1, %1, %4", f)                                                        \
   X(40, "v_sub_u32", "v_sub_u32 %1, %1, %4", f)                                                        \
   X(41, "v_or_b32", "v_or_b32 %1, %1, %4", f)                                                          \
-  X(42, "v_xor+cmp pair", "v_cmp_lt_u32 vcc, %1, %4\n v_addc_co_u32 %1, vcc, %1, %4, vcc", f)
+  X(42, "v_xor+cmp pair", "v_cmp_lt_u32 vcc, %1, %4\n v_addc_co_u32 %1, vcc, %1, %4, vcc", f)                 \
+  X(43, "v_max_u32", "v_max_u32 %1, %1, %4", f)                                                        \
+  X(44, "v_max_i32", "v_max_i32 %1, %1, %4", f)                                                        \
+  X(45, "v_min_u32", "v_min_u32 %1, %1, %4", f)                                                        \
+  X(46, "v_pk_max_i16", "v_pk_max_i16 %1, %1, %4", f)                                                  \
+  X(47, "v_pk_add_u16", "v_pk_add_u16 %1, %1, %4", f)                                                  \
+  X(48, "v_add_u32_sdwa", "v_add_u32_sdwa %1, %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3", f) \
+  X(49, "v_lshl_or_b32", "v_lshl_or_b32 %1, %1, 3, %4", f)                                             \
+  X(50, "v_cvt_u32_f32", "v_cvt_u32_f32 %1, %1", f)                                                    \
+  X(51, "v_cvt_f32_u32", "v_cvt_f32_u32 %1, %1", f)                                                    \
+  X(52, "v_max3_u32", "v_max3_u32 %1, %1, %4, %5", f)                                                  \
+  X(53, "v_pk_max_f16", "v_pk_max_f16 %1, %1, %4", f)                                                  \
+  X(54, "v_maximum3_f32?", "v_max3_f32 %1, %1, %4, %4", f)
 
 template <int OP, int CH>
 __global__ __launch_bounds__(64) void k(double* out, int iters, double seed) {
@@ -96,11 +108,13 @@ double run(int waves) {
   return ms * 1e-3 * 2.4e9 / (64.0 * iters * waves);
 }
 
-int main() {
-  printf("%-18s %10s %10s %10s %10s   (cycles per instruction per SIMD; dep = 1 dependent chain, 1 wave)\n", "op", "dep,1w", "8ch,1w",
-         "8ch,2w", "8ch,4w");
+int main(int argc, char** argv) {
+  const int first = argc > 1 ? atoi(argv[1]) : 0;  // print the ops from this id on
+  printf("%-18s %10s %10s %10s %10s %10s %10s   (cycles per instruction per SIMD; dep = 1 dependent chain, 1 wave)\n", "op", "dep,1w",
+         "8ch,1w", "8ch,2w", "8ch,3w", "8ch,4w", "8ch,8w");
 #define X(ID, NAME, ASM, KIND) \
-  printf("%-18s %10.2f %10.2f %10.2f %10.2f\n", NAME, run<ID, 1>(1), run<ID, 8>(1), run<ID, 8>(2), run<ID, 8>(4));
+  if (ID >= first)             \
+    printf("%-18s %10.2f %10.2f %10.2f %10.2f %10.2f %10.2f\n", NAME, run<ID, 1>(1), run<ID, 8>(1), run<ID, 8>(2), run<ID, 8>(3), run<ID, 8>(4), run<ID, 8>(8));
   OPS(X)
 #undef X
   return 0;

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
       if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
         const float z0 = zc[so];
         // StepFilter.cpp:113 only valid centres; :143 double difference stored as float
-        const float out = (z0 == z0) ? (float)((double)vmx - (double)vmn) : qnan();
+        // (float)((double)vmx - (double)vmn) == vmx - vmn in float32: the double difference of two floats rounded to
+        // float is the correctly rounded float difference (53 >= 2 * 24 + 2 bits: double rounding is innocuous)
+        const float out = (z0 == z0) ? __fsub_rn(vmx, vmn) : qnan();
         sh[mo + (size_t)j * g.rows + i] = out;
       }
     };
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
   // double division); first read after the barriers of the first period
   __shared__ double ratio[S::npoints() + 1];
   for (int k = lane; k <= S::npoints(); k += kLanes) ratio[k] = (double)k / (double)ncrit;
+  const float one_if_crit = 0.0 < crit ? 1.0f : 0.0f;
   float vm[P];  // NaN-ignoring max of the valid step heights (NaN == no valid cell yet)
   int cnt[P];
   static_for<P>([&](auto kc) __attribute__((always_inline)) {
@@ -181,16 +184,22 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
     auto emit = [&](int p, float m, int count) __attribute__((always_inline)) {
       const int j = rbase + p - R;
       if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
-        // isValid: at least one valid step_height in the window (StepFilter.cpp:161), else the cell stays NaN
-        const double sm = (double)vmax2_zero(m);  // stepMax starts at 0.0 (:149)
-        const double a1 = ratio[count] * sm;       // nCells / nCellCritical_ * stepMax (:169)
-        const double step = sm < a1 ? sm : a1;     // :170
-        // step / crit without the division sequence: q0 = step * RN(1/crit), then two residual corrections
-        // (Markstein: the first makes q faithful, the second correctly rounded), all branch-free
-        const double q0 = step * rcrit;
-        const double q1 = fma(fma(-q0, crit, step), rcrit, q0);
-        const double q = fma(fma(-q1, crit, step), rcrit, q1);
-        float o = step < crit ? (float)(1.0 - q) : 0.0f;
+        // isValid: at least one valid step_height in the window (StepFilter.cpp:161), else the cell stays NaN.
+        // nCells == 0: step = min(stepMax, 0 * stepMax) = 0 (:169-170) -> 1 - 0 / crit = 1 (0 if crit == 0: "0 < 0" fails);
+        // nCells >= nCellCritical: the ratio is >= 1, so step = stepMax, and a counted cell means stepMax > crit -> 0.
+        // Only 0 < nCells < nCellCritical needs the arithmetic, and a wavefront rarely holds such a cell.
+        float o = count == 0 ? one_if_crit : 0.0f;
+        if (__builtin_expect(__any(count > 0 && count < ncrit), 0)) {
+          const double sm = (double)vmax2_zero(m);  // stepMax starts at 0.0 (:149)
+          const double a1 = ratio[count] * sm;       // nCells / nCellCritical_ * stepMax (:169)
+          const double step = sm < a1 ? sm : a1;     // :170
+          // step / crit without the division sequence: q0 = step * RN(1/crit), then two residual corrections
+          // (Markstein: the first makes q faithful, the second correctly rounded), all branch-free
+          const double q0 = step * rcrit;
+          const double q1 = fma(fma(-q0, crit, step), rcrit, q0);
+          const double q = fma(fma(-q1, crit, step), rcrit, q1);
+          o = step < crit ? (float)(1.0 - q) : 0.0f;
+        }
         o = (m == m) ? o : qnan();
         out[mo + (size_t)j * g.rows + i] = o;
       }
@@ -245,16 +254,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
 }
 
 // resident wave slots of the device for a kernel compiled for `waves` waves per SIMD
-long wave_slots(int waves) {
-  static long simds = 0;
-  if (!simds) {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    simds = 4L * cus;
-  }
-  return simds * waves;
-}
+long wave_slots(int waves) { return 4L * device_cus() * waves; }
 
 template <int Q>
 void launch_height(const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
 }  // namespace
 
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream) {
+                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream) {
   MaskArgs m;
   m.slope_disc = p.slope_disc;
   m.step_disc = p.step_disc;
@@ -909,6 +909,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.def = p.def;
   a.inner_q = fast::footprint_inner_q(g.res, p.rmin, p.rmax);
   // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
+  if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream)) return hipGetLastError();
   if (fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream)) return hipGetLastError();
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;

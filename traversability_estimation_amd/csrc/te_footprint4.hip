@@ -1,15 +1,22 @@
-// te_footprint3.hip -- the sliding-sum kernel of the circular footprint pass, laid out like k_normals3.
+// te_footprint4.hip -- the sliding-sum kernel of the circular footprint pass on 32-bit fixed point.
 //
 //   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
 //     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
 //
-// Same arithmetic as k_fp_slide (te_footprint.hip): one double per cell, T' + 4096 U (T' = traversability, NaN ->
-// default; U = 1 for a cell that fails isTraversableForFilters), the disc sum slides one row per step, a disc without
-// an untraversable cell gives the mean, otherwise the lane walks the host-built SpiralIterator table over the rows in
-// the ring until the first untraversable cell.  What changed is the instruction stream (te_normals3.hip explains why
-// that is what counts on gfx950): ring of exactly 2R+2 rows addressed through rotating chunk base registers with
-// immediate offsets (no scalar ring bookkeeping: the old kernel issued 65 scalar instructions per row), one running
-// scalar row pointer per layer, 11-12 single-wave blocks per CU instead of 8.
+// k_fp_slide4 (te_footprint3.hip) slides one DOUBLE per cell and is bound by the instructions one wave can issue: 38
+// ds_read_b64 + 38 v_add_f64 + scalar and wait instructions per row, 3 waves per SIMD, 11 blocks per CU (13 KB rings).
+// The footprint value is a mean of at most a few hundred traversability values in [0, 1] compared at 1e-5 -- it does
+// not need 53 bits.  Here a cell is ONE 32-bit word
+//     cell = round(T' * 2^k) | U << 24        T' = traversability (NaN -> default), U = 1: fails isTraversableForFilters
+// with k chosen by the host such that the sum of one disc edge (2R+1 cells) stays below 2^24: the leading and the
+// trailing edge are each added up with v_add3_u32 in the packed form (T in bits 0..23, the number of untraversable
+// cells in bits 24..31, neither field can overflow), then  X += lead - trail  (mod 2^32) and  n_U += lead>>24 - trail>>24;
+// sum(T) = X - (n_U << 24) exactly.  Integer sums do not drift, so the slide is exact in the fixed-point values;
+// the only error is the rounding of T' to 2^-k (k = 19 at R = 9: 9.5e-7 per cell, hence for the mean).
+// Half the LDS (20 rows x 82 words = 6.5 KB: 16 blocks per CU, 4 waves per SIMD), half the LDS instructions
+// (ds_read2_b32 takes the cells e and -e of a row together), a third fewer vector instructions.
+// Used when the host can bound the traversability values (layer written by the chain with non-negative weights);
+// otherwise, and for radii whose k would drop below 17, k_fp_slide4 serves.
 #include "te_internal.h"
 #include "te_march.h"
 
@@ -20,11 +27,10 @@ namespace fast {
 
 namespace {
 
-constexpr int kF3Waves = 3;
-constexpr int kF3Head = 24;  // spiral entries every lane walks on its own before the wavefront takes the long walks over
-constexpr double kUOff3 = 4096.0;  // as in te_footprint.hip: sums of T' stay below it, so sum(T') and sum(U) split exactly
+constexpr int kF4Waves = 4;
+constexpr int kF4Head = 24;  // spiral entries every lane walks on its own before the wavefront takes the long walks over
 
-struct F3Args {
+struct F4Args {
   const float* trav;
   const uint8_t* untrav;
   float* footprint;
@@ -34,11 +40,13 @@ struct F3Args {
   int n_spiral;
   const int16_t* table;  // [n_spiral][4]: di, dj, ring (integer norm), tie flag (never set here: tie-free discs only)
   const int* gtab;       // clip table of the disc: {n, ...} per (ky, kx)
-  double rmin, rmax, def, res;
+  double rmin, rmax, res;
+  float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 24, scale = 2^k
+  double inv_scale;    // 2^-k
   int inner_q;  // see the tail, step (0)
 };
 
-constexpr int f3_chunk_rows(int NR) {
+constexpr int f4_chunk_rows(int NR) {
   const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 13, 17, 2};
   for (int c : pref)
     if (NR % c == 0) return c;
@@ -46,14 +54,14 @@ constexpr int f3_chunk_rows(int NR) {
 }
 
 template <int Q>
-__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves, 4))) void k_fp_slide3(F3Args a) {
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves, kF4Waves))) void k_fp_slide4(F4Args a) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
   constexpr int NR = 2 * R + 2;
-  constexpr int C = f3_chunk_rows(NR);
+  constexpr int C = f4_chunk_rows(NR);
   constexpr int NC = NR / C;
-  constexpr int RB = W * 8;
-  __shared__ double ring[NR * W];
+  constexpr int RB = W * 4;
+  __shared__ unsigned ring[NR * W];
   char* const ringb = reinterpret_cast<char*>(ring);
   typedef const float __attribute__((address_space(1))) cgfloat;
   typedef const uint8_t __attribute__((address_space(1))) cgbyte;
@@ -70,10 +78,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
 
   unsigned vb[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) vb[c] = (unsigned)(c * C * RB + lane * 8);
+  for (int c = 0; c < NC; ++c) vb[c] = (unsigned)(c * C * RB + lane * 4);
   const int hl = lane < 2 * R ? lane : 2 * R - 1;
   const int hcol = hl < R ? hl : kLanes + hl;
-  const int vhd = hcol * 8 - lane * 8;
+  const int vhd = hcol * 4 - lane * 4;
   const bool halo_in = i0 - R + hcol >= 0 && i0 - R + hcol < a.rows;
   const int lhalo = halo_in ? hcol - R : lane;
   const int icol = i0 + lane;
@@ -112,16 +120,17 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
   };
   auto stage_row = [&](int r, unsigned vbase, int ro, float pm, float ph, unsigned um, unsigned uh) __attribute__((always_inline)) {
     const bool rin = r >= 0 && r < a.cols;
-    const double tm = __builtin_isfinite(pm) ? (double)pm : a.def;  // :719-724
-    const double th = __builtin_isfinite(ph) ? (double)ph : a.def;
-    const double vm = fma((double)um, kUOff3, tm), vh = fma((double)uh, kUOff3, th);
-    *reinterpret_cast<double*>(ringb + vbase + (ro * RB + R * 8)) = rin ? vm : 0.0;  // cells outside the map: nothing
-    *reinterpret_cast<double*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0.0;
+    const float tm = __builtin_isfinite(pm) ? pm : a.def;  // :719-724
+    const float th = __builtin_isfinite(ph) ? ph : a.def;
+    // round(T' * 2^k): the product is exact, + 0.5 is exact below 2^23, the conversion truncates (and clamps at 0)
+    const unsigned vm = (unsigned)__builtin_fmaf(tm, a.scale, 0.5f) | (um << 24);
+    const unsigned vh = (unsigned)__builtin_fmaf(th, a.scale, 0.5f) | (uh << 24);
+    *reinterpret_cast<unsigned*>(ringb + vbase + (ro * RB + R * 4)) = rin ? vm : 0u;  // cells outside the map: nothing
+    *reinterpret_cast<unsigned*>(ringb + (vbase + vhd) + ro * RB) = (rin && halo_in) ? vh : 0u;
   };
   // The strip starts with its first disc summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1 (the layout
-  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, column by column (unrolled; as rolled loops the sum waited for every LDS read).  Sliding in
-  // from an empty disc cost 2R+1 full steps per strip (a fifth of the kernel on the 4096^2 map, all of it on a small
-  // one); the direct sum is about three steps' worth of instructions.  Every term is exact, so S is the same number.
+  // step j = js, u = 0 expects) C at a time, then every lane adds the cells of its disc, column by column (a column has
+  // at most 2R+1 cells, so its packed sum cannot overflow a field).
   __syncthreads();
   static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
@@ -133,34 +142,37 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k], umq[k], uhq[k]);  // rows j+2+R of the first C steps
 
-  double S = 0.0;
+  unsigned X = 0;   // sum over the disc of the packed cells, mod 2^32
+  unsigned NU = 0;  // untraversable cells in the disc (exact)
   static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
     constexpr int d = decltype(dc)::value;
     constexpr int h = Shape<Q>::hw(d);
-    double col = 0.0;
+    unsigned colp = 0, colm = 0;
     static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
       constexpr int p = R - h + decltype(rc)::value;  // ring row of map row js - h + rc
       const char* row = ringb + vb[p / C] + (p % C) * RB;
-      col += *reinterpret_cast<const double*>(row + (R + d) * 8);
-      if (d != 0) col += *reinterpret_cast<const double*>(row + (R - d) * 8);
+      colp += *reinterpret_cast<const unsigned*>(row + (R + d) * 4);
+      if (d != 0) colm += *reinterpret_cast<const unsigned*>(row + (R - d) * 4);
     });
-    S += col;
+    X += colp + colm;
+    NU += (colp >> 24) + (colm >> 24);
   });
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
   float out = 0.0f;
-  double rnt = 1.0 / (double)nt_mid;
+  const float rnt = (float)(a.inv_scale / (double)nt_mid);
   const double drmin = a.rmin, inv_span = 1.0 / (a.rmax - a.rmin);
 
   auto tail = [&](int j, int u) __attribute__((always_inline)) {
     int nt = nt_mid;
-    double rn = rnt;
+    float rn = rnt;
     const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
     if (__builtin_expect(ky != 0, 0)) {
       nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
-      rn = 1.0 / (double)nt;
+      rn = (float)(a.inv_scale / (double)nt);
     }
-    out = (float)(S * rn);  // :732-735 no untraversable cell in the footprint: the mean
-    const bool blocked = S >= 0.5 * kUOff3;
+    const unsigned T = X - (NU << 24);  // sum of the fixed-point traversabilities of the disc, exact
+    out = (float)T * rn;  // :732-735 no untraversable cell in the footprint: the mean (T < 2^29: the conversion is good to 2^-25)
+    const bool blocked = NU != 0;
     if (__builtin_expect(__any(blocked), 0)) {
       // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
       // oldest row of the ring, which is row u of the chunk vb[0] points to.
@@ -192,9 +204,9 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
         int hits = 0;
         for (int dj = -dm; dj <= dm; ++dj) {
           const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
-          const double* row = ring + slot_of(dj) * W + lane + R;
+          const unsigned* row = ring + slot_of(dj) * W + lane + R;
 #pragma unroll 8
-          for (int di = -hwi; di <= hwi; ++di) hits += row[di] >= 0.5 * kUOff3 ? 1 : 0;
+          for (int di = -hwi; di <= hwi; ++di) hits += (int)(row[di] >> 24);
         }
         if (hits > 0) {
           out = 0.0f;
@@ -204,12 +216,12 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
       // (1) every lane walks the head of its own spiral, eight entries per trip with their eight ring cells fetched
       // together (one entry per trip made every lane wait for a table load and an LDS read in turn).  Pointless after (0).
       if (!found && a.inner_q < 8) {
-        double t = 0.0;
+        unsigned tq = 0;  // fixed-point sum of the cells before the first untraversable one (exact)
         int ncells = 0;
         const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
-        const int n_head = a.n_spiral < kF3Head ? a.n_spiral : kF3Head;
+        const int n_head = a.n_spiral < kF4Head ? a.n_spiral : kF4Head;
         for (int k0 = 0; k0 < n_head && !found; k0 += 8) {
-          double v[8];
+          unsigned v[8];
           bool in[8];
           int ring_no[8];
 #pragma unroll
@@ -225,12 +237,12 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             if (found || !in[q]) continue;
-            if (v[q] >= 0.5 * kUOff3) {
-              out = value_at(ring_no[q], t, ncells);
+            if ((v[q] >> 24) != 0) {
+              out = value_at(ring_no[q], (double)tq * a.inv_scale, ncells);
               found = true;
             } else {
               ncells++;
-              t += v[q];
+              tq += v[q];
             }
           }
         }
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
         const int l = __builtin_ctzll(rest);
         rest &= rest - 1ull;
         const int ic = i0 + l;
-        double acc = 0.0;
+        unsigned acc = 0;
         int cnt = 0;
         float oc = __builtin_nanf("");
         bool done = false;
@@ -256,8 +268,8 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
           const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
           const int ii = ic + di, jj = j + dj;
           const bool in = valid && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
-          const double v = ring[slot_of(dj) * W + l + R + di];
-          const unsigned long long bm = __ballot(in && v >= 0.5 * kUOff3);
+          const unsigned v = ring[slot_of(dj) * W + l + R + di];
+          const unsigned long long bm = __ballot(in && (v >> 24) != 0);
           if (bm != 0ull) {
             const int first = __builtin_ctzll(bm);
             const int ring_first = __builtin_amdgcn_readlane((int)((w >> 16) & 0xffu), first);
@@ -267,14 +279,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
               return;
             }
             const bool before = in && lane < first;
-            acc += before ? v : 0.0;
+            acc += before ? v : 0u;
             cnt += __popcll(__ballot(before));
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);  // exact terms (see slide): any order
-            oc = value_at(ring_first, acc, cnt);
+            for (int d = 32; d >= 1; d >>= 1) acc += (unsigned)__shfl_xor((int)acc, d);  // integers: any order
+            oc = value_at(ring_first, (double)acc * a.inv_scale, cnt);
             return;
           }
-          acc += in ? v : 0.0;
+          acc += in ? v : 0u;
           cnt += __popcll(__ballot(in));
         });
         if (lane == l) out = oc;  // an untraversable cell is in the disc, so oc was set
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
 
   auto slide = [&](auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
-    double acc = 0.0;
+    unsigned lead = 0, trail = 0;  // packed sums of the 2R+1 cells of the leading / trailing edge (no field overflows)
     static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
       constexpr int d = decltype(dc)::value;
       constexpr int h = Shape<Q>::hw(d);
@@ -292,17 +304,20 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
       constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
       const char* rl = ringb + vb[al];
       const char* rt = ringb + vb[at];
-      const double zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + d) * 8));
-      const double zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + d) * 8));
+      const unsigned zl = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R + d) * 4));
+      const unsigned zt = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R + d) * 4));
       if (d == 0) {
-        acc = zl - zt;
+        lead += zl;
+        trail += zt;
       } else {
-        const double zl2 = *reinterpret_cast<const double*>(rl + (ol * RB + (R - d) * 8));
-        const double zt2 = *reinterpret_cast<const double*>(rt + (ot * RB + (R - d) * 8));
-        acc += (zl - zt) + (zl2 - zt2);
+        const unsigned zl2 = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R - d) * 4));
+        const unsigned zt2 = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R - d) * 4));
+        lead += zl + zl2;
+        trail += zt + zt2;
       }
     });
-    S += acc;  // every term is exact (multiples of the float quantum below 2^53), so is any order
+    X += lead - trail;
+    NU += (lead >> 24) - (trail >> 24);
   };
 
   int j = js;
@@ -335,12 +350,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF3Waves
 }
 
 template <int Q>
-void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
-  F3Args a = a0;
+void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
+  F4Args a = a0;
   constexpr int R = Shape<Q>::R;
-  constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8;
+  constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 4;
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
-  if (per_cu > 16) per_cu = 16;
+  if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;
+  static const int per_cu_env = getenv("TE_F4_BLOCKS_PER_CU") ? atoi(getenv("TE_F4_BLOCKS_PER_CU")) : 0;  // measurement aid
+  if (per_cu_env > 0) per_cu = per_cu_env;
   const int capacity = per_cu * device_cus();
   const int per_row = a.nbx * (batch > 0 ? batch : 1);
   int strips = capacity / per_row;
@@ -348,25 +365,25 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
   int sr = (a.cols + strips - 1) / strips;
   // small maps cannot fill the wave slots: every resident block runs at once, so the launch takes one warm-up plus the
   // rows of one strip -- the shortest strips win (the spiral walks of a row are serial within its wavefront)
-  static const int min_strip = getenv("TE_F3_MIN_STRIP") ? atoi(getenv("TE_F3_MIN_STRIP")) : 1;
+  static const int min_strip = getenv("TE_F4_MIN_STRIP") ? atoi(getenv("TE_F4_MIN_STRIP")) : 1;
   sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
   sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
   const int nstrips = (a.cols + sr - 1) / sr;
-  hipLaunchKernelGGL((k_fp_slide3<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
+  hipLaunchKernelGGL((k_fp_slide4<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
 }
 
 }  // namespace
 
 // Shapes: every disc shape up to radius 10 (te_march.h) except the single cell, and for radii 11 .. 16 (the default
 // footprint, 0.45 m, is 15 cells at 0.03 m) every sum of two squares up to 256.  Compiled in TE_PARTS parts like
-// te_normals3.hip (build.py): part k instantiates its list and exports one launcher, part 0 also holds footprint_slide3.
-#define TE_F3_P0(X) X(4) X(16) X(26) X(37) X(50) X(65) X(73) X(85) X(100) X(121) X(136) X(148) X(162) X(178) X(193) X(202) X(212) X(229) X(256)
-#define TE_F3_P1(X) X(10) X(13) X(25) X(36) X(49) X(64) X(82) X(98) X(109) X(117) X(130) X(146) X(160) X(173) X(185) X(200) X(226) X(241) X(250)
-#define TE_F3_P2(X) X(9) X(20) X(34) X(45) X(58) X(61) X(81) X(97) X(106) X(116) X(128) X(145) X(157) X(170) X(181) X(197) X(225) X(234) X(245)
-#define TE_F3_P3(X) X(2) X(8) X(18) X(32) X(41) X(53) X(72) X(80) X(90) X(104) X(113) X(125) X(144) X(153) X(169) X(196) X(208) X(221) X(233) X(244)
-#define TE_F3_P4(X) X(1) X(5) X(17) X(29) X(40) X(52) X(68) X(74) X(89) X(101) X(122) X(137) X(149) X(164) X(180) X(194) X(205) X(218) X(232) X(242)
-#if !defined(TE_PARTS) || defined(TE_F3_SHAPES)
+// te_normals3.hip (build.py): part k instantiates its list and exports one launcher, part 0 also holds footprint_slide4.
+#define TE_F4_P0(X) X(4) X(16) X(26) X(37) X(50) X(65) X(73) X(85) X(100) X(121) X(136) X(148) X(162) X(178) X(193) X(202) X(212) X(229) X(256)
+#define TE_F4_P1(X) X(10) X(13) X(25) X(36) X(49) X(64) X(82) X(98) X(109) X(117) X(130) X(146) X(160) X(173) X(185) X(200) X(226) X(241) X(250)
+#define TE_F4_P2(X) X(9) X(20) X(34) X(45) X(58) X(61) X(81) X(97) X(106) X(116) X(128) X(145) X(157) X(170) X(181) X(197) X(225) X(234) X(245)
+#define TE_F4_P3(X) X(2) X(8) X(18) X(32) X(41) X(53) X(72) X(80) X(90) X(104) X(113) X(125) X(144) X(153) X(169) X(196) X(208) X(221) X(233) X(244)
+#define TE_F4_P4(X) X(1) X(5) X(17) X(29) X(40) X(52) X(68) X(74) X(89) X(101) X(122) X(137) X(149) X(164) X(180) X(194) X(205) X(218) X(232) X(242)
+#if !defined(TE_PARTS) || defined(TE_F4_SHAPES)
 #undef TE_PARTS
 #undef TE_PART
 #define TE_PARTS 1
@@ -375,27 +392,27 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
 #if TE_PARTS != 1 && TE_PARTS != 5
 #error "te_footprint3.hip is cut into 1 or 5 parts"
 #endif
-#ifndef TE_F3_SHAPES
+#ifndef TE_F4_SHAPES
 #if TE_PARTS == 1
-#define TE_F3_SHAPES(X) TE_F3_P0(X) TE_F3_P1(X) TE_F3_P2(X) TE_F3_P3(X) TE_F3_P4(X)
+#define TE_F4_SHAPES(X) TE_F4_P0(X) TE_F4_P1(X) TE_F4_P2(X) TE_F4_P3(X) TE_F4_P4(X)
 #else
-#define TE_F3_CAT2(a, b) a##b
-#define TE_F3_CAT(a, b) TE_F3_CAT2(a, b)
-#define TE_F3_SHAPES(X) TE_F3_CAT(TE_F3_P, TE_PART)(X)
+#define TE_F4_CAT2(a, b) a##b
+#define TE_F4_CAT(a, b) TE_F4_CAT2(a, b)
+#define TE_F4_SHAPES(X) TE_F4_CAT(TE_F4_P, TE_PART)(X)
 #endif
 #endif
-#define TE_F3_NAME2(k) f3_launch_part##k
-#define TE_F3_NAME(k) TE_F3_NAME2(k)
+#define TE_F4_NAME2(k) f4_launch_part##k
+#define TE_F4_NAME(k) TE_F4_NAME2(k)
 
-// launches shape Q if it belongs to this part (args: the F3Args block of part 0 -- the same struct in every part)
-bool TE_F3_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
-  const F3Args& a = *static_cast<const F3Args*>(args);
+// launches shape Q if it belongs to this part (args: the F4Args block of part 0 -- the same struct in every part)
+bool TE_F4_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
+  const F4Args& a = *static_cast<const F4Args*>(args);
   switch (Q) {
 #define X(q)                  \
   case q:                     \
-    launch_f3<q>(a, batch, s); \
+    launch_f4<q>(a, batch, s); \
     return true;
-    TE_F3_SHAPES(X)
+    TE_F4_SHAPES(X)
 #undef X
     default:
       return false;
@@ -404,31 +421,31 @@ bool TE_F3_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
 
 #if TE_PART == 0
 #if TE_PARTS > 1
-bool f3_launch_part1(int Q, const void* args, int batch, hipStream_t s);
-bool f3_launch_part2(int Q, const void* args, int batch, hipStream_t s);
-bool f3_launch_part3(int Q, const void* args, int batch, hipStream_t s);
-bool f3_launch_part4(int Q, const void* args, int batch, hipStream_t s);
+bool f4_launch_part1(int Q, const void* args, int batch, hipStream_t s);
+bool f4_launch_part2(int Q, const void* args, int batch, hipStream_t s);
+bool f4_launch_part3(int Q, const void* args, int batch, hipStream_t s);
+bool f4_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
-// Largest di^2 + dj^2 of the spiral rings that lie within the inner radius (ring * res <= rmin, getCurrentRadius()'s
-// integer norm) and that SpiralIterator takes without its circle test (all but the two outermost); -1: no such ring.
-int footprint_inner_q(double res, double rmin, double rmax) {
-  const int nrings = (int)ceil(rmax / res);
-  int d = -1;
-  while (d + 1 <= nrings - 2 && (double)(d + 1) * res <= rmin) ++d;
-  return d < 0 ? -1 : (d + 1) * (d + 1) - 1;
-}
-
-// The sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken.
-bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      hipStream_t s) {
+// The fixed-point sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not
+// taken.  tcap: upper bound of the finite values of the traversability layer, as the host can prove it (the layer was
+// written by the chain: w_scale * (w_slope + w_step + w_rough) with non-negative weights); < 0: unknown.
+bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
+                      double tcap, hipStream_t s) {
   const Disc& d = p.fp_disc;
-  static const bool off = getenv("TE_NO_F3") != nullptr;
+  static const bool off = getenv("TE_NO_F4") != nullptr;
   if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
     return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
   if (p.n_spiral > ((int)(3.2 * (d.R + 1) * (d.R + 1) / kLanes) + 1) * kLanes) return false;  // the kernel's table registers
-  F3Args a;
+  // the fixed-point scale: (2R+1) cells of at most cap * 2^k + 1/2 each must stay below 2^24 (the packed edge sums), and
+  // the default value that replaces NaN has to fit as well
+  if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
+  const double cap = (tcap > p.def ? tcap : p.def) * (1.0 + 1e-6) + 1e-12;
+  int k = 23;
+  while (k >= 0 && (double)(2 * d.R + 1) * (cap * ldexp(1.0, k) + 1.0) >= 16777216.0) --k;
+  if (k < 17) return false;  // rounding each value to 2^-17 could show at the 1e-5 level: the double kernel serves
+  F4Args a;
   a.trav = L.trav;
   a.untrav = L.untrav;
   a.footprint = L.footprint;
@@ -442,13 +459,15 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.gtab = clip_table;
   a.rmin = p.rmin;
   a.rmax = p.rmax;
-  a.def = p.def;
+  a.def = (float)p.def;
+  a.scale = (float)ldexp(1.0, k);
+  a.inv_scale = ldexp(1.0, -k);
   a.res = g.res;
   a.inner_q = footprint_inner_q(g.res, p.rmin, p.rmax);
-  if (f3_launch_part0(d.Q, &a, g.batch, s)) return true;
+  if (f4_launch_part0(d.Q, &a, g.batch, s)) return true;
 #if TE_PARTS > 1
-  if (f3_launch_part1(d.Q, &a, g.batch, s) || f3_launch_part2(d.Q, &a, g.batch, s) || f3_launch_part3(d.Q, &a, g.batch, s) ||
-      f3_launch_part4(d.Q, &a, g.batch, s))
+  if (f4_launch_part1(d.Q, &a, g.batch, s) || f4_launch_part2(d.Q, &a, g.batch, s) || f4_launch_part3(d.Q, &a, g.batch, s) ||
+      f4_launch_part4(d.Q, &a, g.batch, s))
     return true;
 #endif
   return false;

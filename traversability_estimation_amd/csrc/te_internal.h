@@ -1,5 +1,6 @@
 // te_internal.h -- shared between the C-ABI shim (te_shim.hip) and the gfx950 kernels (te_kernels.hip).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -145,14 +146,31 @@ struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 
               // only discs that lie inside the map), whatever the flags and the slope layer say
 };
 
+// Compute units of the CURRENT device (hipGetDevice), cached per device; the launchers size their grids from it.
+// (A function-local static of the first device's count would be a data race with one context per thread and the
+// wrong capacity on a node with different devices.)
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess) return cus;
+  if (dev >= 0 && dev < 64) {
+    const int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+  }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
 // launch wrappers (te_kernels.hip); all asynchronous on `stream`
 hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, int filter, unsigned flags,
                          hipStream_t stream);
 hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, unsigned flags,
                         hipStream_t stream);
 // spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)
+// trav_cap: upper bound of the finite traversability values if the layer was written by the chain (see footprint_slide4), else < 0
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, const ChainParams* combine, hipStream_t stream);
+                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream);
 int chain_max_reach(const ChainParams& p);
 // te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map;
 // robot_slope: the layer checkInclination reads (nullptr: footprint/check_robot_inclination off)
@@ -181,6 +199,10 @@ int normals_fast_max_blocks(const Geo& g);
 // te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)
 bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       hipStream_t s);
+// te_footprint4.hip: the same on 32-bit fixed point, when the values of the traversability layer are bounded by tcap
+// (tcap < 0: no bound known)
+bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
+                      double tcap, hipStream_t s);
 void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -138,6 +139,9 @@ struct te_ctx {
   int* clip_table = nullptr;
   int* fp_clip_table = nullptr;
   bool combine_deferred = false;
+  // the traversability layer was written from outside (upload, device pointer, a per-plugin combine of uploaded scores):
+  // its values are then not bounded by the weights, and the fixed-point footprint kernel must not be used
+  bool trav_external = false;
   bool tables_ready = false;
   // the circular-footprint tables are built separately: a footprint this build cannot handle (more than 20 cells) must
   // not stop the filter chain or the per-plugin entry points, which never use them (the reference has no such coupling)
@@ -377,6 +381,10 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.aux_stream = (flags & TE_RUN_SEQUENTIAL) ? nullptr : c->aux_stream;
   // whole-map run with the footprint pass right behind: the mask kernel writes the combined layer
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
+  // (only if the footprint pass can run at all: with a footprint this build cannot handle the combined layer would
+  // never be written)
+  if ((flags & TE_RUN_FOOTPRINT) && !c->fp_tables_ready)
+    return fail(c->fp_tables_rc ? c->fp_tables_rc : TE_ERR_NOT_READY, "%s", c->fp_tables_err[0] ? c->fp_tables_err : "footprint tables not built");
   c->combine_deferred = (r.map < 0) && c->L.aux_stream && (flags & TE_RUN_FOOTPRINT);
   if (c->combine_deferred) flags |= kDeferCombine;
   c->L.ev_fork = c->ev_fork;
@@ -384,6 +392,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   c->footprint_done = false;  // the layers the footprint pass reads have changed
+  if (r.map < 0) c->trav_external = false;  // every cell of the combined layer now comes from the chain
   return TE_OK;
 }
 
@@ -392,8 +401,12 @@ int run_footprint_locked(te_ctx* c, unsigned flags) {
     return fail(TE_ERR_NOT_READY, "te_run_footprint: run the filter chain first (it produces the layers the footprint reads)");
   if (!c->fp_tables_ready) return fail(c->fp_tables_rc ? c->fp_tables_rc : TE_ERR_NOT_READY, "%s", c->fp_tables_err);
   HIP_TRY(hipSetDevice(c->device));
+  // bound of the combined layer, if the chain wrote it: scores lie in [0, 1], so w_scale * (w_slope + w_step + w_rough)
+  const ChainParams& q = c->cp;
+  const bool bounded = !c->trav_external && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
+  const double trav_cap = bounded ? (double)q.w_scale * ((double)q.w_slope + (double)q.w_step + (double)q.w_rough) : -1.0;
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
-                           c->combine_deferred ? &c->cp : nullptr, c->stream));
+                           c->combine_deferred ? &c->cp : nullptr, trav_cap, c->stream));
   c->combine_deferred = false;
   c->footprint_done = true;
   return TE_OK;
@@ -717,6 +730,7 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
   *dptr = p;
   if (bytes) *bytes = c->layer_elems * sizeof(float);
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
   if (layer == TE_LAYER_ELEVATION) {  // caller fills the elevation in place (zero-copy producer)
     c->have_elev = true;
     c->chain_done = false;
@@ -740,6 +754,7 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
   HIP_TRY(hipMemcpyAsync(p + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
   return TE_OK;
 }
 
@@ -801,6 +816,7 @@ static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host
     c->footprint_done = false;
   }
   if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
   return TE_OK;
 }
 
@@ -948,6 +964,12 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
     return fail(TE_ERR_NOT_READY, "te_run_filter: no elevation uploaded");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
+  // A single plugin's filter overwrites score layers from whatever inputs are resident (TE_FILTER_NORMALS also slope
+  // and roughness, with the normals radius): the layers no longer form one chain result, so region re-filters, the
+  // footprint pass and the path checks must not build on them.
+  c->chain_done = false;
+  c->footprint_done = false;
+  c->trav_external = true;
   return TE_OK;
 }
 
@@ -966,8 +988,12 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
       col0 + w > c->geo.cols)
     return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: rectangle outside the map");
   if (!c->chain_done) return fail(TE_ERR_NOT_READY, "te_run_chain_region: run the full chain once first");
+  // The footprint of a re-filtered rectangle is not computed by this call: a caller that asked for it must not get
+  // TE_OK and a stale traversability_footprint layer (te_run_footprint refreshes the whole layer).
+  if (flags & (TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO))
+    return fail(TE_ERR_UNSUPPORTED, "te_run_chain_region: TE_RUN_FOOTPRINT is a whole-map pass, call te_run_footprint after the region runs");
   const Region r = {map, row0, col0, row0 + h, col0 + w};
-  return run_chain_locked(c, flags & ~TE_RUN_FOOTPRINT, r);
+  return run_chain_locked(c, flags, r);
 }
 
 int te_run_footprint(te_ctx* c) {
@@ -1352,6 +1378,19 @@ int te_sync(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);
   HIP_TRY(hipSetDevice(c->device));
+  // A blocking hipStreamSynchronize parks the thread and is woken by an interrupt; for the launches of this library
+  // (a few hundred microseconds) that wake-up is a visible part of the latency, so the stream is polled first
+  // (TE_SYNC_SPIN_US microseconds, default 2000; 0: block at once).
+  static const long spin_us = getenv("TE_SYNC_SPIN_US") ? atol(getenv("TE_SYNC_SPIN_US")) : 2000;
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) return TE_OK;
+      if (e != hipErrorNotReady) return fail(TE_ERR_HIP, "te_sync: %s", hipGetErrorString(e));
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return TE_OK;
 }

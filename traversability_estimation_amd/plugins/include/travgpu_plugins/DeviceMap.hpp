@@ -29,7 +29,8 @@ class DeviceMap {
   // copy of the whole map (SlopeFilter.cpp:62, StepFilter.cpp:105, RoughnessFilter.cpp:76), so StepFilter and
   // RoughnessFilter both arrive with the same `elevation`, SlopeFilter and RoughnessFilter with the same
   // `surface_normal_z`.  A device layer is identified by the map's time stamp, geometry and start index plus a hash of
-  // the buffer (sampled; TRAVGPU_PLUGIN_HASH=full hashes every cell, TRAVGPU_PLUGIN_CACHE=0 always uploads).
+  // the buffer (every cell; TRAVGPU_PLUGIN_HASH=sampled reads ~4096 cells and then relies on the stamp, TRAVGPU_PLUGIN_CACHE=0
+  // always uploads).
   bool upload(const grid_map::GridMap& map, const std::string& layer, int te_layer);
   // after a download into `layer`: the device layer and that host buffer are the same thing
   bool noteResident(const grid_map::GridMap& map, const std::string& layer, int te_layer);

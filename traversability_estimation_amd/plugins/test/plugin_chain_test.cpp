@@ -175,6 +175,22 @@ static void test_device() {
     CHECK(dev.uploads() - up0 == 5);
     CHECK(t->update(map0, b));  // and back: the device layer is identified, not assumed
     CHECK(dev.uploads() - up0 == 6);
+    // one cell edited in place under the SAME stamp (inpainting, a local update): it must be uploaded, not taken for
+    // the resident layer, wherever the cell lies
+    grid_map::GridMap edited = map0;
+    edited["elevation"](rows - 2, cols / 2 + 1) += 0.5f;
+    grid_map::GridMap e1, e2;
+    CHECK(t->update(edited, e1));
+    CHECK(dev.uploads() - up0 == 7);
+    CHECK(t->update(map0, e2));
+    CHECK(dev.uploads() - up0 == 8);
+    {
+      const grid_map::Matrix &a = e1["traversability_step"], &b = e2["traversability_step"];
+      size_t differ = 0;
+      for (size_t k = 0; k < (size_t)a.rows() * a.cols(); ++k)
+        if (memcmp(a.data() + k, b.data() + k, 4) != 0) ++differ;
+      CHECK(differ > 0);  // the edited cell reached the device
+    }
   }
   std::printf("drop-in plugins (Slope -> Step -> Roughness):\n");
   CHECK(compare("traversability_slope", m3["traversability_slope"], sl) == 0);
