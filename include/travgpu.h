@@ -187,7 +187,24 @@ int te_run_filter(te_ctx* ctx, int filter, unsigned flags);
 int te_run_chain(te_ctx* ctx, unsigned flags);
 /* Re-filter only the cells whose outputs can change when the h x w rectangle at (row0,col0) of map
  * `map` changed (the rectangle dilated by the chain's reach). */
+/* With TE_RUN_FOOTPRINT (| TE_RUN_FOOTPRINT_MEMO) the circular footprint pass follows on the cells that can see the
+ * change (the re-filtered cells grown by 3 cells for isTraversableForFilters and by the footprint's reach); the
+ * traversability_footprint layer must have been complete before (te_run_chain with the flag, or te_run_footprint),
+ * TE_ERR_NOT_READY otherwise.  The caller of the reference's node re-filters the whole map on every update
+ * (TraversabilityMap.cpp:202-237); this is the incremental form of the same call. */
 int te_run_chain_region(te_ctx* ctx, unsigned flags, int map, int row0, int col0, int h, int w);
+/* The h x w rectangle at (row0, col0) of a layer of map `map` into a packed column-major h x w host tile (the layout
+ * te_upload_tile reads); returns when the tile is in host memory. */
+int te_download_tile(te_ctx* ctx, int layer, int map, int row0, int col0, int h, int w, float* host_tile);
+/* Streaming updates (BASELINE configs[4]: a resident map, one dirty tile per tick).  te_upload_tile_async returns at
+ * once: the tile crosses PCIe on the context's copy-in stream into a device staging slot -- concurrently with the kernels
+ * of the previous tick -- and is placed into the elevation layer on the compute stream, in order with the launches
+ * that follow (te_run_chain_region).  te_download_tile_async is its mirror: the rectangle is copied to a staging slot in
+ * order with the launches before it and crosses PCIe on the copy-out stream while the next tick computes.  Two slots
+ * each way.  host_tile must stay valid until te_sync (which waits for all three streams) -- page-lock it (te_pin_host),
+ * otherwise the runtime stages the copy itself and the call blocks for its duration. */
+int te_upload_tile_async(te_ctx* ctx, const float* host_tile, int map, int row0, int col0, int h, int w);
+int te_download_tile_async(te_ctx* ctx, int layer, int map, int row0, int col0, int h, int w, float* host_tile);
 int te_run_footprint(te_ctx* ctx);
 /* Batched TraversabilityMap::checkFootprintPath for circular footprints (TraversabilityMap.cpp:320-342 ->
  * checkCircularFootprintPath :344-462) on the resident traversability_footprint layer of map `map`, which must be

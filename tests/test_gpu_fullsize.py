@@ -167,3 +167,95 @@ def test_streaming_dirty_tiles(capi):
                 a, b = inc.download(k), ref.download(k)
                 n_bad, mx, _ = compare_layer(k, a, b)
                 assert n_bad == 0, (tick, k, n_bad, mx)
+
+
+def test_cfg4_true_size_batch_of_512_maps(capi, oracle):
+    """BASELINE configs[3] at its own size: 512 maps of 512 x 512, radius 5, one launch (the batch axis that the ranks
+    shard).  The MPC-rollout shape: one base map + N(0, 1 cm) perturbations, seed = map index.  Eight maps spread over
+    the batch against the oracle (chain + footprint); a map uploaded twice gives the same bits in both slots."""
+    from traversability_estimation_amd import synth
+    rows = cols = 512
+    res, B = 0.05, 512
+    base = synth.perlin_elevation(rows, cols, seed=2000)
+    per = rows * cols
+    p = bench_params(capi, synth, 5, res)
+    picks = (0, 1, 63, 200, 255, 256, 400, 511)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(rows, cols, B, res)
+        kept = {}
+        for b0 in range(0, B, 64):  # uploaded in blocks of 64 maps (64 MiB of host memory at a time)
+            blk = np.stack([(base + np.random.default_rng(2000 + b).normal(0.0, 0.01, size=base.shape).astype(np.float32)).astype(np.float32)
+                            for b in range(b0, b0 + 64)])
+            for b in picks:
+                if b0 <= b < b0 + 64:
+                    kept[b] = blk[b - b0].copy()
+            if b0 == 256:
+                blk[44] = kept[200]  # slot 300 holds map 200 again
+            ctx.upload_elevation(blk, map0=b0)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in ALL}
+    for k in ALL:
+        a = got[k]
+        assert np.array_equal(a[200 * per:201 * per].view(np.uint32), a[300 * per:301 * per].view(np.uint32)), k
+    op = oracle_params(oracle, p)
+    oracle.set_threads(8)
+    try:
+        g = oracle.geom(rows, cols, res)
+        for b in picks:
+            want = oracle.chain(g, op, kept[b])
+            want["traversability_footprint"] = oracle.footprint(g, op, kept[b], want)
+            assert_layers_match({k: got[k][b * per:(b + 1) * per] for k in ALL}, want, layers=ALL, ctx=f"cfg4 map {b} of 512")
+    finally:
+        oracle.set_threads(1)
+
+
+def test_cfg5_true_size_streaming_8192(capi, oracle):
+    """BASELINE configs[4] at its own size: an 8192 x 8192 resident map, 256 x 256 dirty tiles, re-filter of the dirty
+    region incl. the footprint pass.  After every tick the oracle runs on a crop around the tile that holds the tile's
+    whole zone of influence (chain reach 10, mask 3, footprint 9 cells, plus as much again for the crop's cut edges)."""
+    from traversability_estimation_amd import synth
+    n, res, tile = 8192, 0.05, 256
+    # (a 2048^2 noise map repeated 4 x 4 under a slow ramp: the generator needs a minute for 8192^2, the content is beside the point)
+    elev = np.tile(synth.perlin_elevation(2048, 2048, seed=77).reshape(2048, 2048), (4, 4))
+    elev = (elev + np.linspace(0.0, 1.5, n, dtype=np.float32)[None, :]).astype(np.float32)
+    p = bench_params(capi, synth, 5, res)
+    op = oracle_params(oracle, p)
+    rng = np.random.default_rng(78)
+    reach = 2 * 5 + 3 + 9 + 2  # cells beyond the tile whose outputs can change
+    margin = reach + 2 * 5 + 12  # cells of a crop that see its cut edge
+    oracle.set_threads(8)
+    try:
+        with capi.Context(0) as ctx:
+            ctx.set_params(p)
+            ctx.set_geometry(n, n, 1, res)
+            ctx.upload_elevation(elev)
+            ctx.run_chain(capi.RUN_FOOTPRINT)
+            for tick in range(5):
+                r0, c0 = (int(v) for v in rng.integers(0, n - tile, size=2))
+                if tick == 1:
+                    r0, c0 = n - tile, 0          # a corner
+                if tick == 2:
+                    r0, c0 = 4000, n - tile - 3   # three cells from the right border
+                patch = (synth.perlin_elevation(tile, tile, seed=3000 + tick).reshape(tile, tile) * np.float32(0.6)).astype(np.float32)
+                elev[c0:c0 + tile, r0:r0 + tile] = patch
+                ctx.upload_tile(np.ascontiguousarray(patch), 0, r0, c0)
+                ctx.run_chain_region(0, r0, c0, tile, tile, flags=capi.RUN_FOOTPRINT)
+                ctx.sync()
+                # crop = zone of influence + margin, clipped to the map
+                i_lo, i_hi = max(0, r0 - reach - margin), min(n, r0 + tile + reach + margin)
+                j_lo, j_hi = max(0, c0 - reach - margin), min(n, c0 + tile + reach + margin)
+                crop = np.ascontiguousarray(elev[j_lo:j_hi, i_lo:i_hi])
+                g = oracle.geom(i_hi - i_lo, j_hi - j_lo, res)
+                want = oracle.chain(g, op, crop)
+                want["traversability_footprint"] = oracle.footprint(g, op, crop, want)
+                ki = slice(0 if i_lo == 0 else margin, (i_hi - i_lo) if i_hi == n else (i_hi - i_lo) - margin)
+                kj = slice(0 if j_lo == 0 else margin, (j_hi - j_lo) if j_hi == n else (j_hi - j_lo) - margin)
+                for k in ALL:
+                    a = ctx.download_tile(k, 0, i_lo, j_lo, i_hi - i_lo, j_hi - j_lo)[kj, ki]
+                    b = want[k].reshape(j_hi - j_lo, i_hi - i_lo)[kj, ki]
+                    n_bad, mx, _ = compare_layer(k, a, b)
+                    assert n_bad == 0, (tick, k, n_bad, mx)
+    finally:
+        oracle.set_threads(1)

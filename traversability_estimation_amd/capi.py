@@ -29,7 +29,8 @@ RUN_NORMALS_ONLY = 0x20
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
-           "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile",
+           "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile", "te_download_tile",
+           "te_upload_tile_async", "te_download_tile_async",
            "te_device_ptr", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
            "te_download_layer", "te_time_chain", "te_time_chain_samples", "te_last_error", "te_version",
@@ -127,6 +128,9 @@ def load():
         L.te_set_geometry.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.te_upload_elevation.argtypes = [vp, fp, C.c_int, C.c_int]
         L.te_upload_tile.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.te_download_tile.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.te_upload_tile_async.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.te_download_tile_async.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.te_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_upload_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
@@ -349,6 +353,28 @@ class Context:
         w, h = t.shape
         _check(load().te_upload_tile(self._h, t.ctypes.data_as(C.POINTER(C.c_float)), int(map_index), int(row0),
                                      int(col0), int(h), int(w)))
+
+    def download_tile(self, layer, map_index, row0, col0, h, w):
+        """The h x w rectangle of a layer as an array of shape (w, h) == [col][row]."""
+        t = np.empty((int(w), int(h)), np.float32)
+        _check(load().te_download_tile(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), int(map_index), int(row0),
+                                       int(col0), int(h), int(w), t.ctypes.data_as(C.POINTER(C.c_float))))
+        return t
+
+    def upload_tile_async(self, tile, map_index, row0, col0):
+        """As upload_tile, but returns at once (copy-in stream + staging slot); `tile` must be a C-contiguous float32 array of
+        shape (w, h) that stays alive and unchanged until sync() -- page-lock it (pin_host) for a truly asynchronous copy."""
+        assert tile.dtype == np.float32 and tile.flags["C_CONTIGUOUS"], "upload_tile_async: float32, C-contiguous (no hidden copy)"
+        w, h = tile.shape
+        _check(load().te_upload_tile_async(self._h, tile.ctypes.data_as(C.POINTER(C.c_float)), int(map_index), int(row0), int(col0),
+                                           int(h), int(w)))
+
+    def download_tile_async(self, layer, map_index, row0, col0, out):
+        """The rectangle of shape out.shape == (w, h) into `out` (float32, C-contiguous); valid after sync()."""
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+        w, h = out.shape
+        _check(load().te_download_tile_async(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), int(map_index),
+                                             int(row0), int(col0), int(h), int(w), out.ctypes.data_as(C.POINTER(C.c_float))))
 
     def device_ptr(self, layer):
         p, n = C.c_void_p(), C.c_size_t()

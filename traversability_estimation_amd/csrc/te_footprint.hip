@@ -248,6 +248,7 @@ struct MaskArgs {
   int edge_fail;  // submap_edge_failures(): border sides on which the 2.5*res submap lookup fails
   int combine;  // also write traversability = w_scale*((w_slope*slope + w_step*step) + w_rough*roughness) (float32)
   float w_scale, w_slope, w_step, w_rough;
+  int ti0, tj0, map;  // first tile of the launch (in tiles of MX x MY cells) and the map (< 0: blockIdx.z): region runs
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // straight from global memory.
   constexpr int MTH = MY + 2 * MH;
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
-  const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
-  const int i0 = blockIdx.x * MX, j0 = blockIdx.y * MY;
+  const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * g.rows * g.cols;
+  const int i0 = ((int)blockIdx.x + a.ti0) * MX, j0 = ((int)blockIdx.y + a.tj0) * MY;
   // The three scores of this thread's MY/MBY cells: issued together with the tile loads, so that they
   // are in flight during the staging and the two LDS passes (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
   constexpr int NC = MY / MBY;
@@ -862,7 +863,8 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
 }  // namespace
 
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream) {
+                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream,
+                            const Region* region, bool* region_done) {
   MaskArgs m;
   m.slope_disc = p.slope_disc;
   m.step_disc = p.step_disc;
@@ -878,20 +880,42 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.w_slope = combine ? combine->w_slope : 0.0f;
   m.w_step = combine ? combine->w_step : 0.0f;
   m.w_rough = combine ? combine->w_rough : 0.0f;
+  m.ti0 = m.tj0 = 0;
+  m.map = -1;
+  if (region_done) *region_done = false;
+  // A region run (te_run_chain_region with the footprint flag): isTraversableForFilters of a cell reads scores within
+  // 3 cells (circle(3 res), circle(2.5 res) and the 3x3 blocks around its cells), so the mask is recomputed on the
+  // region grown by MH; the footprint of a cell reads the mask and the traversability within the footprint's reach.
+  Region rm = {-1, 0, 0, g.rows, g.cols}, rf = rm;
+  if (region) {
+    auto grow = [&](const Region& r, int k) {
+      Region o = r;
+      o.i0 = r.i0 - k < 0 ? 0 : r.i0 - k;
+      o.j0 = r.j0 - k < 0 ? 0 : r.j0 - k;
+      o.i1 = r.i1 + k > g.rows ? g.rows : r.i1 + k;
+      o.j1 = r.j1 + k > g.cols ? g.cols : r.j1 + k;
+      return o;
+    };
+    rm = grow(*region, MH);
+    rf = grow(rm, p.reach);
+    m.map = region->map;
+  }
   {
-    const long tiles32 = (long)((g.rows + MX - 1) / MX) * ((g.cols + 31) / 32) * (g.batch > 0 ? g.batch : 1);
+    const long tiles32 = (long)((rm.i1 - rm.i0 + MX - 1) / MX) * ((rm.j1 - rm.j0 + 31) / 32) * (region ? 1 : (g.batch > 0 ? g.batch : 1));
     static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
     const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
-    if (small && tiles32 < 128 && small_env != 8)  // a very small map: one cell per thread
-      hipLaunchKernelGGL(k_fp_mask<4>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 3) / 4), (unsigned)g.batch),
-                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
-    else if (small)
-      hipLaunchKernelGGL(k_fp_mask<8>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 7) / 8), (unsigned)g.batch),
-                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+    const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : 32);  // a very small map: one cell per thread
+    m.ti0 = rm.i0 / MX;
+    m.tj0 = rm.j0 / my;
+    const dim3 grid((unsigned)((rm.i1 - 1) / MX - m.ti0 + 1), (unsigned)((rm.j1 - 1) / my - m.tj0 + 1), (unsigned)(region ? 1 : g.batch));
+    if (my == 4)
+      hipLaunchKernelGGL(k_fp_mask<4>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+    else if (my == 8)
+      hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else
-      hipLaunchKernelGGL(k_fp_mask<32>, dim3((unsigned)((g.rows + MX - 1) / MX), (unsigned)((g.cols + 31) / 32), (unsigned)g.batch),
-                         dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+      hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
   }
+  const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;
   const Disc& d = p.fp_disc;
   for (int k = 0; k <= kMaxRadiusCells; ++k) a.h[k] = (k <= d.R) ? d.hw[k] : -1;
@@ -909,8 +933,13 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.def = p.def;
   a.inner_q = fast::footprint_inner_q(g.res, p.rmin, p.rmax);
   // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
-  if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream)) return hipGetLastError();
-  if (fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream)) return hipGetLastError();
+  if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, rfp) ||
+      fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, rfp)) {
+    if (region_done) *region_done = true;
+    return hipGetLastError();
+  }
+  // (the kernel below always covers the whole map: a region run falls back to it, correct and slower)
+  if (region && g.batch > 1) return hipErrorNotSupported;  // it would also redo the other maps of the batch: not a region run
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
     const int Rk = p.reach;

@@ -37,6 +37,8 @@ struct F4Args {
   int rows, cols;
   long long map_cells;
   int nbx, strip_rows;
+  // the part of the map this launch covers: block columns [bx0, bx0 + nbx_l), output rows [j_lo, j_hi), map (< 0: blockIdx.z)
+  int bx0, nbx_l, j_lo, j_hi, map;
   int n_spiral;
   const int16_t* table;  // [n_spiral][4]: di, dj, ring (integer norm), tie flag (never set here: tie-free discs only)
   const int* gtab;       // clip table of the disc: {n, ...} per (ky, kx)
@@ -68,13 +70,13 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   typedef float __attribute__((address_space(1))) gfloat;
 
   const int lane = threadIdx.x;
-  const int bx = (int)blockIdx.x % a.nbx, strip = (int)blockIdx.x / a.nbx;
+  const int bx = a.bx0 + (int)blockIdx.x % a.nbx_l, strip = (int)blockIdx.x / a.nbx_l;
   int i0 = bx * kLanes;
   i0 = i0 + kLanes > a.rows ? a.rows - kLanes : i0;  // the last block ends at the map edge (rows >= 64)
-  const int js = strip * a.strip_rows;
-  if (js >= a.cols) return;
-  const int jend = js + a.strip_rows < a.cols ? js + a.strip_rows : a.cols;
-  const size_t mo = (size_t)blockIdx.z * (size_t)a.map_cells;
+  const int js = a.j_lo + strip * a.strip_rows;
+  if (js >= a.j_hi) return;
+  const int jend = js + a.strip_rows < a.j_hi ? js + a.strip_rows : a.j_hi;
+  const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
 
   unsigned vb[NC];
 #pragma unroll
@@ -359,18 +361,20 @@ void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   static const int per_cu_env = getenv("TE_F4_BLOCKS_PER_CU") ? atoi(getenv("TE_F4_BLOCKS_PER_CU")) : 0;  // measurement aid
   if (per_cu_env > 0) per_cu = per_cu_env;
   const int capacity = per_cu * device_cus();
-  const int per_row = a.nbx * (batch > 0 ? batch : 1);
+  const int nz = a.map >= 0 ? 1 : (batch > 0 ? batch : 1);
+  const int H = a.j_hi - a.j_lo;
+  const int per_row = a.nbx_l * nz;
   int strips = capacity / per_row;
   strips = strips < 1 ? 1 : strips;
-  int sr = (a.cols + strips - 1) / strips;
+  int sr = (H + strips - 1) / strips;
   // small maps cannot fill the wave slots: every resident block runs at once, so the launch takes one warm-up plus the
   // rows of one strip -- the shortest strips win (the spiral walks of a row are serial within its wavefront)
   static const int min_strip = getenv("TE_F4_MIN_STRIP") ? atoi(getenv("TE_F4_MIN_STRIP")) : 1;
   sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
   sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
-  const int nstrips = (a.cols + sr - 1) / sr;
-  hipLaunchKernelGGL((k_fp_slide4<Q>), dim3((unsigned)(a.nbx * nstrips), 1, (unsigned)batch), dim3(kLanes), 0, s, a);
+  const int nstrips = (H + sr - 1) / sr;
+  hipLaunchKernelGGL((k_fp_slide4<Q>), dim3((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz), dim3(kLanes), 0, s, a);
 }
 
 }  // namespace
@@ -431,7 +435,7 @@ bool f4_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 // taken.  tcap: upper bound of the finite values of the traversability layer, as the host can prove it (the layer was
 // written by the chain: w_scale * (w_slope + w_step + w_rough) with non-negative weights); < 0: unknown.
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      double tcap, hipStream_t s) {
+                      double tcap, hipStream_t s, const Region* region) {
   const Disc& d = p.fp_disc;
   static const bool off = getenv("TE_NO_F4") != nullptr;
   if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
@@ -454,6 +458,12 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.map_cells = (long long)g.rows * g.cols;
   a.nbx = (g.rows + kLanes - 1) / kLanes;
   a.strip_rows = 0;
+  a.bx0 = region ? region->i0 / kLanes : 0;
+  a.nbx_l = region ? (region->i1 - 1) / kLanes - a.bx0 + 1 : a.nbx;
+  a.j_lo = region ? region->j0 : 0;
+  a.j_hi = region ? region->j1 : g.cols;
+  a.map = region ? region->map : -1;
+  if (a.j_hi <= a.j_lo || a.nbx_l <= 0) return true;
   a.n_spiral = p.n_spiral;
   a.table = spiral_table;
   a.gtab = clip_table;

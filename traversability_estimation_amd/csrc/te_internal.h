@@ -169,8 +169,12 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
                         hipStream_t stream);
 // spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)
 // trav_cap: upper bound of the finite traversability values if the layer was written by the chain (see footprint_slide4), else < 0
+// region (nullptr: all maps, all cells): the cells whose scores changed; the mask is recomputed within 3 cells of them
+// and the footprint within the footprint's reach of those -- false is returned in *region_done if the kernels at hand
+// cannot restrict themselves to a region (the caller then runs the whole-map pass)
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
-                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream);
+                            const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream,
+                            const Region* region = nullptr, bool* region_done = nullptr);
 int chain_max_reach(const ChainParams& p);
 // te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map;
 // robot_slope: the layer checkInclination reads (nullptr: footprint/check_robot_inclination off)
@@ -197,12 +201,13 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
                    FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
 // te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)
+// region: the output cells to compute (whole block columns and the rows [j0, j1) of map `map`); nullptr: every map, every cell
 bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      hipStream_t s);
+                      hipStream_t s, const Region* region = nullptr);
 // te_footprint4.hip: the same on 32-bit fixed point, when the values of the traversability layer are bounded by tcap
 // (tcap < 0: no bound known)
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      double tcap, hipStream_t s);
+                      double tcap, hipStream_t s, const Region* region = nullptr);
 void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast
 

@@ -154,6 +154,17 @@ struct te_ctx {
   unsigned graph_flags[kGraphs] = {0, 0, 0, 0};
   int graph_next = 0;
   bool graph_ok = true;  // cleared after a failed capture: direct launches from then on
+  // streaming tiles (te_upload_tile_async / te_download_tile_async): copy streams, two device staging slots each way
+  struct TileSlot {
+    float* buf = nullptr;
+    size_t cap = 0;                              // in floats
+    hipEvent_t ready = nullptr, freed = nullptr;  // filled / consumed
+    bool used = false;
+  };
+  hipStream_t in_stream = nullptr, out_stream = nullptr;
+  TileSlot in_slot[2], out_slot[2];
+  int in_next = 0, out_next = 0;
+  bool tiles_pending = false;  // te_sync has copy streams to wait for
 };
 
 namespace {
@@ -598,6 +609,16 @@ int te_destroy(te_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (hipStream_t st : {c->in_stream, c->out_stream})
+      if (st) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+      }
+    for (te_ctx::TileSlot* sl : {&c->in_slot[0], &c->in_slot[1], &c->out_slot[0], &c->out_slot[1]}) {
+      if (sl->buf) (void)hipFree(sl->buf);
+      if (sl->ready) (void)hipEventDestroy(sl->ready);
+      if (sl->freed) (void)hipEventDestroy(sl->freed);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -717,6 +738,106 @@ int te_upload_tile(te_ctx* c, const float* host_tile, int map, int row0, int col
                            (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_elev = true;
+  return TE_OK;
+}
+
+namespace {
+
+int check_tile(te_ctx* c, const char* who, int map, int row0, int col0, int h, int w) {
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "%s: geometry not set", who);
+  if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows || col0 + w > c->geo.cols)
+    return fail(TE_ERR_INVALID_ARG, "%s: tile (%d,%d)+(%d,%d) outside %dx%d", who, row0, col0, h, w, c->geo.rows, c->geo.cols);
+  return TE_OK;
+}
+
+// a staging slot of at least n floats with its two events; growing one waits for whatever still uses it
+int prepare_slot(te_ctx* c, te_ctx::TileSlot& sl, size_t n) {
+  if (!sl.ready) HIP_TRY(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+  if (!sl.freed) HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+  if (sl.cap < n) {
+    if (sl.buf) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(sl.buf));
+      sl.buf = nullptr;
+      sl.cap = 0;
+      sl.used = false;
+    }
+    HIP_TRY(hipMalloc((void**)&sl.buf, n * sizeof(float)));
+    sl.cap = n;
+  }
+  return TE_OK;
+}
+
+int tile_streams(te_ctx* c) {
+  if (!c->in_stream) HIP_TRY(hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
+  if (!c->out_stream) HIP_TRY(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+  return TE_OK;
+}
+
+}  // namespace
+
+int te_download_tile(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
+  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (const int rc = check_tile(c, "te_download_tile", map, row0, col0, h, w)) return rc;
+  const float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile: bad layer %d", layer);
+  HIP_TRY(hipSetDevice(c->device));
+  const float* src = p + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
+  HIP_TRY(hipMemcpy2DAsync(host_tile, (size_t)h * sizeof(float), src, (size_t)c->geo.rows * sizeof(float), (size_t)h * sizeof(float),
+                           (size_t)w, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TE_OK;
+}
+
+int te_upload_tile_async(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
+  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile_async: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (const int rc = check_tile(c, "te_upload_tile_async", map, row0, col0, h, w)) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  if (const int rc = tile_streams(c)) return rc;
+  te_ctx::TileSlot& sl = c->in_slot[c->in_next];
+  c->in_next ^= 1;
+  if (const int rc = prepare_slot(c, sl, (size_t)h * w)) return rc;
+  // PCIe into the slot on the copy-in stream, once the compute stream has consumed what the slot held before
+  if (sl.used) HIP_TRY(hipStreamWaitEvent(c->in_stream, sl.freed, 0));
+  HIP_TRY(hipMemcpyAsync(sl.buf, host_tile, (size_t)h * w * sizeof(float), hipMemcpyHostToDevice, c->in_stream));
+  HIP_TRY(hipEventRecord(sl.ready, c->in_stream));
+  // into the layer on the compute stream: ordered after every launch already queued there (they may still read the cells)
+  HIP_TRY(hipStreamWaitEvent(c->stream, sl.ready, 0));
+  float* dst = c->L.elev + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->geo.rows * sizeof(float), sl.buf, (size_t)h * sizeof(float), (size_t)h * sizeof(float),
+                           (size_t)w, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipEventRecord(sl.freed, c->stream));
+  sl.used = true;
+  c->tiles_pending = true;
+  c->have_elev = true;
+  return TE_OK;
+}
+
+int te_download_tile_async(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
+  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (const int rc = check_tile(c, "te_download_tile_async", map, row0, col0, h, w)) return rc;
+  const float* p = layer_ptr(c, layer);
+  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: bad layer %d", layer);
+  HIP_TRY(hipSetDevice(c->device));
+  if (const int rc = tile_streams(c)) return rc;
+  te_ctx::TileSlot& sl = c->out_slot[c->out_next];
+  c->out_next ^= 1;
+  if (const int rc = prepare_slot(c, sl, (size_t)h * w)) return rc;
+  // the rectangle as the launches queued so far leave it, copied aside on the compute stream (the next tick may
+  // overwrite it), once the slot's previous content has crossed PCIe
+  if (sl.used) HIP_TRY(hipStreamWaitEvent(c->stream, sl.freed, 0));
+  const float* src = p + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
+  HIP_TRY(hipMemcpy2DAsync(sl.buf, (size_t)h * sizeof(float), src, (size_t)c->geo.rows * sizeof(float), (size_t)h * sizeof(float),
+                           (size_t)w, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipEventRecord(sl.ready, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->out_stream, sl.ready, 0));
+  HIP_TRY(hipMemcpyAsync(host_tile, sl.buf, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->out_stream));
+  HIP_TRY(hipEventRecord(sl.freed, c->out_stream));
+  sl.used = true;
+  c->tiles_pending = true;
   return TE_OK;
 }
 
@@ -988,12 +1109,30 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
       col0 + w > c->geo.cols)
     return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: rectangle outside the map");
   if (!c->chain_done) return fail(TE_ERR_NOT_READY, "te_run_chain_region: run the full chain once first");
-  // The footprint of a re-filtered rectangle is not computed by this call: a caller that asked for it must not get
-  // TE_OK and a stale traversability_footprint layer (te_run_footprint refreshes the whole layer).
-  if (flags & (TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO))
-    return fail(TE_ERR_UNSUPPORTED, "te_run_chain_region: TE_RUN_FOOTPRINT is a whole-map pass, call te_run_footprint after the region runs");
   const Region r = {map, row0, col0, row0 + h, col0 + w};
-  return run_chain_locked(c, flags, r);
+  const bool want_fp = (flags & (TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO)) != 0;
+  const bool fp_was_done = c->footprint_done;
+  if (want_fp && !fp_was_done)
+    return fail(TE_ERR_NOT_READY, "te_run_chain_region: the footprint flag refreshes a complete traversability_footprint layer; run the "
+                                  "whole-map footprint pass once first (te_run_chain with TE_RUN_FOOTPRINT, or te_run_footprint)");
+  int rc = run_chain_locked(c, flags & ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO), r);
+  if (rc || !want_fp) return rc;
+  // The scores changed within the chain's reach of the rectangle (launch_chain re-filters and re-combines exactly that);
+  // the footprint pass follows on the cells that can see them.
+  const int grow = chain_max_reach(c->cp);
+  Region changed = r;
+  changed.i0 = r.i0 - grow < 0 ? 0 : r.i0 - grow;
+  changed.j0 = r.j0 - grow < 0 ? 0 : r.j0 - grow;
+  changed.i1 = r.i1 + grow > c->geo.rows ? c->geo.rows : r.i1 + grow;
+  changed.j1 = r.j1 + grow > c->geo.cols ? c->geo.cols : r.j1 + grow;
+  const ChainParams& q = c->cp;
+  const bool bounded = !c->trav_external && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
+  const double trav_cap = bounded ? (double)q.w_scale * ((double)q.w_slope + (double)q.w_step + (double)q.w_rough) : -1.0;
+  bool region_done = false;
+  HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0, nullptr, trav_cap,
+                           c->stream, &changed, &region_done));
+  c->footprint_done = true;  // complete before, refreshed where it could change
+  return TE_OK;
 }
 
 int te_run_footprint(te_ctx* c) {
@@ -1374,6 +1513,14 @@ int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, i
   return TE_OK;
 }
 
+static int sync_tiles(te_ctx* c) {  // the copy streams of the streaming-tile calls
+  if (!c->tiles_pending) return TE_OK;
+  if (c->in_stream) HIP_TRY(hipStreamSynchronize(c->in_stream));
+  if (c->out_stream) HIP_TRY(hipStreamSynchronize(c->out_stream));
+  c->tiles_pending = false;
+  return TE_OK;
+}
+
 int te_sync(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -1386,13 +1533,13 @@ int te_sync(te_ctx* c) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const hipError_t e = hipStreamQuery(c->stream);
-      if (e == hipSuccess) return TE_OK;
+      if (e == hipSuccess) return sync_tiles(c);
       if (e != hipErrorNotReady) return fail(TE_ERR_HIP, "te_sync: %s", hipGetErrorString(e));
       if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
     }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return TE_OK;
+  return sync_tiles(c);
 }
 
 int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
