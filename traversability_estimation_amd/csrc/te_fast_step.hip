@@ -9,6 +9,8 @@
 // (CircleIterator clamps at the border).
 #include "te_march.h"
 
+#include <cstdlib>
+
 namespace te {
 namespace fast {
 
@@ -29,10 +31,13 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
   const int lane = threadIdx.x;
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  const int i0 = rg.i0 + blockIdx.x * kLanes;
+  // (the last block of a row of blocks is shifted left to end at the region's edge: no lane is ever masked; the columns
+  // it shares with its neighbour are written twice with the same bits)
+  const int i0 = rg.i0 + (int)blockIdx.x * kLanes + kLanes > rg.i1 ? rg.i1 - kLanes : rg.i0 + (int)blockIdx.x * kLanes;
   const int out_rows = T::out_rows(periods);
   const int js = rg.j0 + blockIdx.y * out_rows;
-  const int i = i0 + lane;
+  const int jstop = js + out_rows < rg.j1 ? js + out_rows : rg.j1;  // one past the last output row of this strip
+  typedef float __attribute__((address_space(1))) gfloat;
   float amax[P], amin[P], zc[P];
   static_for<P>([&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
@@ -51,6 +56,12 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
     loader.store(rowbuf, stage, lane, [](float t) { return __builtin_isfinite(t) ? t : qnan(); });
     __syncthreads();
     if (per + 1 < periods) loader.load(stage, elev + mo, g, rbase + P, i0 - R, lane);  // in flight during the period
+    // Row p of the period completes output row rbase + p - R.  Which of the P rows emit is one bit mask per period
+    // (uniform: a scalar bit test per emit instead of three compares), and the output address is a scalar row pointer
+    // that advances by two rows per pass + one of two constant lane offsets (first / second row of the pass).
+    const int p_lo = js - (rbase - R) > 0 ? js - (rbase - R) : 0, p_hi = jstop - (rbase - R) < P ? jstop - (rbase - R) : P;
+    const unsigned emask = p_hi > p_lo ? (p_hi >= 32 ? ~0u : (1u << p_hi) - 1u) & ~((1u << p_lo) - 1u) : 0u;
+    gfloat* op = (gfloat*)(sh + mo + ((long long)(rbase - R) * g.rows + i0));  // output row of period row 0 (may lie above the strip: never stored)
     // Two rows per pass: every pending output takes the run values of both rows with ONE v_max3/v_min3.
     // Row p is at offset e1 (slot = (p+e1) mod P) and row p+1 at e1-1 of the same output; the output that
     // completes with row p (e1 == -R) is emitted in between and its slot restarts with row p+1 (offset +R).
@@ -66,14 +77,13 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
     };
     auto emit = [&](int p, float vmx, float vmn) __attribute__((always_inline)) {  // the output row completed by row p of this period
       const int so = (p + R + 1) % P;
-      const int j = rbase + p - R;
-      if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
+      if ((emask >> p) & 1u) {
         const float z0 = zc[so];
         // StepFilter.cpp:113 only valid centres; :143 double difference stored as float
         // (float)((double)vmx - (double)vmn) == vmx - vmn in float32: the double difference of two floats rounded to
         // float is the correctly rounded float difference (53 >= 2 * 24 + 2 bits: double rounding is innocuous)
         const float out = (z0 == z0) ? __fsub_rn(vmx, vmn) : qnan();
-        sh[mo + (size_t)j * g.rows + i] = out;
+        op[(p & 1) ? g.rows + lane : lane] = out;
       }
     };
     static_for<(P + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
@@ -116,6 +126,7 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
         emit(p, amax[so], amin[so]);
         amax[so] = amin[so] = qnan();
       }
+      op += 2 * (long long)g.rows;
     });
   }
 }
@@ -133,10 +144,11 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
   const int lane = threadIdx.x;
   const int map = rg.map >= 0 ? rg.map : blockIdx.z;
   const size_t mo = (size_t)map * g.rows * g.cols;
-  const int i0 = rg.i0 + blockIdx.x * kLanes;
+  const int i0 = rg.i0 + (int)blockIdx.x * kLanes + kLanes > rg.i1 ? rg.i1 - kLanes : rg.i0 + (int)blockIdx.x * kLanes;  // see k_step_height_fast
   const int out_rows = T::out_rows(periods);
   const int js = rg.j0 + blockIdx.y * out_rows;
-  const int i = i0 + lane;
+  const int jstop = js + out_rows < rg.j1 ? js + out_rows : rg.j1;
+  typedef float __attribute__((address_space(1))) gfloat;
   // nCells / nCellCritical_ for every possible count, divided once per block (exactly the reference's
   // double division); first read after the barriers of the first period
   __shared__ double ratio[S::npoints() + 1];
@@ -163,6 +175,10 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
     loader.store(rowbuf, stage, lane, [&](float v) { return make_float2(v, __int_as_float(v > crit_lo ? 1 : 0)); });
     __syncthreads();
     if (per + 1 < periods) loader.load(stage, shl + mo, g, rbase + P, i0 - R, lane);
+    // emit mask and running output pointer of the period: see k_step_height_fast
+    const int p_lo = js - (rbase - R) > 0 ? js - (rbase - R) : 0, p_hi = jstop - (rbase - R) < P ? jstop - (rbase - R) : P;
+    const unsigned emask = p_hi > p_lo ? (p_hi >= 32 ? ~0u : (1u << p_hi) - 1u) & ~((1u << p_lo) - 1u) : 0u;
+    gfloat* op = (gfloat*)(out + mo + ((long long)(rbase - R) * g.rows + i0));
     // One row = 2R+1 staged cells {value, flag}; the reads of the NEXT row are issued before the current row is
     // reduced (two row buffers alternate), so the LDS latency is covered by the reduction and the scatter.
     auto read_row = [&](int p, float2 (&raw)[2 * R + 1]) __attribute__((always_inline)) {
@@ -182,8 +198,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
       });
     };
     auto emit = [&](int p, float m, int count) __attribute__((always_inline)) {
-      const int j = rbase + p - R;
-      if (j >= js && j < js + out_rows && j < rg.j1 && i < rg.i1) {
+      if ((emask >> p) & 1u) {
         // isValid: at least one valid step_height in the window (StepFilter.cpp:161), else the cell stays NaN.
         // nCells == 0: step = min(stepMax, 0 * stepMax) = 0 (:169-170) -> 1 - 0 / crit = 1 (0 if crit == 0: "0 < 0" fails);
         // nCells >= nCellCritical: the ratio is >= 1, so step = stepMax, and a counted cell means stepMax > crit -> 0.
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
           o = step < crit ? (float)(1.0 - q) : 0.0f;
         }
         o = (m == m) ? o : qnan();
-        out[mo + (size_t)j * g.rows + i] = o;
+        op[(p & 1) ? g.rows + lane : lane] = o;
       }
     };
     float2 rawa[2 * R + 1], rawb[2 * R + 1];
@@ -249,12 +264,16 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
         vm[so] = qnan();
         cnt[so] = 0;
       }
+      op += 2 * (long long)g.rows;
     });
   }
 }
 
 // resident wave slots of the device for a kernel compiled for `waves` waves per SIMD
-long wave_slots(int waves) { return 4L * device_cus() * waves; }
+long wave_slots(int waves) {
+  static const int ov = getenv("TE_STEP_WAVES") ? atoi(getenv("TE_STEP_WAVES")) : 0;  // measurement aid: strips sized for this many waves per SIMD
+  return 4L * device_cus() * (ov > 0 ? ov : waves);
+}
 
 template <int Q>
 void launch_height(const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
@@ -278,6 +297,7 @@ void launch_score(const Geo& g, double crit, float crit_lo, int ncrit, const flo
 }  // namespace
 
 bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
+  if (r.i1 - r.i0 < kLanes) return false;  // the blocks are 64 cells wide and never mask a lane (the last one is shifted)
   switch (Q) {
 #define X(q) \
   case q:    \
@@ -292,6 +312,7 @@ bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const R
 
 bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
                      hipStream_t s) {
+  if (r.i1 - r.i0 < kLanes) return false;
   // largest float <= crit
   float lo = (float)crit;
   if ((double)lo > crit) lo = nextafterf(lo, -INFINITY);

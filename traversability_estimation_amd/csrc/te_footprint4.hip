@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   cgfloat* ldt = (cgfloat*)(a.trav + mo + ((long long)(js - R) * a.rows + i0));
   cgbyte* ldu = (cgbyte*)(a.untrav + mo + ((long long)(js - R) * a.rows + i0));
   auto load_row = [&](int r, float& pm, float& ph, unsigned& um, unsigned& uh) __attribute__((always_inline)) {
-    if (r >= 0 && r < a.cols) {
+    if ((unsigned)r < (unsigned)a.cols) {  // 0 <= r < cols in one compare
       pm = ldt[lane];
       ph = ldt[lhalo];
       um = ldu[lane];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
     ldu += a.rows;
   };
   auto stage_row = [&](int r, unsigned vbase, int ro, float pm, float ph, unsigned um, unsigned uh) __attribute__((always_inline)) {
-    const bool rin = r >= 0 && r < a.cols;
+    const bool rin = (unsigned)r < (unsigned)a.cols;
     const float tm = __builtin_isfinite(pm) ? pm : a.def;  // :719-724
     const float th = __builtin_isfinite(ph) ? ph : a.def;
     // round(T' * 2^k): the product is exact, + 0.5 is exact below 2^23, the conversion truncates (and clamps at 0)
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   auto tail = [&](int j, int u) __attribute__((always_inline)) {
     int nt = nt_mid;
     float rn = rnt;
-    const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
-    if (__builtin_expect(ky != 0, 0)) {
+    if (__builtin_expect((unsigned)(j - R) >= (unsigned)(a.cols - 2 * R), 0)) {  // a row of the top / bottom frame (uniform)
+      const int ky = j < R ? R - j : -(R - (a.cols - 1 - j));
       nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
       rn = (float)(a.inv_scale / (double)nt);
     }
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
 
   auto slide = [&](auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
-    unsigned lead = 0, trail = 0;  // packed sums of the 2R+1 cells of the leading / trailing edge (no field overflows)
+    // all ring reads of the step first, then ONE wait for all of them, then the sums (the compiler's own placement waits
+    // before every add3 for its two operands: 13 s_waitcnt per step -- with four waves per SIMD it is the instruction
+    // count that matters, the latency is covered by the other waves)
+    unsigned zl[2 * R + 1], zt[2 * R + 1];
     static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
       constexpr int d = decltype(dc)::value;
       constexpr int h = Shape<Q>::hw(d);
@@ -306,16 +309,23 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
       const char* rl = ringb + vb[al];
       const char* rt = ringb + vb[at];
-      const unsigned zl = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R + d) * 4));
-      const unsigned zt = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R + d) * 4));
+      zl[R + d] = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R + d) * 4));
+      zt[R + d] = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R + d) * 4));
+      if (d != 0) {
+        zl[R - d] = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R - d) * 4));
+        zt[R - d] = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R - d) * 4));
+      }
+    });
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the compiler would otherwise wait before every add3, for its two operands
+    unsigned lead = 0, trail = 0;  // packed sums of the 2R+1 cells of the leading / trailing edge (no field overflows)
+    static_for<R + 1>([&](auto dcr) __attribute__((always_inline)) {
+      constexpr int d = R - decltype(dcr)::value;
       if (d == 0) {
-        lead += zl;
-        trail += zt;
+        lead += zl[R];
+        trail += zt[R];
       } else {
-        const unsigned zl2 = *reinterpret_cast<const unsigned*>(rl + (ol * RB + (R - d) * 4));
-        const unsigned zt2 = *reinterpret_cast<const unsigned*>(rt + (ot * RB + (R - d) * 4));
-        lead += zl + zl2;
-        trail += zt + zt2;
+        lead += zl[R + d] + zl[R - d];
+        trail += zt[R + d] + zt[R - d];
       }
     });
     X += lead - trail;

@@ -1119,7 +1119,12 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
   if (rc || !want_fp) return rc;
   // The scores changed within the chain's reach of the rectangle (launch_chain re-filters and re-combines exactly that);
   // the footprint pass follows on the cells that can see them.
-  const int grow = chain_max_reach(c->cp);
+  // (checkForStep also follows a ray of up to max_gap_width and a Bresenham line along it through the ELEVATION, which
+  // changed in the rectangle itself: the mask of a cell depends on elevations up to 2.5 + 1 + max_gap/res cells away; the
+  // mask is recomputed within 3 cells of `changed`)
+  const int gap_cells = (int)ceil(c->params.fp_max_gap / c->geo.res) + 5;
+  const int reach = chain_max_reach(c->cp);
+  const int grow = reach > gap_cells - 3 ? reach : gap_cells - 3;
   Region changed = r;
   changed.i0 = r.i0 - grow < 0 ? 0 : r.i0 - grow;
   changed.j0 = r.j0 - grow < 0 ? 0 : r.j0 - grow;
