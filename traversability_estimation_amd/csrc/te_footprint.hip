@@ -910,20 +910,51 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     rf = grow(rm, p.reach);
     m.map = region->map;
   }
-  {
-    const long tiles32 = (long)((rm.i1 - rm.i0 + MX - 1) / MX) * ((rm.j1 - rm.j0 + 31) / 32) * (region ? 1 : (g.batch > 0 ? g.batch : 1));
-    static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
-    const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
-    const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : 32);  // a very small map: one cell per thread
+  const long tiles32 = (long)((rm.i1 - rm.i0 + MX - 1) / MX) * ((rm.j1 - rm.j0 + 31) / 32) * (region ? 1 : (g.batch > 0 ? g.batch : 1));
+  static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
+  const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
+  const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : 32);  // a very small map: one cell per thread
+  // the mask kernel on the tile rows [t0, t1) (tiles of my cells) of the region
+  auto launch_mask = [&](int t0, int t1, hipStream_t st) {
+    if (t1 <= t0) return;
     m.ti0 = rm.i0 / MX;
-    m.tj0 = rm.j0 / my;
-    const dim3 grid((unsigned)((rm.i1 - 1) / MX - m.ti0 + 1), (unsigned)((rm.j1 - 1) / my - m.tj0 + 1), (unsigned)(region ? 1 : g.batch));
+    m.tj0 = t0;
+    const dim3 grid((unsigned)((rm.i1 - 1) / MX - m.ti0 + 1), (unsigned)(t1 - t0), (unsigned)(region ? 1 : g.batch));
     if (my == 4)
-      hipLaunchKernelGGL(k_fp_mask<4>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+      hipLaunchKernelGGL(k_fp_mask<4>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else if (my == 8)
-      hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+      hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else
-      hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, stream, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+      hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+  };
+  const int t_lo = rm.j0 / my, t_hi = (rm.j1 - 1) / my + 1;
+  // Whole large maps: the two kernels of the pass overlap, half a map apart.  The mask kernel is the one kernel of the
+  // chain that is near the memory bandwidth, the sliding sum is bound by its LDS reads and instruction issue: the
+  // upper half's sliding sum runs beside the lower half's mask kernel on the second stream.
+  static const int bands_env = getenv("TE_FP_BANDS") ? atoi(getenv("TE_FP_BANDS")) : 2;
+  if (!region && bands_env >= 2 && my == 32 && L.aux_stream && L.ev_fp_fork && L.ev_fp_join && g.cols >= 1024) {
+    const int j_mid = ((g.cols / 2 + 31) / 32) * 32;
+    int t_mid = (j_mid + p.reach + my - 1) / my;  // the upper half's discs read the mask down to row j_mid + reach - 1
+    t_mid = t_mid < t_hi ? t_mid : t_hi;
+    const Region top = {-1, 0, 0, g.rows, j_mid}, bot = {-1, 0, j_mid, g.rows, g.cols};
+    launch_mask(t_lo, t_mid, stream);
+    (void)hipEventRecord(L.ev_fp_fork, stream);
+    (void)hipStreamWaitEvent(L.aux_stream, L.ev_fp_fork, 0);
+    const bool f4 = fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, L.aux_stream, &top);
+    const bool f3 = !f4 && fast::footprint_slide3(g, p, L, spiral_table, clip_table, L.aux_stream, &top);
+    (void)hipEventRecord(L.ev_fp_join, L.aux_stream);
+    launch_mask(t_mid, t_hi, stream);
+    if (f4 || f3) {
+      if (f4)
+        (void)fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, &bot);
+      else
+        (void)fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, &bot);
+      (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);
+      return hipGetLastError();
+    }
+    (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);  // neither kernel takes the shape: the whole-map kernel below, after the mask
+  } else {
+    launch_mask(t_lo, t_hi, stream);
   }
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;

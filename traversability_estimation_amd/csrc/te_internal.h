@@ -84,6 +84,7 @@ struct Layers {
   // second stream + fork/join events: step filter || normals kernel on whole-map runs (nullptr: sequential)
   hipStream_t aux_stream;
   hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fp_fork, ev_fp_join;  // mask kernel of the lower half || sliding-sum kernel of the upper half (launch_footprint)
 };
 
 // polygon footprints (te_polygon.hip)

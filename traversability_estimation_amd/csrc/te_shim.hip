@@ -119,7 +119,7 @@ struct te_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fp_fork = nullptr, ev_fp_join = nullptr;
   te_params params;
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
   float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
@@ -400,6 +400,8 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   if (c->combine_deferred) flags |= kDeferCombine;
   c->L.ev_fork = c->ev_fork;
   c->L.ev_join = c->ev_join;
+  c->L.ev_fp_fork = c->ev_fp_fork;
+  c->L.ev_fp_join = c->ev_fp_join;
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   c->footprint_done = false;  // the layers the footprint pass reads have changed
@@ -585,6 +587,8 @@ int te_create(int device, te_ctx** out) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fp_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fp_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
     return fail(TE_ERR_HIP, "te_create: %s", hipGetErrorString(e));
@@ -608,6 +612,8 @@ int te_destroy(te_ctx* c) {
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fp_fork) (void)hipEventDestroy(c->ev_fp_fork);
+    if (c->ev_fp_join) (void)hipEventDestroy(c->ev_fp_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (hipStream_t st : {c->in_stream, c->out_stream})
       if (st) {

@@ -427,7 +427,9 @@ static void test_traversability_map() {
       teo_check_polygon_paths(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), 1, off, poses.data(), 4, foot3,
                               &paths[k].conservative, &safe, &trav, &area, &status);
     }
-    if (results[k].is_safe != safe || results[k].traversability != trav || results[k].area != area) {
+    // (the traversability of a circular path is a mean of footprint values, which the fixed-point footprint kernel
+    // delivers within 1e-6 of the double sum, not bit for bit; the decision and the area are exact)
+    if (results[k].is_safe != safe || std::fabs(results[k].traversability - trav) > 1e-5 || results[k].area != area) {
       ++n_bad;
       std::fprintf(stderr, "path %zu: got (%d, %.17g, %.17g) want (%d, %.17g, %.17g)\n", k, results[k].is_safe,
                    results[k].traversability, results[k].area, safe, trav, area);
@@ -481,7 +483,7 @@ static void test_traversability_map() {
         teo_check_polygon_paths_incl(&g, &p, elev, sl.data(), st.data(), ro.data(), tr.data(), rs.data(), 1, off, poses.data(),
                                      4, foot3, &paths[k].conservative, &safe, &trav, &area, &status);
       }
-      if (results[k].is_safe != safe || results[k].traversability != trav || results[k].area != area) ++n_bad_incl;
+      if (results[k].is_safe != safe || std::fabs(results[k].traversability - trav) > 1e-5 || results[k].area != area) ++n_bad_incl;
       n_safe_incl += safe;
     }
     std::printf("  checkFootprintPaths with check_robot_inclination: %d safe (of %d without), %d mismatches\n", n_safe_incl,
