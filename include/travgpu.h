@@ -173,6 +173,12 @@ int te_upload_tile(te_ctx* ctx, const float* host_tile, int map, int row0, int c
 /* Device pointer of a layer ([batch][cols][rows] float32) for zero-copy producers/consumers
  * (e.g. a torch tensor filled on the same device); valid until te_set_geometry/te_destroy. */
 int te_device_ptr(te_ctx* ctx, int layer, void** dptr, size_t* bytes);
+/* The optional input layer robot_slope (checkInclination, TraversabilityMap.cpp:748-762; it travels with the elevation
+ * map when the caller has one) is present after an upload.  present = 0 declares it absent again -- an elevation map that
+ * comes without the layer must not be checked against the previous map's -- and present = 1 declares a buffer filled
+ * through te_device_ptr ready.  With check_robot_inclination set the path checks fail (TE_ERR_NOT_READY) while the
+ * layer is absent, like the reference's atPosition() throws for a missing layer. */
+int te_set_layer_present(te_ctx* ctx, int layer, int present);
 
 /* Host -> device copy of any layer (e.g. surface_normal_z for TE_FILTER_SLOPE); elevation marks the context ready. */
 int te_upload_layer(te_ctx* ctx, int layer, const float* host, int map0, int nmaps);

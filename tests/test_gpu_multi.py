@@ -112,3 +112,31 @@ def test_two_gloo_ranks_drive_their_shards_through_libtravgpu(capi, tmp_path):
         want = one.download("traversability").reshape(n_maps, rows * cols)
     n_bad, mx, _ = compare_layer("traversability", full, want, tol=2e-6)
     assert n_bad == 0, (n_bad, mx)
+
+
+def test_bcast_params_across_devices_over_rccl(capi):
+    """te_bcast_params with contexts on different devices takes the RCCL branch (ncclCommInitAll + grouped ncclBroadcast
+    on streams of the call's own).  Needs >= 2 GPUs: on the one-GPU boxes of the test pool this is skipped, on a
+    multi-GPU node it is the first thing to run there."""
+    n_dev = capi.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU: the RCCL branch of te_bcast_params needs two devices")
+    n_dev = min(n_dev, 8)
+    ctxs = [capi.Context(d) for d in range(n_dev)] + [capi.Context(0)]  # the last one shares the root's device (host copy)
+    try:
+        p = capi.default_params(slope_critical=0.7, step_ncrit=7, fp_radius=0.21, w_slope=0.5)
+        ctxs[0].set_params(p)
+        capi.bcast_params(ctxs, root=0)
+        want = bytes(memoryview(ctxs[0].get_params()))
+        for c in ctxs[1:]:
+            assert bytes(memoryview(c.get_params())) == want
+        # and from a root that is not context 0
+        p2 = capi.default_params(rough_critical=0.09)
+        ctxs[n_dev - 1].set_params(p2)
+        capi.bcast_params(ctxs, root=n_dev - 1)
+        want = bytes(memoryview(ctxs[n_dev - 1].get_params()))
+        for c in ctxs:
+            assert bytes(memoryview(c.get_params())) == want
+    finally:
+        for c in ctxs:
+            c.close()

@@ -140,6 +140,19 @@ def test_gpu_inclination_against_oracle(oracle):
         buf = np.roll(np.roll(rs.reshape(cols, rows), sj, axis=0), si, axis=1)
         ctx.upload_layer_circular("robot_slope", buf, (si, sj))
         assert np.array_equal(ctx.download("robot_slope").view(np.uint32), rs.view(np.uint32))
+        # te_set_layer_present: a map that comes without the layer declares it absent again; asking for the device
+        # pointer alone does not make it present
+        ctx.set_layer_present("robot_slope", False)
+        with pytest.raises(capi.TeError, match="robot_slope"):
+            ctx.check_inclination(seg[:4])
+        ctx.device_ptr("robot_slope")
+        with pytest.raises(capi.TeError, match="robot_slope"):
+            ctx.check_inclination(seg[:4])
+        ctx.set_layer_present("robot_slope", True)
+        ok2, _ = ctx.check_inclination(seg)
+        assert np.array_equal(ok2, ok)
+        with pytest.raises(capi.TeError):
+            ctx.set_layer_present("elevation", False)
     want_ok, want_st = oracle.check_inclination(g, rs, seg)
     assert np.array_equal(ok, want_ok) and np.array_equal(st_seg, want_st)
     assert 2000 < ok.sum() < len(seg) - 2000

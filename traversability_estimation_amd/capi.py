@@ -31,7 +31,7 @@ RUN_NORMALS_ONLY = 0x20
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
            "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile", "te_download_tile",
            "te_upload_tile_async", "te_download_tile_async",
-           "te_device_ptr", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
+           "te_device_ptr", "te_set_layer_present", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
            "te_download_layer", "te_time_chain", "te_time_chain_samples", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
@@ -132,6 +132,7 @@ def load():
         L.te_upload_tile_async.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.te_download_tile_async.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.te_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.te_set_layer_present.argtypes = [vp, C.c_int, C.c_int]
         L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_upload_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         L.te_download_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
@@ -381,6 +382,9 @@ class Context:
         _check(load().te_device_ptr(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), C.byref(p),
                                     C.byref(n)))
         return p.value, n.value
+
+    def set_layer_present(self, layer, present):
+        _check(load().te_set_layer_present(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer), 1 if present else 0))
 
     def upload_layer(self, layer, data, map0=0):
         a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)

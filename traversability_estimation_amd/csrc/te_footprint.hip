@@ -931,7 +931,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // Whole large maps: the two kernels of the pass overlap, half a map apart.  The mask kernel is the one kernel of the
   // chain that is near the memory bandwidth, the sliding sum is bound by its LDS reads and instruction issue: the
   // upper half's sliding sum runs beside the lower half's mask kernel on the second stream.
-  static const int bands_env = getenv("TE_FP_BANDS") ? atoi(getenv("TE_FP_BANDS")) : 2;
+  // MEASURED (MI355X, 4096^2, same box): 0.418 ms per chain launch with the two bands against 0.385 ms without -- the
+  // two kernels slow each other down by more than they overlap, and the half-length strips of the sliding sum pay
+  // their start-up twice.  Off unless TE_FP_BANDS=2 asks for it.
+  static const int bands_env = getenv("TE_FP_BANDS") ? atoi(getenv("TE_FP_BANDS")) : 1;
   if (!region && bands_env >= 2 && my == 32 && L.aux_stream && L.ev_fp_fork && L.ev_fp_join && g.cols >= 1024) {
     const int j_mid = ((g.cols / 2 + 31) / 32) * 32;
     int t_mid = (j_mid + p.reach + my - 1) / my;  // the upper half's discs read the mask down to row j_mid + reach - 1

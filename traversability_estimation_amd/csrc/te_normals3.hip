@@ -69,6 +69,7 @@ struct N3Args {
   const int* gtab;     // [(2R+1)^2][6] x/y moments {n, si, sj, sii, sij, sjj} of the disc clipped by the map border
   double res;
   double Nd, K1h, Kr2, kinv;  // N; N*res^2*sum(di^2)/2; (N*res)^2; 1/(N(N-1))
+  int Ni, SIIi;               // N and sum(di^2) = sum(dj^2) of the full disc as integers (discs with invalid cells)
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
   int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
@@ -86,12 +87,15 @@ typedef float __attribute__((address_space(1))) gfloat;
 // One block: columns [i0, i0 + 64), output rows [js, jend).  GENERAL: every row takes the x/y moments of its (possibly
 // clipped) disc from the table and the general tail -- the blocks of the first / last block column and of the top / bottom
 // frame rows; otherwise every disc of the block lies inside the map and the closed-form tail is used.
-// HOLES: the march can also handle discs with invalid cells (below).  Without it the march gives up at the first invalid
+// HOLES: the march can also handle discs with invalid cells: every ring row carries a bit mask of its invalid cells (hm),
+// a disc that holds such a row subtracts the x/y moments of the invalid cells it contains from those of the full (or
+// clipped) disc and takes the general tail.  Without it the march gives up at the first invalid
 // cell it stages and returns false; the kernel then runs the strip again with HOLES.  A clean strip -- the common case by
 // far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
 // clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
 template <int Q, bool KEEP, bool GENERAL, bool HOLES>
-__device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int i0, const int own_lo, const int js, const int jend) {
+__device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
+                                       const int jend) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
   constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R: exactly what one slide reads
@@ -120,9 +124,8 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
   const double zref = (double)zref32;
 
   // ---- ring ----------------------------------------------------------------------------------------------------------
-  // An invalid cell -- and a cell that is not there: outside the map -- is held as the smallest denormal (stage_row): it
-  // adds nothing to the z-sums (absorbed by rounding, and 0 when squared) and can be told from every valid dz, which is
-  // a difference of two float32 values (a multiple of 2^-149, or exactly 0).
+  // An invalid cell -- and a cell that is not there: outside the map -- is held as +0.0: it adds nothing to the z-sums.
+  // Which cells of a ring row are invalid is kept beside the ring (hm, HOLES march only).
   // chunk base registers: byte address of the chunk + the lane's own column
   unsigned vb[NC];
 #pragma unroll
@@ -165,15 +168,27 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
     const bool okm = __builtin_isfinite(pm) && rin, okh = __builtin_isfinite(ph) && halo_in && rin;
     const float tm = okm ? pm : zref32, th = okh ? ph : zref32;
     typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
-    u32x2 bm = __builtin_bit_cast(u32x2, (double)tm - zref);  // +0.0 where absent ...
-    u32x2 bh = __builtin_bit_cast(u32x2, (double)th - zref);
-    if (HOLES) {
-      bm.x = okm ? bm.x : 1u;                                  // ... turned into the marker (one select on the low word)
-      bh.x = okh ? bh.x : 1u;
-    }
+    const u32x2 bm = __builtin_bit_cast(u32x2, (double)tm - zref);  // +0.0 where absent
+    const u32x2 bh = __builtin_bit_cast(u32x2, (double)th - zref);
     *reinterpret_cast<u32x2*>(ringb + vbase + (ro * RB + R * 8)) = bm;
     *reinterpret_cast<u32x2*>(ringb + (vbase + vhd) + ro * RB) = bh;
-    row_dirty = rin && __any(!__builtin_isfinite(pm) || (!__builtin_isfinite(ph) && halo_in));
+    if (HOLES) {
+      // invalid cells of the map in this row, as bits over the window columns: lane k holds column R + k (main) and
+      // column hcol (halo; lanes >= 2R repeat lane 2R - 1 and are ignored)
+      const unsigned long long mm = __ballot(!__builtin_isfinite(pm) && rin);
+      const unsigned long long mh = __ballot(!__builtin_isfinite(ph) && halo_in && rin) & ((1ull << (2 * R)) - 1ull);
+      constexpr unsigned long long RM = (1ull << R) - 1ull;
+      const unsigned long long lo = (mh & RM) | (mm << R);                 // columns 0 .. 63
+      const unsigned long long hi = (mm >> (64 - R)) | ((mh >> R) << R);   // columns 64 .. W-1
+      const int slot = (int)(__builtin_amdgcn_readfirstlane(vbase) / (unsigned)RB) + ro;  // (lane 0: chunk base)
+      if (lane == 0) {
+        hm[slot][0] = lo;
+        hm[slot][1] = hi;
+      }
+      row_dirty = (mm | mh) != 0ull;
+    } else {
+      row_dirty = rin && __any(!__builtin_isfinite(pm) || (!__builtin_isfinite(ph) && halo_in));
+    }
   };
   // The march starts with the disc of its first row summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1
   // (the layout step j = js, u = 0 expects), C rows in flight at a time, then every lane adds up the four moments of its
@@ -326,43 +341,50 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
       flag_tiles(j);
     }
   };
-  // ---- rows whose disc holds invalid cells: x/y moments of the VALID cells, slid like the z-moments -------------------
-  // They are kept only while a dirty row is in the ring ("holes" mode).  On entry they are counted once from the ring
-  // itself (absent cells carry the marker, whatever the reason: invalid, outside the map, above the strip), so no case
-  // analysis of borders and warm-up is needed; a disc without a dirty row never looks at them.
-  int Mn = 0, Mi = 0, Mj = 0, Mii = 0, Mij = 0, Mjj = 0;
-  bool holes = false;
-  auto absent = [&](double v) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned long long, v) == 1ull; };
-  auto count_moments = [&](int u) __attribute__((always_inline)) {
-    // disc of row j: ring rows u .. u+2R counted from the row vb[0] points to
-    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / RB) + u;
-    int n = 0, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
-#pragma unroll 1
-    for (int dj = -R; dj <= R; ++dj) {
-      const int hw = isqrt_c(Q - dj * dj);
-      int sl = slot0 + R + dj;
-      sl = sl >= NR ? sl - NR : sl;
-      sl = sl >= NR ? sl - NR : sl;
-      const double* row = ring + sl * W + lane + R;
-#pragma unroll 1
-      for (int di = -hw; di <= hw; ++di) {
-        const int w = absent(row[di]) ? 0 : 1;
-        n += w;
-        si += w * di;
-        sii += w * di * di;
-        sj += w * dj;
-        sij += w * di * dj;
-        sjj += w * dj * dj;
-      }
-    }
-    Mn = n; Mi = si; Mj = sj; Mii = sii; Mij = sij; Mjj = sjj;
-  };
+  // ---- rows whose disc holds invalid cells ------------------------------------------------------------------------------
+  // x/y moments of the VALID cells = those of the full (GENERAL: clipped) disc minus those of the invalid cells in it.
+  // The invalid cells come from the bit masks of the dirty ring rows of the disc (uniform loop over those rows, one
+  // broadcast LDS read each; a lane shifts its run of the row out of the mask and walks the set bits -- with sparse
+  // holes there is one, rarely two).  The z-moments are already right: an invalid cell is +0.0 in the ring.
   auto tail_holes = [&](int j, auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
-    constexpr int pc = u + R;  // ring position of row j
-    const double ctr = *reinterpret_cast<const double*>(ringb + vb[(pc / C) % NC] + ((pc % C) * RB + R * 8));
+    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
+    int hn = 0, hi_ = 0, hj = 0, hii = 0, hij = 0, hjj = 0;
+    bool nocentre = false;
+    unsigned bits = dmask & kDiscMask;  // bit k: map row j - R + k is dirty (uniform)
+    while (bits) {
+      const int k = __builtin_ctz(bits);
+      bits &= bits - 1u;
+      int sl = slot0 + k;
+      sl = sl >= NR ? sl - NR : sl;
+      sl = sl >= NR ? sl - NR : sl;
+      const unsigned long long lo = hm[sl][0], hi = hm[sl][1];
+      const int dj = k - R, adj = dj < 0 ? -dj : dj;
+      const int w = (int)__builtin_sqrtf((float)(Q - adj * adj));  // half-width of the disc's run in this row (exact: small integers)
+      const int sh = lane + R - w;                                  // window column of the run's first cell, 0 .. 63 + R
+      const unsigned long long x = sh < 64 ? ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) : (hi >> (sh - 64));
+      unsigned b = (unsigned)x & ((2u << (2 * w)) - 1u);            // bit t: cell di = t - w of the run is invalid
+      if (dj == 0) nocentre = ((b >> w) & 1u) != 0;
+      while (b) {
+        const int di = __builtin_ctz(b) - w;
+        b &= b - 1u;
+        hn += 1;
+        hi_ += di;
+        hj += dj;
+        hii += di * di;
+        hij += di * dj;
+        hjj += dj * dj;
+      }
+    }
+    int n0 = a.Ni, si0 = 0, sj0 = 0, sii0 = a.SIIi, sij0 = 0, sjj0 = a.SIIi;
+    if (GENERAL) {
+      const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+      const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+      n0 = gt[0]; si0 = gt[1]; sj0 = gt[2]; sii0 = gt[3]; sij0 = gt[4]; sjj0 = gt[5];
+    }
+    const int Mn = n0 - hn;
     double qs = 0.0;
-    const int unresolved = general_tail3(a.res, Mn, Mi, Mj, Mii, Mij, Mjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+    const int unresolved = general_tail3(a.res, Mn, si0 - hi_, sj0 - hj, sii0 - hii, sij0 - hij, sjj0 - hjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
     const float sl = acosf_poly01(fz);
     o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
     float rq = (float)(qs * rcp_fast((double)Mn * (double)(Mn - 1)));
@@ -370,8 +392,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
     const float rgh = __builtin_amdgcn_sqrtf(rq);
     o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
     const float qn = __builtin_nanf("");
-    const bool nocentre = absent(ctr);  // no normal, slope or roughness where the input layer is invalid
-    const bool bad = unresolved != 0 && !nocentre;
+    const bool bad = unresolved != 0 && !nocentre;  // (no normal, slope or roughness where the input layer is invalid)
     if (nocentre || bad) {
       o_slope = qn;
       o_rough = qn;
@@ -466,78 +487,6 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
     Sjz = fma(-0.5, Sz0 + Sz, acc);
   };
 
-  // the slide of a step in holes mode: the z-moments as above (absent cells add nothing) and the six x/y moments of the
-  // valid cells.  With w = 1 for a valid cell, column e of half-height h, leading cell wl (row j+1+h), trailing wt (j-h):
-  //   n'  = n  + sum (wl - wt)             i'  = i  + sum e (wl - wt)        ii' = ii + sum e^2 (wl - wt)
-  //   j'  = j  - n  + sum [h wl + (h+1) wt]
-  //   ij' = ij - i  + sum e [h wl + (h+1) wt]
-  //   jj' = jj - 2j + n + sum [h^2 wl - (h+1)^2 wt]          (n, i, j on the right: before the step)
-  auto slide_holes = [&](auto uc) __attribute__((always_inline)) {
-    constexpr int u = decltype(uc)::value;
-    double sv[R + 1];
-    int wl_g[R + 1], wt_g[R + 1], el_g[R + 1], et_g[R + 1];  // per half-height: sum wl, sum wt, sum e wl, sum e wt
-    int q_l = 0, q_t = 0;                                     // sum e^2 wl, sum e^2 wt
-    const double Sz0 = Sz;
-    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
-      constexpr int d = decltype(dc)::value;
-      constexpr int h = Shape<Q>::hw(d);
-      constexpr int pl = u + R + 1 + h, pt = u + R - h;
-      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
-      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
-      const char* rl = ringb + vb[al];
-      const char* rt = ringb + vb[at];
-      auto column = [&](auto ec, bool init) __attribute__((always_inline)) {
-        constexpr int e = decltype(ec)::value - R;
-        const double zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + e) * 8));
-        const double zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + e) * 8));
-        const double uu = zl - zt, vv = zl + zt;
-        Sz += uu;
-        if (e != 0) Siz = fma((double)e, uu, Siz);
-        Szz = fma(uu, vv, Szz);
-        const int wl = absent(zl) ? 0 : 1, wt = absent(zt) ? 0 : 1;
-        if (init) {
-          sv[h] = vv;
-          wl_g[h] = wl;
-          wt_g[h] = wt;
-          el_g[h] = e * wl;
-          et_g[h] = e * wt;
-        } else {
-          sv[h] += vv;
-          wl_g[h] += wl;
-          wt_g[h] += wt;
-          el_g[h] += e * wl;
-          et_g[h] += e * wt;
-        }
-        q_l += e * e * wl;
-        q_t += e * e * wt;
-      };
-      column(std::integral_constant<int, R + d>{}, first);
-      if (d != 0) column(std::integral_constant<int, R - d>{}, false);
-    });
-    double acc = Sjz;
-    int dn = 0, di = 0, dj = 0, dij = 0, djj = 0;
-    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
-      constexpr int d = decltype(dc)::value;
-      constexpr int h = Shape<Q>::hw(d);
-      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
-      if (first) {
-        acc = fma((double)h + 0.5, sv[h], acc);
-        dn += wl_g[h] - wt_g[h];
-        di += el_g[h] - et_g[h];
-        dj += h * wl_g[h] + (h + 1) * wt_g[h];
-        dij += h * el_g[h] + (h + 1) * et_g[h];
-        djj += h * h * wl_g[h] - (h + 1) * (h + 1) * wt_g[h];
-      }
-    });
-    Sjz = fma(-0.5, Sz0 + Sz, acc);
-    Mjj += djj - 2 * Mj + Mn;
-    Mij += dij - Mi;
-    Mj += dj - Mn;
-    Mn += dn;
-    Mi += di;
-    Mii += q_l - q_t;
-  };
-
   // ---- the march ---------------------------------------------------------------------------------------------------
   int j = js;
   auto rotate = [&]() __attribute__((always_inline)) {
@@ -596,10 +545,6 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
           return;
         }
         constexpr bool out = true;
-        if (dmask != 0 && !holes) {  // a dirty row has entered the ring (it leads in this step's slide)
-          count_moments(u);
-          holes = true;
-        }
         if (out) {
           if ((dmask & kDiscMask) == 0) {
             if (GENERAL) {
@@ -612,13 +557,9 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, const int 
             tail_holes(j, uc);
           }
         }
-        if (holes)
-          slide_holes(uc);
-        else
-          slide(uc);
+        slide(uc);
         stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
         dmask = (dmask >> 1) | (row_dirty ? kTopBit : 0u);
-        holes = holes && dmask != 0;  // the last dirty row has left the ring: the table / closed form serves again
         load_row(j + 2 + R + C, pmq[u], phq[u]);
         if (out) store_row();
         ++j;
@@ -634,6 +575,7 @@ template <int Q, bool KEEP>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3(N3Args a) {
   constexpr int R = Shape<Q>::R;
   __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+  __shared__ unsigned long long hmask[2 * R + 2][2];  // invalid cells of the ring rows (HOLES march)
   // which block (uniform): [0, nb_fast) interior columns x interior rows; then the edge block columns over all rows;
   // then the top and the bottom frame rows of the interior columns
   int b = (int)blockIdx.x, bx, js, jend;
@@ -659,14 +601,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
   const int own_lo = a.i_lo + bx * kLanes;
   const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
   if (js >= jend) return;
-  const bool clean = general ? march3<Q, KEEP, true, false>(a, ring, i0, own_lo, js, jend)
-                             : march3<Q, KEEP, false, false>(a, ring, i0, own_lo, js, jend);
+  const bool clean = general ? march3<Q, KEEP, true, false>(a, ring, hmask, i0, own_lo, js, jend)
+                             : march3<Q, KEEP, false, false>(a, ring, hmask, i0, own_lo, js, jend);
   if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
     __syncthreads();
     if (general)
-      march3<Q, KEEP, true, true>(a, ring, i0, own_lo, js, jend);
+      march3<Q, KEEP, true, true>(a, ring, hmask, i0, own_lo, js, jend);
     else
-      march3<Q, KEEP, false, true>(a, ring, i0, own_lo, js, jend);
+      march3<Q, KEEP, false, true>(a, ring, hmask, i0, own_lo, js, jend);
   }
 }
 
@@ -677,7 +619,7 @@ int resident_blocks() {
   // (hipOccupancyMaxActiveBlocksPerMultiprocessor answers 12 for 13 120 B; the hardware admits 11: the census fits an
   // allocation granule of 1280..2048 bytes, the conservative end is used here)
   constexpr int R = Shape<Q>::R;
-  constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8;
+  constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8 + (2 * R + 2) * 16;  // ring + hole masks
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);
   if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
   static const int ov = getenv("TE_N3_BLOCKS_PER_CU") ? atoi(getenv("TE_N3_BLOCKS_PER_CU")) : 0;  // measurement aid
@@ -832,6 +774,8 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.gtab = L.clip_table;
   a.res = g.res;
   a.Nd = N;
+  a.Ni = d.npoints;
+  a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;
   a.Kr2 = (N * g.res) * (N * g.res);
   a.kinv = 1.0 / (N * (N - 1.0));

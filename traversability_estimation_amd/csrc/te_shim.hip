@@ -852,7 +852,8 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   std::lock_guard<std::mutex> lk(c->mu);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_device_ptr: geometry not set");
   if (const int rc = ensure_input_layer(c, layer)) return rc;
-  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;  // the caller fills it in place
+  // (robot_slope: handing out the pointer does not make the layer present -- the buffer is all NaN until the caller
+  // has filled it and says so with te_set_layer_present)
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
   *dptr = p;
@@ -863,6 +864,15 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
     c->chain_done = false;
     c->footprint_done = false;
   }
+  return TE_OK;
+}
+
+int te_set_layer_present(te_ctx* c, int layer, int present) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (layer != TE_LAYER_ROBOT_SLOPE) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: only the optional input layer robot_slope can be declared present / absent");
+  if (present && !c->robot_slope) return fail(TE_ERR_NOT_READY, "te_set_layer_present: robot_slope was never uploaded nor handed out (te_device_ptr)");
+  c->have_robot_slope = present != 0;
   return TE_OK;
 }
 
@@ -1640,29 +1650,33 @@ int te_bcast_params(te_ctx** ctxs, int n, int root) {
     const int nd = (int)devs.size();
     std::vector<Rccl::comm_t> comms(nd, nullptr);
     std::vector<void*> buf(nd, nullptr);
+    // streams of this call's own: the contexts' streams belong to their mutexes, and this is configure-time
+    std::vector<hipStream_t> st(nd, nullptr);
     int e = rccl.CommInitAll(comms.data(), nd, devs.data());
     if (e) return fail(TE_ERR_HIP, "te_bcast_params: ncclCommInitAll failed (%d)", e);
     bool bad = false;
     for (int d = 0; d < nd && !bad; ++d) {
-      bad = hipSetDevice(devs[d]) != hipSuccess || hipMalloc(&buf[d], sizeof(te_params)) != hipSuccess;
+      bad = hipSetDevice(devs[d]) != hipSuccess || hipMalloc(&buf[d], sizeof(te_params)) != hipSuccess ||
+            hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking) != hipSuccess;
       if (!bad && d == 0) bad = hipMemcpy(buf[0], &p, sizeof(te_params), hipMemcpyHostToDevice) != hipSuccess;
     }
     if (!bad) {
       rccl.GroupStart();
       for (int d = 0; d < nd; ++d) {  // rank 0 is the root's device; ncclChar == 0
         (void)hipSetDevice(devs[d]);
-        e = e ? e : rccl.Broadcast(buf[d], buf[d], sizeof(te_params), 0, 0, comms[d], ctxs[rep[d]]->stream);
+        e = e ? e : rccl.Broadcast(buf[d], buf[d], sizeof(te_params), 0, 0, comms[d], st[d]);
       }
       e = rccl.GroupEnd() || e;
       for (int d = 0; d < nd && !e; ++d) {
         (void)hipSetDevice(devs[d]);
-        bad = bad || hipStreamSynchronize(ctxs[rep[d]]->stream) != hipSuccess ||
+        bad = bad || hipStreamSynchronize(st[d]) != hipSuccess ||
               hipMemcpy(&got[d], buf[d], sizeof(te_params), hipMemcpyDeviceToHost) != hipSuccess;
       }
     }
     for (int d = 0; d < nd; ++d) {
       (void)hipSetDevice(devs[d]);
       if (buf[d]) (void)hipFree(buf[d]);
+      if (st[d]) (void)hipStreamDestroy(st[d]);
       if (comms[d]) rccl.CommDestroy(comms[d]);
     }
     if (bad || e) {

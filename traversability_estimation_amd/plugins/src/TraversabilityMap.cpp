@@ -66,9 +66,14 @@ bool TraversabilityMap::setElevationMap(const grid_map::GridMap& elevationMap) {
   // robot_slope (robotSlopeType_ :47) is nowhere computed by the reference: checkInclination reads it off whatever map
   // the node was handed, so it travels with the elevation map when it is there
   robotSlopeLayer_ = elevationMap.exists("robot_slope");
-  if (robotSlopeLayer_ &&
-      !check(te_upload_layer_circular(ctx_, TE_LAYER_ROBOT_SLOPE, elevationMap.get("robot_slope").data(), 0, start(0), start(1))))
-    return false;
+  if (robotSlopeLayer_) {
+    if (!check(te_upload_layer_circular(ctx_, TE_LAYER_ROBOT_SLOPE, elevationMap.get("robot_slope").data(), 0, start(0), start(1))))
+      return false;
+  } else {
+    // a map without the layer: the device must not keep checking inclinations against the previous map's layer (the
+    // reference's atPosition("robot_slope") throws for a map that lacks it)
+    (void)te_set_layer_present(ctx_, TE_LAYER_ROBOT_SLOPE, 0);
+  }
   geometry_ = grid_map::GridMap();
   geometry_.setGeometry(elevationMap.getLength(), elevationMap.getResolution(), elevationMap.getPosition());
   geometry_.setStartIndex(start);

@@ -490,7 +490,11 @@ static void test_traversability_map() {
                 n_safe, n_bad_incl);
     CHECK(n_bad_incl == 0);
     CHECK(n_safe_incl > 0 && n_safe_incl < n_safe);
+    // the next elevation map comes WITHOUT the layer (same geometry): the previous map's inclinations must not be used
+    CHECK(tm.setElevationMap(rolled(flat, si, sj)) && tm.computeTraversability());
+    CHECK(!tm.checkFootprintPaths(paths, results));
     CHECK(tm.setCheckRobotInclination(false));
+    CHECK(tm.checkFootprintPaths(paths, results) && results.size() == paths.size());
   }
   // a request with a path without poses stops there (TraversabilityEstimation.cpp:290)
   paths[4].poses.poses.clear();
