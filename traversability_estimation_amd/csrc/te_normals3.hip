@@ -87,13 +87,20 @@ typedef float __attribute__((address_space(1))) gfloat;
 // One block: columns [i0, i0 + 64), output rows [js, jend).  GENERAL: every row takes the x/y moments of its (possibly
 // clipped) disc from the table and the general tail -- the blocks of the first / last block column and of the top / bottom
 // frame rows; otherwise every disc of the block lies inside the map and the closed-form tail is used.
-// HOLES: the march can also handle discs with invalid cells: every ring row carries a bit mask of its invalid cells (hm),
-// a disc that holds such a row subtracts the x/y moments of the invalid cells it contains from those of the full (or
-// clipped) disc and takes the general tail.  Without it the march gives up at the first invalid
-// cell it stages and returns false; the kernel then runs the strip again with HOLES.  A clean strip -- the common case by
+// HOLES (0 / 1 / 2): how the march deals with invalid cells.
+//   0: not at all -- it gives up at the first invalid cell it stages and returns false; the kernel then runs the strip
+//      again with HOLES = 1.
+//   1: SPARSE holes.  Every ring row carries a bit mask of its invalid cells (hm); a disc that holds such a row subtracts
+//      the x/y moments of the invalid cells it contains from those of the full (or clipped) disc and takes the general
+//      tail.  The work is proportional to the dirty rows in the disc and the invalid cells in them: with 0.1 % speckle
+//      1.4x cheaper than (2), with 1 % 1.4x dearer, in solid unobserved regions 5x -- so this march gives up as well,
+//      when more than kSparseRows of the ring's rows are dirty, and the kernel runs the strip a third time with
+//   2: DENSE holes.  Invalid cells are held in the ring as a marker value and the six x/y moments of the VALID cells are
+//      slid like the z-moments while a dirty row is in the ring (about 240 integer operations per row, whatever the
+//      number of holes).  A clean strip -- the common case by
 // far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
 // clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
-template <int Q, bool KEEP, bool GENERAL, bool HOLES>
+template <int Q, bool KEEP, bool GENERAL, int HOLES>
 __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
                                        const int jend) {
   constexpr int R = Shape<Q>::R;
@@ -168,11 +175,18 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     const bool okm = __builtin_isfinite(pm) && rin, okh = __builtin_isfinite(ph) && halo_in && rin;
     const float tm = okm ? pm : zref32, th = okh ? ph : zref32;
     typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
-    const u32x2 bm = __builtin_bit_cast(u32x2, (double)tm - zref);  // +0.0 where absent
-    const u32x2 bh = __builtin_bit_cast(u32x2, (double)th - zref);
+    u32x2 bm = __builtin_bit_cast(u32x2, (double)tm - zref);  // +0.0 where absent ...
+    u32x2 bh = __builtin_bit_cast(u32x2, (double)th - zref);
+    if (HOLES == 2) {
+      // ... turned into the marker, the smallest denormal (one select on the low word): it adds nothing to the z-sums
+      // (absorbed by rounding, and 0 when squared) and can be told from every valid dz, which is a difference of two
+      // float32 values (a multiple of 2^-149, or exactly 0)
+      bm.x = okm ? bm.x : 1u;
+      bh.x = okh ? bh.x : 1u;
+    }
     *reinterpret_cast<u32x2*>(ringb + vbase + (ro * RB + R * 8)) = bm;
     *reinterpret_cast<u32x2*>(ringb + (vbase + vhd) + ro * RB) = bh;
-    if (HOLES) {
+    if (HOLES == 1) {
       // invalid cells of the map in this row, as bits over the window columns: lane k holds column R + k (main) and
       // column hcol (halo; lanes >= 2R repeat lane 2R - 1 and are ignored)
       const unsigned long long mm = __ballot(!__builtin_isfinite(pm) && rin);
@@ -209,7 +223,9 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   });
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
-  if (!HOLES && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
+  if (HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
+  constexpr int kSparseRows = 4;  // (measured on MI355X, 4096^2: 0.1 % speckle has 1.6 dirty rows of 20 on average, 1 % eleven)
+  if (HOLES == 1 && __builtin_expect(__builtin_popcount(dmask) > kSparseRows, 0)) return false;
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
@@ -346,7 +362,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   // The invalid cells come from the bit masks of the dirty ring rows of the disc (uniform loop over those rows, one
   // broadcast LDS read each; a lane shifts its run of the row out of the mask and walks the set bits -- with sparse
   // holes there is one, rarely two).  The z-moments are already right: an invalid cell is +0.0 in the ring.
-  auto tail_holes = [&](int j, auto uc) __attribute__((always_inline)) {
+  auto tail_sparse = [&](int j, auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
     const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
     int hn = 0, hi_ = 0, hj = 0, hii = 0, hij = 0, hjj = 0;
@@ -393,6 +409,61 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
     const float qn = __builtin_nanf("");
     const bool bad = unresolved != 0 && !nocentre;  // (no normal, slope or roughness where the input layer is invalid)
+    if (nocentre || bad) {
+      o_slope = qn;
+      o_rough = qn;
+      fx = qn;
+      fy = qn;
+      fz = qn;
+    }
+    if (__builtin_expect(__any(bad && own), 0)) flag_tiles(j);
+  };
+  // ---- HOLES == 2: x/y moments of the VALID cells, slid like the z-moments ----------------------------------------------
+  // They are kept only while a dirty row is in the ring ("holes" mode).  On entry they are counted once from the ring
+  // itself (absent cells carry the marker, whatever the reason: invalid, outside the map, above the strip), so no case
+  // analysis of borders and warm-up is needed; a disc without a dirty row never looks at them.
+  int Mn = 0, Mi = 0, Mj = 0, Mii = 0, Mij = 0, Mjj = 0;
+  bool holes = false;
+  auto absent = [&](double v) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned long long, v) == 1ull; };
+  auto count_moments = [&](int u) __attribute__((always_inline)) {
+    // disc of row j: ring rows u .. u+2R counted from the row vb[0] points to
+    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / RB) + u;
+    int n = 0, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
+#pragma unroll 1
+    for (int dj = -R; dj <= R; ++dj) {
+      const int hw = isqrt_c(Q - dj * dj);
+      int sl = slot0 + R + dj;
+      sl = sl >= NR ? sl - NR : sl;
+      sl = sl >= NR ? sl - NR : sl;
+      const double* row = ring + sl * W + lane + R;
+#pragma unroll 1
+      for (int di = -hw; di <= hw; ++di) {
+        const int w = absent(row[di]) ? 0 : 1;
+        n += w;
+        si += w * di;
+        sii += w * di * di;
+        sj += w * dj;
+        sij += w * di * dj;
+        sjj += w * dj * dj;
+      }
+    }
+    Mn = n; Mi = si; Mj = sj; Mii = sii; Mij = sij; Mjj = sjj;
+  };
+  auto tail_dense = [&](int j, auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int pc = u + R;  // ring position of row j
+    const double ctr = *reinterpret_cast<const double*>(ringb + vb[(pc / C) % NC] + ((pc % C) * RB + R * 8));
+    double qs = 0.0;
+    const int unresolved = general_tail3(a.res, Mn, Mi, Mj, Mii, Mij, Mjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+    const float sl = acosf_poly01(fz);
+    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    float rq = (float)(qs * rcp_fast((double)Mn * (double)(Mn - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+    const float qn = __builtin_nanf("");
+    const bool nocentre = absent(ctr);  // no normal, slope or roughness where the input layer is invalid
+    const bool bad = unresolved != 0 && !nocentre;
     if (nocentre || bad) {
       o_slope = qn;
       o_rough = qn;
@@ -487,6 +558,78 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     Sjz = fma(-0.5, Sz0 + Sz, acc);
   };
 
+  // the slide of a step in holes mode: the z-moments as above (absent cells add nothing) and the six x/y moments of the
+  // valid cells.  With w = 1 for a valid cell, column e of half-height h, leading cell wl (row j+1+h), trailing wt (j-h):
+  //   n'  = n  + sum (wl - wt)             i'  = i  + sum e (wl - wt)        ii' = ii + sum e^2 (wl - wt)
+  //   j'  = j  - n  + sum [h wl + (h+1) wt]
+  //   ij' = ij - i  + sum e [h wl + (h+1) wt]
+  //   jj' = jj - 2j + n + sum [h^2 wl - (h+1)^2 wt]          (n, i, j on the right: before the step)
+  auto slide_holes = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    double sv[R + 1];
+    int wl_g[R + 1], wt_g[R + 1], el_g[R + 1], et_g[R + 1];  // per half-height: sum wl, sum wt, sum e wl, sum e wt
+    int q_l = 0, q_t = 0;                                     // sum e^2 wl, sum e^2 wt
+    const double Sz0 = Sz;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr int pl = u + R + 1 + h, pt = u + R - h;
+      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      const char* rl = ringb + vb[al];
+      const char* rt = ringb + vb[at];
+      auto column = [&](auto ec, bool init) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value - R;
+        const double zl = *reinterpret_cast<const double*>(rl + (ol * RB + (R + e) * 8));
+        const double zt = *reinterpret_cast<const double*>(rt + (ot * RB + (R + e) * 8));
+        const double uu = zl - zt, vv = zl + zt;
+        Sz += uu;
+        if (e != 0) Siz = fma((double)e, uu, Siz);
+        Szz = fma(uu, vv, Szz);
+        const int wl = absent(zl) ? 0 : 1, wt = absent(zt) ? 0 : 1;
+        if (init) {
+          sv[h] = vv;
+          wl_g[h] = wl;
+          wt_g[h] = wt;
+          el_g[h] = e * wl;
+          et_g[h] = e * wt;
+        } else {
+          sv[h] += vv;
+          wl_g[h] += wl;
+          wt_g[h] += wt;
+          el_g[h] += e * wl;
+          et_g[h] += e * wt;
+        }
+        q_l += e * e * wl;
+        q_t += e * e * wt;
+      };
+      column(std::integral_constant<int, R + d>{}, first);
+      if (d != 0) column(std::integral_constant<int, R - d>{}, false);
+    });
+    double acc = Sjz;
+    int dn = 0, di = 0, dj = 0, dij = 0, djj = 0;
+    static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      constexpr int h = Shape<Q>::hw(d);
+      constexpr bool first = d == 0 || Shape<Q>::hw(d > 0 ? d - 1 : 0) != h;
+      if (first) {
+        acc = fma((double)h + 0.5, sv[h], acc);
+        dn += wl_g[h] - wt_g[h];
+        di += el_g[h] - et_g[h];
+        dj += h * wl_g[h] + (h + 1) * wt_g[h];
+        dij += h * el_g[h] + (h + 1) * et_g[h];
+        djj += h * h * wl_g[h] - (h + 1) * (h + 1) * wt_g[h];
+      }
+    });
+    Sjz = fma(-0.5, Sz0 + Sz, acc);
+    Mjj += djj - 2 * Mj + Mn;
+    Mij += dij - Mi;
+    Mj += dj - Mn;
+    Mn += dn;
+    Mi += di;
+    Mii += q_l - q_t;
+  };
+
   // ---- the march ---------------------------------------------------------------------------------------------------
   int j = js;
   auto rotate = [&]() __attribute__((always_inline)) {
@@ -497,7 +640,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       vb[NC - 1] = v0;
     }
   };
-  if constexpr (!HOLES) {
+  if constexpr (HOLES == 0) {
     bool aborted = false;
 #pragma unroll 1
     while (true) {
@@ -534,7 +677,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     }
     if (aborted) return false;
   } else {
-    bool done = false;
+    bool done = false, dense = false;
 #pragma unroll 1
     while (!done) {
       static_for<C>([&](auto uc) __attribute__((always_inline)) {
@@ -544,28 +687,40 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
           done = true;
           return;
         }
-        constexpr bool out = true;
-        if (out) {
-          if ((dmask & kDiscMask) == 0) {
-            if (GENERAL) {
-              const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
-              tail_clipped(j, ky);
-            } else {
-              tail(j);
-            }
-          } else {
-            tail_holes(j, uc);
-          }
+        if (HOLES == 2 && dmask != 0 && !holes) {  // a dirty row has entered the ring (it leads in this step's slide)
+          count_moments(u);
+          holes = true;
         }
-        slide(uc);
+        if ((dmask & kDiscMask) == 0) {
+          if (GENERAL) {
+            const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
+            tail_clipped(j, ky);
+          } else {
+            tail(j);
+          }
+        } else if constexpr (HOLES == 1) {
+          tail_sparse(j, uc);
+        } else {
+          tail_dense(j, uc);
+        }
+        if (HOLES == 2 && holes)
+          slide_holes(uc);
+        else
+          slide(uc);
         stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
         dmask = (dmask >> 1) | (row_dirty ? kTopBit : 0u);
+        if (HOLES == 2) holes = holes && dmask != 0;  // the last dirty row has left the ring: the table / closed form serves again
         load_row(j + 2 + R + C, pmq[u], phq[u]);
-        if (out) store_row();
+        store_row();
         ++j;
+        if (HOLES == 1 && __builtin_expect(__builtin_popcount(dmask) > kSparseRows && j < jend, 0)) {  // too many: the dense march
+          dense = true;
+          done = true;
+        }
       });
       if (!done) rotate();
     }
+    if (dense) return false;
   }
   if (__builtin_expect(flag_rows != 0, 0)) write_flags();
   return true;
@@ -601,14 +756,19 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
   const int own_lo = a.i_lo + bx * kLanes;
   const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
   if (js >= jend) return;
-  const bool clean = general ? march3<Q, KEEP, true, false>(a, ring, hmask, i0, own_lo, js, jend)
-                             : march3<Q, KEEP, false, false>(a, ring, hmask, i0, own_lo, js, jend);
+  const bool clean = general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
+                             : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
   if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
     __syncthreads();
-    if (general)
-      march3<Q, KEEP, true, true>(a, ring, hmask, i0, own_lo, js, jend);
-    else
-      march3<Q, KEEP, false, true>(a, ring, hmask, i0, own_lo, js, jend);
+    const bool sparse = general ? march3<Q, KEEP, true, 1>(a, ring, hmask, i0, own_lo, js, jend)
+                                : march3<Q, KEEP, false, 1>(a, ring, hmask, i0, own_lo, js, jend);
+    if (!sparse) {  // too many dirty rows at once: the march that slides the moments of the valid cells
+      __syncthreads();
+      if (general)
+        march3<Q, KEEP, true, 2>(a, ring, hmask, i0, own_lo, js, jend);
+      else
+        march3<Q, KEEP, false, 2>(a, ring, hmask, i0, own_lo, js, jend);
+    }
   }
 }
 
