@@ -389,14 +389,21 @@ def main():
         # HBM traffic of the same launch sequence: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
         # WRITE_SIZE do not fit one pass), so the number comes from the committed profile of this exact workload --
         # and only if that profile was taken with the kernels of this tree (hash of csrc/)
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tpath) and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
-            t = json.load(open(tpath))
-            if t.get("kernel_sources_sha16") == kernel_sources_sha16():
-                out["roofline"]["traffic"] = t["traffic_bytes"]
-                out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r02_hbm_traffic.json)"
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True)  # newest round first
+        if tpaths and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
+            sha = kernel_sources_sha16()
+            hit = None
+            for tp in tpaths:
+                t = json.load(open(tp))
+                if t.get("kernel_sources_sha16") == sha:
+                    hit = (tp, t)
+                    break
+            if hit:
+                out["roofline"]["traffic"] = hit[1]["traffic_bytes"]
+                out["roofline"]["traffic_unit"] = f"bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/{os.path.basename(hit[0])})"
             else:
-                out["roofline"]["traffic_unit"] = "not reported: profiles/r02_hbm_traffic.json was taken with other kernel sources"
+                out["roofline"]["traffic_unit"] = f"not reported: profiles/{os.path.basename(tpaths[0])} was taken with other kernel sources"
         if host_path is not None:
             out["host_path"] = host_path
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -43,8 +43,17 @@ def main():
     p = capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
                             fp_radius=synth.benchmark_radius(6.0, a.res), fp_offset=synth.benchmark_radius(3.0, a.res))
     elevs = [synth.perlin_elevation(n, n, seed=1235 + b) for b in range(B)]
-    if a.holes > 0:
+    if 0 < a.holes < 0.5:
         elevs = [synth.with_holes(e, a.holes, seed=99 + b) for b, e in enumerate(elevs)]
+    elif a.holes >= 0.5:  # rectangles of 100..400 cells a side until (holes - 0.5) of the area is covered (as bench.py --holes)
+        rng = np.random.default_rng(99)
+        for b in range(B):
+            area, target = 0, (a.holes - 0.5) * n * n
+            while area < target:
+                h, w = (int(v) for v in rng.integers(100, 400, size=2))
+                r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+                elevs[b][c0:c0 + w, r0:r0 + h] = np.nan
+                area += h * w
     flags = 0 if a.no_footprint else capi.RUN_FOOTPRINT
     if a.sequential:
         flags |= capi.RUN_SEQUENTIAL

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): GPU test suite, bench lines, rocprofv3 kernel statistics and PMC passes of the bench
 # workload.  Usage: tools/profile_round.sh <tag> [quick]   -> gpurun_out/<tag>/...
 # PMC passes are separate runs with --pmc only (never combined with trace domains).
-TAG=${1:-r02}
+TAG=${1:-r03}
 QUICK=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
@@ -10,11 +10,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $ROOT/bench.py"
-PROF_ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-host-path"  # (bench.py itself adds 2 x 100 event-timed launches)
+PROF_ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-check"  # (bench.py itself adds 2 x 100 event-timed launches)
 
 (cd $ROOT && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > $OUT/pytest.log
-timeout 600 $BENCH --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
-TE_NO_N3=1 timeout 600 $BENCH --steps 100 --warmup 20 --no-cpu-baseline --no-host-path > $OUT/bench_no_n3.json 2> $OUT/bench_no_n3.err
+timeout 900 $BENCH --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_overlap -o p --output-format csv -- $BENCH $PROF_ARGS > $OUT/kt_overlap.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_seq -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/kt_seq.log 2>&1

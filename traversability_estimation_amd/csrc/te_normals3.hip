@@ -94,7 +94,7 @@ typedef float __attribute__((address_space(1))) gfloat;
 //      the x/y moments of the invalid cells it contains from those of the full (or clipped) disc and takes the general
 //      tail.  The work is proportional to the dirty rows in the disc and the invalid cells in them: with 0.1 % speckle
 //      1.4x cheaper than (2), with 1 % 1.4x dearer, in solid unobserved regions 5x -- so this march gives up as well,
-//      when more than kSparseRows of the ring's rows are dirty, and the kernel runs the strip a third time with
+//      when more than kSparseRows (8) of the ring's 2R+2 rows are dirty, and the kernel runs the strip a third time with
 //   2: DENSE holes.  Invalid cells are held in the ring as a marker value and the six x/y moments of the VALID cells are
 //      slid like the z-moments while a dirty row is in the ring (about 240 integer operations per row, whatever the
 //      number of holes).  A clean strip -- the common case by
@@ -224,7 +224,11 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
   if (HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
-  constexpr int kSparseRows = 4;  // (measured on MI355X, 4096^2: 0.1 % speckle has 1.6 dirty rows of 20 on average, 1 % eleven)
+  // Break-even of the two marches, measured on MI355X (4096^2, R = 9): a disc row with invalid cells costs the sparse tail
+  // about 30 instructions, the dense march about 240 per row whatever it holds.  0.1 % speckle has 1.6 dirty rows of 20
+  // on average (never 9), 1 % eleven.  A lower threshold (4) made most strips of the 0.1 % map give up somewhere along
+  // their 94 rows and pay both marches: 1.02 ms per chain launch instead of 0.55.
+  constexpr int kSparseRows = 8;
   if (HOLES == 1 && __builtin_expect(__builtin_popcount(dmask) > kSparseRows, 0)) return false;
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
