@@ -85,6 +85,7 @@ struct Layers {
   hipStream_t aux_stream;
   hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_fp_fork, ev_fp_join;  // mask kernel of the lower half || sliding-sum kernel of the upper half (launch_footprint)
+  int sparse_holes;  // 1: at most a few per mille of the elevation cells are invalid (counted at upload): k_normals3 takes its sparse march
 };
 
 // polygon footprints (te_polygon.hip)

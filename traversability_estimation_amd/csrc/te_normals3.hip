@@ -70,6 +70,7 @@ struct N3Args {
   double res;
   double Nd, K1h, Kr2, kinv;  // N; N*res^2*sum(di^2)/2; (N*res)^2; 1/(N(N-1))
   int Ni, SIIi;               // N and sum(di^2) = sum(dj^2) of the full disc as integers (discs with invalid cells)
+  int sparse_holes;           // the map holds few invalid cells (host's count at upload): HOLES = 1 instead of 2
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
   int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
@@ -93,8 +94,10 @@ typedef float __attribute__((address_space(1))) gfloat;
 //   1: SPARSE holes.  Every ring row carries a bit mask of its invalid cells (hm); a disc that holds such a row subtracts
 //      the x/y moments of the invalid cells it contains from those of the full (or clipped) disc and takes the general
 //      tail.  The work is proportional to the dirty rows in the disc and the invalid cells in them: with 0.1 % speckle
-//      1.4x cheaper than (2), with 1 % 1.4x dearer, in solid unobserved regions 5x -- so this march gives up as well,
-//      when more than kSparseRows (8) of the ring's 2R+2 rows are dirty, and the kernel runs the strip a third time with
+//      1.4x cheaper than (2), with 1 % 1.4x dearer, in solid unobserved regions 5x.  Which of the two a launch uses is
+//      decided by the host from the fraction of invalid cells counted when the elevation was uploaded (a kernel that
+//      holds all three marches and hands a strip from one to the next measured slower in EVERY case: the compiler
+//      allocates registers for the union, 168 + scratch instead of 151).
 //   2: DENSE holes.  Invalid cells are held in the ring as a marker value and the six x/y moments of the VALID cells are
 //      slid like the z-moments while a dirty row is in the ring (about 240 integer operations per row, whatever the
 //      number of holes).  A clean strip -- the common case by
@@ -224,12 +227,6 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
   if (HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
-  // Break-even of the two marches, measured on MI355X (4096^2, R = 9): a disc row with invalid cells costs the sparse tail
-  // about 30 instructions, the dense march about 240 per row whatever it holds.  0.1 % speckle has 1.6 dirty rows of 20
-  // on average (never 9), 1 % eleven.  A lower threshold (4) made most strips of the 0.1 % map give up somewhere along
-  // their 94 rows and pay both marches: 1.02 ms per chain launch instead of 0.55.
-  constexpr int kSparseRows = 8;
-  if (HOLES == 1 && __builtin_expect(__builtin_popcount(dmask) > kSparseRows, 0)) return false;
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
@@ -681,7 +678,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     }
     if (aborted) return false;
   } else {
-    bool done = false, dense = false;
+    bool done = false;
 #pragma unroll 1
     while (!done) {
       static_for<C>([&](auto uc) __attribute__((always_inline)) {
@@ -717,20 +714,15 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         load_row(j + 2 + R + C, pmq[u], phq[u]);
         store_row();
         ++j;
-        if (HOLES == 1 && __builtin_expect(__builtin_popcount(dmask) > kSparseRows && j < jend, 0)) {  // too many: the dense march
-          dense = true;
-          done = true;
-        }
       });
       if (!done) rotate();
     }
-    if (dense) return false;
   }
   if (__builtin_expect(flag_rows != 0, 0)) write_flags();
   return true;
 }
 
-template <int Q, bool KEEP>
+template <int Q, bool KEEP, int HM>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3(N3Args a) {
   constexpr int R = Shape<Q>::R;
   __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
@@ -764,15 +756,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
                              : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
   if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
     __syncthreads();
-    const bool sparse = general ? march3<Q, KEEP, true, 1>(a, ring, hmask, i0, own_lo, js, jend)
-                                : march3<Q, KEEP, false, 1>(a, ring, hmask, i0, own_lo, js, jend);
-    if (!sparse) {  // too many dirty rows at once: the march that slides the moments of the valid cells
-      __syncthreads();
-      if (general)
-        march3<Q, KEEP, true, 2>(a, ring, hmask, i0, own_lo, js, jend);
-      else
-        march3<Q, KEEP, false, 2>(a, ring, hmask, i0, own_lo, js, jend);
-    }
+    if (general)
+      march3<Q, KEEP, true, HM>(a, ring, hmask, i0, own_lo, js, jend);
+    else
+      march3<Q, KEEP, false, HM>(a, ring, hmask, i0, own_lo, js, jend);
   }
 }
 
@@ -825,10 +812,13 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int nblocks = a.n_int * a.s_int + ne * a.s_edge + a.n_top + n_bottom;
   if (nblocks <= 0) return true;
   const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
+  // (the kernel that keeps the normals -- the plugin path -- exists with the dense march only)
   if (keep)
-    hipLaunchKernelGGL((k_normals3<Q, true>), grid, dim3(kLanes), 0, s, a);
+    hipLaunchKernelGGL((k_normals3<Q, true, 2>), grid, dim3(kLanes), 0, s, a);
+  else if (a.sparse_holes)
+    hipLaunchKernelGGL((k_normals3<Q, false, 1>), grid, dim3(kLanes), 0, s, a);
   else
-    hipLaunchKernelGGL((k_normals3<Q, false>), grid, dim3(kLanes), 0, s, a);
+    hipLaunchKernelGGL((k_normals3<Q, false, 2>), grid, dim3(kLanes), 0, s, a);
   return true;
 }
 
@@ -939,6 +929,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.res = g.res;
   a.Nd = N;
   a.Ni = d.npoints;
+  a.sparse_holes = L.sparse_holes;
   a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;
   a.Kr2 = (N * g.res) * (N * g.res);
