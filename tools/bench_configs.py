@@ -98,6 +98,7 @@ def run_cfg5(capi, synth, res, out):
         res5 = {"full_map_chain_ms": ms_full, "full_map_cells_per_s": n * n / (ms_full * 1e-3),
                 "full_map_chain_footprint_ms": ms_full_fp, "full_map_chain_footprint_cells_per_s": n * n / (ms_full_fp * 1e-3)}
         for flags, name, layer in ((0, "chain", "traversability"), (capi.RUN_FOOTPRINT, "chain+footprint", "traversability_footprint")):
+            c.run_chain(flags)  # (a region run with the footprint flag refreshes a COMPLETE footprint layer)
             for download in (False, True):
                 lat = []
                 for k, (r0, c0) in enumerate(origins):

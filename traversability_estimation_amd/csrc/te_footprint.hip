@@ -272,17 +272,11 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   constexpr int NC = MY / MBY;
   const int i = i0 + threadIdx.x;
   const int ic = i < g.rows ? i : g.rows - 1;
-  // threadIdx.y is the same for all lanes of a wavefront (64 x MBY threads): as a scalar it keeps the row index, the
-  // row guards and the row part of every address in scalar registers (the compiler cannot know it is uniform)
-  const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
-  const int jb = ty * NC;  // first tile row of this thread
-  // arguments the straight-line pass looks at for every cell, read once (the argument block is large and was being
-  // re-fetched with scalar loads cell by cell)
-  const bool do_combine = a.combine != 0, do_memo = a.write_memo != 0, do_rough = a.check_rough != 0;
-  const float w_scale = a.w_scale, w_slope = a.w_slope, w_step = a.w_step, w_rough = a.w_rough;
-  const int edge_fail = a.edge_fail;
-  // next to a border side on which the 2.5*res submap lookup fails the full checkForStep decides (submap_fails)
-  const bool i_bad = ((edge_fail & 1) && i0 + (int)threadIdx.x <= 2) || ((edge_fail & 2) && i0 + (int)threadIdx.x >= g.rows - 3);
+  // (MEASURED: making the row index a scalar -- readfirstlane of threadIdx.y, uniform per wavefront -- and hoisting the
+  // per-cell argument reads lowered the static instruction count of the straight-line pass by 5 % and RAISED the executed
+  // one by 13 % (1723 instead of 1522 per wavefront, SQ_INSTS_*): the extra scalar values spill to VGPR lanes,
+  // v_readlane / v_writelane around every use.  The kernel time did not move either way; the simple form stays.)
+  const int jb = threadIdx.y * NC;  // first tile row of this thread
   float s_slope[NC], s_step[NC], s_rough[NC];
   fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
@@ -291,12 +285,12 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     const size_t o = mo + (size_t)j * g.rows + ic;
     s_slope[c] = slope[o];
     s_step[c] = step[o];
-    s_rough[c] = (do_rough || do_combine) ? rough[o] : 1.0f;
+    s_rough[c] = (a.check_rough || a.combine) ? rough[o] : 1.0f;
   });
   {
     // all loads of the tile in flight at once (clamped addresses), then the LDS writes
     constexpr int NT = MX * MBY, NL = (MTW * MTH + NT - 1) / NT;
-    const int tid = ty * MX + threadIdx.x;
+    const int tid = threadIdx.y * MX + threadIdx.x;
     float le[NL], ls[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -330,7 +324,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     // columns are done cell by cell.
     static_assert((MTH - 2) % MBY == 0, "row segments");
     constexpr int SEG = (MTH - 2) / MBY;
-    const int la = threadIdx.x + 2, r0 = 1 + ty * SEG;
+    const int la = threadIdx.x + 2, r0 = 1 + threadIdx.y * SEG;
     float rm[3];
     auto row_min = [&](int r) {
       const float* k = t_key + r * MTW + la;
@@ -348,7 +342,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       const bool hit = (double)m < (double)t_elev[idx] - a.crit_step;  // :825 in the reference's double arithmetic
       t_kl[idx] = hit ? t_key[idx] : qnanf();
     });
-    const int tid = ty * MX + threadIdx.x;
+    const int tid = threadIdx.y * MX + threadIdx.x;
     if (tid < 4 * (MTH - 2)) {
       const int col = (tid & 3) == 0 ? 1 : MTW - 5 + (tid & 3);  // 1, MTW-4, MTW-3, MTW-2
       const int idx = (1 + (tid >> 2)) * MTW + col;
@@ -406,21 +400,21 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     constexpr int c = decltype(cc)::value;
     const int j = j0 + jb + c;
     const float c_slope = s_slope[c], c_step = s_step[c], c_rough = s_rough[c];
-    const bool j_bad = ((edge_fail & 4) && j <= 2) || ((edge_fail & 8) && j >= g.cols - 3);  // uniform
-    const bool near_bad_edge = i_bad || j_bad;
+    const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
+                                                ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
     const bool step_fast = !(c_step == 0.0f) || (q5 && ((screen_mask >> c) & 1u) != 0 && !near_bad_edge);
-    const bool slow = (c_slope == 0.0f) || !step_fast || (do_rough && c_rough == 0.0f);
+    const bool slow = (c_slope == 0.0f) || !step_fast || (a.check_rough && c_rough == 0.0f);
     slow_mask |= (slow && j < g.cols) ? (1u << c) : 0u;
     if (j < g.cols) {
       const size_t o = mo + (size_t)j * g.rows + i;
-      untrav[o] = 0;  // (a cell that needs the window counts or the full checkForStep is decided -- and stored -- below)
-      if (do_combine) {  // MathExpressionFilter, fixed form, float32, left to right
-        const float ta = w_slope * c_slope, tb = w_step * c_step, tc = w_rough * c_rough;
+      if (!slow) untrav[o] = 0;
+      if (a.combine) {  // MathExpressionFilter, fixed form, float32, left to right
+        const float ta = a.w_slope * c_slope, tb = a.w_step * c_step, tc = a.w_rough * c_rough;
         const float tab = ta + tb;
         const float tabc = tab + tc;
-        trav[o] = w_scale * tabc;
+        trav[o] = a.w_scale * tabc;
       }
-      if (do_memo && !slow) {  // a step check that the screen clears is memoised as passed (:857)
+      if (a.write_memo && !slow) {  // a step check that the screen clears is memoised as passed (:857)
         slope_fp[o] = qnanf();
         step_fp[o] = (c_step == 0.0f) ? 1.0f : qnanf();
         rough_fp[o] = qnanf();
@@ -433,7 +427,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     slow_mask &= slow_mask - 1;
     const int j = j0 + jb + c;
     const size_t o = mo + (size_t)j * g.rows + i;
-    const float c_slope = slope[o], c_step = step[o], c_rough = (do_rough || do_combine) ? rough[o] : 1.0f;
+    const float c_slope = slope[o], c_step = step[o], c_rough = (a.check_rough || a.combine) ? rough[o] : 1.0f;
     float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
     bool ok = true;
     const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
