@@ -221,7 +221,8 @@ def test_cfg5_true_size_streaming_8192(capi, oracle):
     # depend on the absolute position of the map, in the reference as here
     n, res, tile = 8192, 0.0625, 256
     # (a 2048^2 noise map repeated 4 x 4 under a slow ramp: the generator needs a minute for 8192^2, the content is beside the point)
-    elev = np.tile(synth.perlin_elevation(2048, 2048, seed=77).reshape(2048, 2048), (4, 4))
+    a = synth.perlin_elevation(2048, 2048, seed=77).reshape(2048, 2048)
+    elev = np.tile(np.block([[a, a[:, ::-1]], [a[::-1, :], a[::-1, ::-1]]]), (2, 2))  # mirrored: no cliffs at the seams
     elev = (elev + np.linspace(0.0, 1.5, n, dtype=np.float32)[None, :]).astype(np.float32)
     p = bench_params(capi, synth, 5, res)
     op = oracle_params(oracle, p)

@@ -24,7 +24,7 @@ def per_kernel(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             m = re.search(r"k_[a-z0-9_]+", r["Kernel_Name"])
-            if m:
+            if m and m.group(0) != "k_count_invalid":  # (runs once when the elevation is uploaded, not in a te_run_chain launch)
                 acc[m.group(0)].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
