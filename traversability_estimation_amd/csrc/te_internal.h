@@ -86,6 +86,7 @@ struct Layers {
   hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_fp_fork, ev_fp_join;  // mask kernel of the lower half || sliding-sum kernel of the upper half (launch_footprint)
   int sparse_holes;  // 1: at most a few per mille of the elevation cells are invalid (counted at upload): k_normals3 takes its sparse march
+  char* hole_queue;  // its scratch: normals_hole_queue_bytes() (te_normals3.hip), nullptr: the dense march serves
 };
 
 // polygon footprints (te_polygon.hip)
@@ -202,6 +203,7 @@ int footprint_inner_q(double res, double rmin, double rmax);  // te_footprint3.h
 bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags,
                    FastGrid* fg, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
+size_t normals_hole_queue_bytes();  // te_normals3.hip: scratch of the sparse-hole march for one device (any map, any batch)
 // te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)
 // region: the output cells to compute (whole block columns and the rows [j0, j1) of map `map`); nullptr: every map, every cell
 bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,

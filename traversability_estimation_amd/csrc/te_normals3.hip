@@ -44,6 +44,11 @@ namespace fast {
 namespace {
 
 constexpr int kN3Waves = 3;  // waves per SIMD the kernel is compiled for
+// Sparse-hole march: the cells whose disc holds an invalid cell wait in a per-block queue (global scratch, it stays in L2)
+// until 64 of them fill a wavefront for the general tail.  An item is 48 bytes: Sz, Siz, Sjz, Szz, the six x/y moments
+// of the valid cells packed into three words, and (row << 8 | lane).  Up to C rows are appended between two looks at
+// the queue (C <= 6, 64 cells each) on top of a remainder below 64.
+constexpr int kHoleQueueItems = 512, kHoleItemBytes = 48, kHoleQueueBytes = kHoleQueueItems * kHoleItemBytes;
 #ifndef TE_N3_ORDER
 #define TE_N3_ORDER 0  // 1: the columns are consumed in the reverse order of their reads (one LDS wait per step)
 #endif
@@ -71,6 +76,7 @@ struct N3Args {
   double Nd, K1h, Kr2, kinv;  // N; N*res^2*sum(di^2)/2; (N*res)^2; 1/(N(N-1))
   int Ni, SIIi;               // N and sum(di^2) = sum(dj^2) of the full disc as integers (discs with invalid cells)
   int sparse_holes;           // the map holds few invalid cells (host's count at upload): HOLES = 1 instead of 2
+  char* hole_queue;           // HOLES = 1: kHoleQueueBytes of global scratch per block (cells waiting for the general tail)
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
   int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
@@ -276,6 +282,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   // (values only: the stores are issued at the end of the step, behind the staging of the next row, so that the wait
   // for the prefetched row never includes this row's stores)
   float o_slope, o_rough, fx = 0.0f, fy = 0.0f, fz = 0.0f;
+  bool deferred = false;  // HOLES = 1: this lane's cell of the current row waits in the queue (its closed form is meaningless)
   auto tail = [&](int j) __attribute__((always_inline)) {
     bool bad;
     {
@@ -324,7 +331,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
     const float sl = acosf_poly01(fz);
     o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    if (__builtin_expect(__any(bad && own), 0)) {
+    if (__builtin_expect(__any(bad && own && !deferred), 0)) {
       const float qn = __builtin_nanf("");
       o_slope = bad ? qn : o_slope;
       o_rough = bad ? qn : o_rough;
@@ -363,6 +370,51 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   // The invalid cells come from the bit masks of the dirty ring rows of the disc (uniform loop over those rows, one
   // broadcast LDS read each; a lane shifts its run of the row out of the mask and walks the set bits -- with sparse
   // holes there is one, rarely two).  The z-moments are already right: an invalid cell is +0.0 in the ring.
+  unsigned qhead = 0, qtail = 0;  // uniform; items qhead .. qtail-1 (mod kHoleQueueItems) wait
+  char* const qb = (HOLES == 1 && !GENERAL && !KEEP)
+                       ? a.hole_queue + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * (size_t)kHoleQueueBytes
+                       : nullptr;
+  // the general tail for up to 64 waiting cells, one per lane; their slope / roughness go straight to the layers
+  auto flush_queue = [&](unsigned count) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the items were written by other lanes of this wave: through L2
+    const bool act = (unsigned)lane < count;
+    const char* it = qb + (size_t)((qhead + (unsigned)lane) & (kHoleQueueItems - 1)) * kHoleItemBytes;
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    d2 m0 = d2{0.0, 0.0}, m1 = d2{0.0, 0.0};
+    u4 w = u4{3u, 0u, 0u, 0u};
+    if (act) {
+      m0 = *reinterpret_cast<const d2*>(it);
+      m1 = *reinterpret_cast<const d2*>(it + 16);
+      w = *reinterpret_cast<const u4*>(it + 32);
+    }
+    const int qn_ = (int)(w.x & 0xffffu), qsi = (int)(short)(w.x >> 16), qsj = (int)(short)(w.y & 0xffffu), qsii = (int)(w.y >> 16),
+              qsij = (int)(short)(w.z & 0xffffu), qsjj = (int)(w.z >> 16);
+    const int jj = (int)(w.w >> 8), ll = (int)(w.w & 0xffu);
+    float gx, gy, gz;
+    double qs = 0.0;
+    const int unresolved = general_tail3(a.res, qn_, qsi, qsj, qsii, qsij, qsjj, m0.x, m0.y, m1.x, m1.y, gx, gy, gz, qs);
+    const float sl = acosf_poly01(gz);
+    float s_out = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    float rq = (float)(qs * rcp_fast((double)qn_ * (double)(qn_ - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    float r_out = qn_ > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+    const bool bad = act && unresolved != 0;
+    if (bad) s_out = r_out = __builtin_nanf("");
+    unsigned long long bm = __ballot(bad);
+    while (__builtin_expect(bm != 0ull, 0)) {  // unresolved cells go to the fix-up pass (rare)
+      const int l = __builtin_ctzll(bm);
+      bm &= bm - 1ull;
+      flag_tiles(__builtin_amdgcn_readlane(jj, l));
+    }
+    if (act) {
+      const size_t o = mo + (size_t)jj * a.rows + (size_t)(i0 + ll);
+      a.slope[o] = s_out;
+      a.rough[o] = r_out;
+    }
+    qhead += count;
+  };
   auto tail_sparse = [&](int j, auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
     const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
@@ -392,6 +444,32 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         hij += di * dj;
         hjj += dj * dj;
       }
+    }
+    if constexpr (!GENERAL && !KEEP) {
+      // Interior blocks: the lanes whose disc holds no invalid cell take the closed form like on a clean row; the
+      // others (22 % of the cells at 0.1 % speckle, while 79 % of the ROWS hold at least one) are put into the queue
+      // with their moments and get the general tail later, 64 at a time (flush_queue).
+      deferred = hn > 0;  // (for tail(): neither these lanes nor the invalid centres below are its business)
+      tail(j);
+      deferred = hn > 0 && !nocentre && own;
+      if (nocentre) o_slope = o_rough = __builtin_nanf("");  // no slope or roughness where the input layer is invalid
+      const unsigned long long dm = __ballot(deferred);
+      if (dm != 0ull) {
+        const unsigned pos = (qtail + __builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u))) & (kHoleQueueItems - 1);
+        if (deferred) {
+          typedef double __attribute__((ext_vector_type(2))) d2;
+          typedef unsigned __attribute__((ext_vector_type(4))) u4;
+          char* it = qb + (size_t)pos * kHoleItemBytes;
+          *reinterpret_cast<d2*>(it) = d2{Sz, Siz};
+          *reinterpret_cast<d2*>(it + 16) = d2{Sjz, Szz};
+          const unsigned w0 = (unsigned)(a.Ni - hn) | ((unsigned)(-hi_) << 16);
+          const unsigned w1 = ((unsigned)(-hj) & 0xffffu) | ((unsigned)(a.SIIi - hii) << 16);
+          const unsigned w2 = ((unsigned)(-hij) & 0xffffu) | ((unsigned)(a.SIIi - hjj) << 16);
+          *reinterpret_cast<u4*>(it + 32) = u4{w0, w1, w2, ((unsigned)j << 8) | (unsigned)lane};
+        }
+        qtail += (unsigned)__popcll(dm);
+      }
+      return;
     }
     int n0 = a.Ni, si0 = 0, sj0 = 0, sii0 = a.SIIi, sij0 = 0, sjj0 = a.SIIi;
     if (GENERAL) {
@@ -475,7 +553,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     if (__builtin_expect(__any(bad && own), 0)) flag_tiles(j);
   };
   auto store_row = [&]() __attribute__((always_inline)) {
-    if (own) {
+    if (own && !deferred) {
       p_slope[lane] = o_slope;
       p_rough[lane] = o_rough;
     }
@@ -692,6 +770,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
           count_moments(u);
           holes = true;
         }
+        deferred = false;
         if ((dmask & kDiscMask) == 0) {
           if (GENERAL) {
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
@@ -715,8 +794,12 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         store_row();
         ++j;
       });
+      if constexpr (HOLES == 1 && !GENERAL && !KEEP)
+        while (qtail - qhead >= (unsigned)kLanes) flush_queue(kLanes);
       if (!done) rotate();
     }
+    if constexpr (HOLES == 1 && !GENERAL && !KEEP)
+      while (qtail != qhead) flush_queue(qtail - qhead < (unsigned)kLanes ? qtail - qhead : (unsigned)kLanes);
   }
   if (__builtin_expect(flag_rows != 0, 0)) write_flags();
   return true;
@@ -774,7 +857,7 @@ int resident_blocks() {
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);
   if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
   static const int ov = getenv("TE_N3_BLOCKS_PER_CU") ? atoi(getenv("TE_N3_BLOCKS_PER_CU")) : 0;  // measurement aid
-  if (ov > 0) per_cu = ov;
+  if (ov > 0) per_cu = ov < kN3Waves * 4 ? ov : kN3Waves * 4;  // (the hole queues are allocated for kN3Waves * 4 per CU)
   return per_cu * device_cus();
 }
 
@@ -879,6 +962,10 @@ bool n3_launch_part4(int Q, const Geo& g, const void* args, bool keep_normals, i
 bool n3_launch_part5(int Q, const Geo& g, const void* args, bool keep_normals, int maps, hipStream_t s, bool* ok);
 #endif
 
+// Scratch of the sparse-hole march: one queue per resident block (the grids are sized to one round of resident blocks,
+// whatever the map and the batch).
+size_t normals_hole_queue_bytes() { return (size_t)(kN3Waves * 4) * (size_t)device_cus() * (size_t)kHoleQueueBytes; }
+
 // The normals / slope / roughness pass over region r (discs clipped by the map border included); returns false
 // if this kernel does not take the case (the caller then uses the sliding kernel of te_slide_normals.hip for everything).
 // On success the caller still owes the fix-up pass for the tiles this kernel flagged.
@@ -929,7 +1016,8 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.res = g.res;
   a.Nd = N;
   a.Ni = d.npoints;
-  a.sparse_holes = L.sparse_holes;
+  a.sparse_holes = L.sparse_holes && L.hole_queue ? 1 : 0;
+  a.hole_queue = L.hole_queue;
   a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;
   a.Kr2 = (N * g.res) * (N * g.res);

@@ -155,6 +155,7 @@ struct te_ctx {
   // invalid cells of the elevation layer as of the last whole upload (-1: unknown -- tiles, device pointer): see sparse_holes()
   long long invalid_cells = -1;
   unsigned long long* d_count = nullptr;
+  char* hole_queue = nullptr;  // scratch of k_normals3's sparse-hole march (allocated when a launch first picks it)
   bool tables_ready = false;
   // the circular-footprint tables are built separately: a footprint this build cannot handle (more than 20 cells) must
   // not stop the filter chain or the per-plugin entry points, which never use them (the reference has no such coupling)
@@ -200,10 +201,25 @@ int count_invalid_elevation(te_ctx* c) {
 
 // few invalid cells, scattered: at most 2 per mille (0.1 % speckle: the sparse march is 1.4x faster than the dense one,
 // at 1 % 1.4x slower; MI355X, 4096^2, R = 9).  Unknown counts take the dense march, whose cost does not depend on the map.
+// (A map without invalid cells takes the dense kernel too: its clean march is the same code, and a tile with invalid
+// cells uploaded later -- tiles are not counted -- is then in safe hands.)
 bool sparse_holes(const te_ctx* c) {
   static const int force = getenv("TE_N3_HOLES") ? atoi(getenv("TE_N3_HOLES")) : 0;  // measurement aid: 1 sparse, 2 dense
   if (force == 1 || force == 2) return force == 1;
-  return c->invalid_cells >= 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems;
+  return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems;
+}
+
+// the sparse march's queues; false (and the dense kernel) if the allocation fails
+bool ensure_hole_queue(te_ctx* c) {
+  if (c->hole_queue) return true;
+  if (hipSetDevice(c->device) != hipSuccess) return false;
+  void* p = nullptr;
+  if (hipMalloc(&p, fast::normals_hole_queue_bytes()) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  c->hole_queue = (char*)p;
+  return true;
 }
 
 void drop_graph(te_ctx* c) {
@@ -439,7 +455,8 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.ev_join = c->ev_join;
   c->L.ev_fp_fork = c->ev_fp_fork;
   c->L.ev_fp_join = c->ev_fp_join;
-  c->L.sparse_holes = sparse_holes(c) ? 1 : 0;
+  c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
+  c->L.hole_queue = c->hole_queue;
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   c->footprint_done = false;  // the layers the footprint pass reads have changed
@@ -480,7 +497,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     HIP_TRY(hipSetDevice(c->device));
     int slot = -1;
     // (the captured launches bake in which k_normals3 variant runs: the hint is part of the key)
-    const unsigned key = flags | (sparse_holes(c) ? 0x80000000u : 0u);
+    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u);
     for (int k = 0; k < te_ctx::kGraphs; ++k)
       if (c->graph_exec[k] && c->graph_flags[k] == key) slot = k;
     if (slot < 0) {
@@ -646,6 +663,7 @@ int te_destroy(te_ctx* c) {
     free_layers(c);
     if (c->d_spiral) (void)hipFree(c->d_spiral);
     if (c->d_count) (void)hipFree(c->d_count);
+    if (c->hole_queue) (void)hipFree(c->hole_queue);
     if (c->clip_table) (void)hipFree(c->clip_table);
     if (c->fp_clip_table) (void)hipFree(c->fp_clip_table);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
