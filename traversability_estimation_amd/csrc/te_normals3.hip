@@ -376,7 +376,9 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
                        : nullptr;
   // the general tail for up to 64 waiting cells, one per lane; their slope / roughness go straight to the layers
   auto flush_queue = [&](unsigned count) {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the items were written by other lanes of this wave: through L2
+    // the items were written by other lanes of THIS wave: workgroup scope -- wait for the stores, the CU's L1 is coherent
+    // for its own waves.  (Agent scope writes back and invalidates the XCD's L2 on this chip: the launch took 2.8 ms.)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const bool act = (unsigned)lane < count;
     const char* it = qb + (size_t)((qhead + (unsigned)lane) & (kHoleQueueItems - 1)) * kHoleItemBytes;
     typedef double __attribute__((ext_vector_type(2))) d2;
