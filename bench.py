@@ -100,7 +100,7 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     for f, _ in op._fields_:
         setattr(op, f, getattr(p, f))
     O.set_threads(threads)
-    n = 128 if threads == 1 else 384
+    n = 128 if threads == 1 else min(args.size, 1024)  # (calibration sample: enough rows for every thread)
     g = O.geom(n, n, args.res)
     crop = np.ascontiguousarray(elev_full[:n, :n])
     t0 = time.perf_counter()
@@ -110,7 +110,7 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     dt = time.perf_counter() - t0
     rate = n * n / dt
     # scale the sample so that it takes about cpu_seconds, at most the whole map
-    seconds = args.cpu_seconds if threads == 1 else min(args.cpu_seconds, 8.0)
+    seconds = args.cpu_seconds if threads == 1 else min(args.cpu_seconds, 10.0)
     n = int(min(args.size, max(128, (rate * seconds) ** 0.5)))
     n -= n % 64
     n = max(n, 128)

@@ -586,11 +586,11 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   na.given_normals = 0;
   // the combine is fused into the normals kernel only when the step layer is complete before it starts;
   // region runs: the step reach may exceed the normals reach, combine separately
-  na.combine = (whole && !overlap && !normals_only) ? 1 : 0;
+  na.combine = (whole && !overlap && !normals_only && !(flags & kDeferCombine)) ? 1 : 0;
   float* const knx = keep ? L.nx : nullptr;
   float* const kny = keep ? L.ny : nullptr;
   float* const knz = keep ? L.nz : nullptr;
-  const bool fused_combine = whole && !overlap && !normals_only;
+  const bool fused_combine = whole && !overlap && !normals_only && !(flags & kDeferCombine);
   FastGrid fg;
   bool combined = false;
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
@@ -607,7 +607,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   }
   if (overlap) (void)hipStreamWaitEvent(stream, L.ev_join, 0);
   // with the footprint pass right behind, its mask kernel (which reads the three scores anyway) combines
-  if (!combined && !normals_only && !(overlap && (flags & kDeferCombine))) {
+  if (!combined && !normals_only && !(flags & kDeferCombine)) {
     const dim3 cgrid((unsigned)((rc.i1 - rc.i0 + 255) / 256), (unsigned)(rc.j1 - rc.j0),
                      (unsigned)(rc.map >= 0 ? 1 : g.batch));
     hipLaunchKernelGGL(k_combine, cgrid, dim3(256), 0, stream, g, p.w_scale, p.w_slope, p.w_step, p.w_rough, L.slope,

@@ -442,14 +442,19 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   }
   if (!c->have_elev) return fail(TE_ERR_NOT_READY, "te_run_chain: no elevation uploaded");
   HIP_TRY(hipSetDevice(c->device));
-  c->L.aux_stream = (flags & TE_RUN_SEQUENTIAL) ? nullptr : c->aux_stream;
+  // Two streams (step filter || normals kernel) pay from about 2^21 cells: below that the launch is a handful of
+  // short kernels and the fork / join events cost more than the overlap gains -- one stream, the combine fused into the
+  // normals kernel (MI355X, R = 5, chain: 256^2 0.045 -> 0.030 ms, 512^2 0.042 -> 0.032, 1024^2 0.052 -> 0.046, 2048^2 equal).
+  static const bool force_two = getenv("TE_TWO_STREAMS") != nullptr;  // measurement aid
+  const bool small = !force_two && (size_t)c->geo.rows * c->geo.cols * c->geo.batch < ((size_t)1 << 21);
+  c->L.aux_stream = ((flags & TE_RUN_SEQUENTIAL) || small) ? nullptr : c->aux_stream;
   // whole-map run with the footprint pass right behind: the mask kernel writes the combined layer
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
   // (only if the footprint pass can run at all: with a footprint this build cannot handle the combined layer would
   // never be written)
   if ((flags & TE_RUN_FOOTPRINT) && !c->fp_tables_ready)
     return fail(c->fp_tables_rc ? c->fp_tables_rc : TE_ERR_NOT_READY, "%s", c->fp_tables_err[0] ? c->fp_tables_err : "footprint tables not built");
-  c->combine_deferred = (r.map < 0) && c->L.aux_stream && (flags & TE_RUN_FOOTPRINT);
+  c->combine_deferred = (r.map < 0) && !(flags & TE_RUN_SEQUENTIAL) && (flags & TE_RUN_FOOTPRINT);
   if (c->combine_deferred) flags |= kDeferCombine;
   c->L.ev_fork = c->ev_fork;
   c->L.ev_join = c->ev_join;
