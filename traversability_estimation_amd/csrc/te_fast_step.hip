@@ -18,7 +18,10 @@ namespace {
 
 // waves per SIMD the kernels are compiled for (register budget 512 / waves); the launchers size the
 // strips so that the whole grid is resident at this occupancy
-constexpr int kHeightWaves = 3, kScoreWaves = 2;
+#ifndef TE_SCORE_WAVES
+#define TE_SCORE_WAVES 2  // (3: 168 VGPRs and a few spills, but a wave of it then fits beside two k_normals3 waves -- tools/build_variant.sh)
+#endif
+constexpr int kHeightWaves = 3, kScoreWaves = TE_SCORE_WAVES;
 
 template <int Q>
 __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g, const float* __restrict__ elev,
