@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--normals-only", action="store_true")
     ap.add_argument("--footprint-only", action="store_true", help="time te_run_footprint alone (mask + slide) after one chain")
     ap.add_argument("--holes", type=float, default=0.0)
+    ap.add_argument("--boxes", type=int, default=0, help="raised / lowered rectangles of 4..40 cells a side (kerbs, crates): untraversable cells")
     ap.add_argument("--loops", type=str, default="", help="comma-separated K: host-timed loops of K launches + sync")
     ap.add_argument("--tag", type=str, default="")
     a = ap.parse_args()
@@ -54,12 +55,19 @@ def main():
                 r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
                 elevs[b][c0:c0 + w, r0:r0 + h] = np.nan
                 area += h * w
+    if a.boxes > 0:
+        rng = np.random.default_rng(7)
+        for b in range(B):
+            for _ in range(a.boxes):
+                h, w = (int(v) for v in rng.integers(4, 40, size=2))
+                r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+                elevs[b][c0:c0 + w, r0:r0 + h] += np.float32(rng.uniform(0.15, 0.5) * rng.choice([-1.0, 1.0]))
     flags = 0 if a.no_footprint else capi.RUN_FOOTPRINT
     if a.sequential:
         flags |= capi.RUN_SEQUENTIAL
     if a.normals_only:
         flags = capi.RUN_NORMALS_ONLY
-    out = {"tag": a.tag, "size": n, "batch": B, "radius_cells": a.radius_cells, "flags": flags, "holes": a.holes,
+    out = {"tag": a.tag, "size": n, "batch": B, "radius_cells": a.radius_cells, "flags": flags, "holes": a.holes, "boxes": a.boxes,
            "env": {k: v for k, v in os.environ.items() if k.startswith("TE_")}}
     with capi.Context(0) as ctx:
         ctx.set_params(p)
