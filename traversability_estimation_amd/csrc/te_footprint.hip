@@ -356,7 +356,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __syncthreads();
   const TileView ve = {t_elev, elev + mo, i0, j0, g.rows, MTH}, vs = {nullptr, step + mo, i0, j0, g.rows, MTH},
                  vl = {nullptr, slope + mo, i0, j0, g.rows, MTH}, vr = {nullptr, rough + mo, i0, j0, g.rows, MTH};
-  if (i >= g.rows) return;
+  const bool in_map = i < g.rows;  // (a thread beyond the last column takes no cells of its own but helps with the list below)
   // Every thread walks MY/MBY consecutive rows of its column.  For the 21-cell window of circle(2.5*res)
   // (di^2+dj^2 <= 5: rows dj=0,+-1 span |di|<=2, rows dj=+-2 span |di|<=1) the two window maxima slide:
   // each tile row is reduced once along i (H1 = max over |di|<=1, H2 = max over |di|<=2: 5 LDS reads and
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     h2l[slot] = fast::vmax3(h1l[slot], l[-2], l[2]);
   };
   unsigned screen_mask = 0;  // bit c: the screening pass clears my c-th cell
-  if (q5) {
+  if (q5 && in_map) {
     fast::static_for<4>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       reduce_row(r - 2, r);  // rows -2 .. 1
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
                                                 ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
     const bool step_fast = !(c_step == 0.0f) || (q5 && ((screen_mask >> c) & 1u) != 0 && !near_bad_edge);
     const bool slow = (c_slope == 0.0f) || !step_fast || (a.check_rough && c_rough == 0.0f);
-    slow_mask |= (slow && j < g.cols) ? (1u << c) : 0u;
-    if (j < g.cols) {
+    slow_mask |= (slow && j < g.cols && in_map) ? (1u << c) : 0u;
+    if (j < g.cols && in_map) {
       const size_t o = mo + (size_t)j * g.rows + i;
       if (!slow) untrav[o] = 0;
       if (a.combine) {  // MathExpressionFilter, fixed form, float32, left to right
@@ -421,31 +421,94 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       }
     }
   });
+  // The cells that need a window count or the full checkForStep.  A thread's own such cells used to be its own serial
+  // loop -- next to a kerb a few threads of a tile carry hundreds of them while the other lanes idle: a 4096^2 map with
+  // 3000 boxes took 2.2 ms in this kernel against 0.07 ms without.  They go to a tile-wide list instead (order-
+  // preserving compaction: neighbouring cells land in neighbouring lanes and meet similar work) and all 256 threads
+  // take them in turn.  An entry is  tile row << 7 | screening bit << 6 | tile column.  The list lives in t_kl, which
+  // nothing reads any more once the screening pass is through (circle(2.5 res) is always the tie-free shape Q = 5:
+  // 6.25 is not a sum of two squares; the general-shape screen below is kept for completeness and reads t_kl -- it
+  // then takes the cells thread by thread as before).
+  static_assert(sizeof(t_kl) >= MX * MY * sizeof(unsigned short), "the list fits the tile it replaces");
+  unsigned short* const todo = reinterpret_cast<unsigned short*>(t_kl);
+  __shared__ int ntodo;
+  if (!q5) {
 #pragma unroll 1
-  while (slow_mask) {
-    const int c = __ffs((int)slow_mask) - 1;
-    slow_mask &= slow_mask - 1;
-    const int j = j0 + jb + c;
-    const size_t o = mo + (size_t)j * g.rows + i;
+    while (slow_mask) {
+      const int c = __ffs((int)slow_mask) - 1;
+      slow_mask &= slow_mask - 1;
+      const int j = j0 + jb + c;
+      const size_t o = mo + (size_t)j * g.rows + i;
+      const float c_slope = slope[o], c_step = step[o], c_rough = (a.check_rough || a.combine) ? rough[o] : 1.0f;
+      float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
+      bool ok = true;
+      const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
+      if (c_slope == 0.0f) {
+        ok = count_zero_ok(g, a.slope_disc, vl, i, j, a.ncrit_slope);
+        m_slope = ok ? 1.0f : 0.0f;
+      }
+      if (ok && c_step == 0.0f) {
+        const bool screen_ok = check_step_screen(a.step_disc, t_elev, t_key, t_kl, ctr, a.crit_step);
+        const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
+                                                    ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
+        ok = (screen_ok && !near_bad_edge) || check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap, a.edge_fail);
+        m_step = ok ? 1.0f : 0.0f;
+      }
+      if (ok && a.check_rough && c_rough == 0.0f) {
+        ok = count_zero_ok(g, a.slope_disc, vr, i, j, a.ncrit_rough);
+        m_rough = ok ? 1.0f : 0.0f;
+      }
+      untrav[o] = ok ? 0 : 1;
+      if (a.write_memo) {
+        slope_fp[o] = m_slope;
+        step_fp[o] = m_step;
+        rough_fp[o] = m_rough;
+      }
+    }
+    return;  // (uniform)
+  }
+  const int tid2 = threadIdx.y * MX + threadIdx.x;
+  if (tid2 == 0) ntodo = 0;
+  __syncthreads();
+  fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value;
+    const bool need = ((slow_mask >> c) & 1u) != 0;
+    const unsigned long long bm = __ballot(need);
+    if (bm != 0ull) {  // uniform
+      int base = 0;
+      if (threadIdx.x == 0) base = atomicAdd(&ntodo, __popcll(bm));
+      base = __shfl(base, 0);
+      if (need)
+        todo[base + __popcll(bm & ((1ull << threadIdx.x) - 1ull))] =
+            (unsigned short)(((jb + c) << 7) | ((((screen_mask >> c) & 1u) != 0 ? 1 : 0) << 6) | (int)threadIdx.x);
+    }
+  });
+  __syncthreads();
+  const int n_todo = ntodo;
+#pragma unroll 1
+  for (int k = tid2; k < n_todo; k += MX * MBY) {
+    const int e = todo[k];
+    const int li = e & 63, lj = e >> 7;
+    const bool screened = ((e >> 6) & 1) != 0;
+    const int ci = i0 + li, j = j0 + lj;
+    const size_t o = mo + (size_t)j * g.rows + ci;
     const float c_slope = slope[o], c_step = step[o], c_rough = (a.check_rough || a.combine) ? rough[o] : 1.0f;
     float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
     bool ok = true;
-    const int ctr = (jb + c + MH) * MTW + (threadIdx.x + MH);
     if (c_slope == 0.0f) {  // checkForSlope
-      ok = count_zero_ok(g, a.slope_disc, vl, i, j, a.ncrit_slope);
+      ok = count_zero_ok(g, a.slope_disc, vl, ci, j, a.ncrit_slope);
       m_slope = ok ? 1.0f : 0.0f;
     }
     if (ok && c_step == 0.0f) {  // checkForStep
-      const bool screen_ok = q5 ? ((screen_mask >> c) & 1u) != 0
-                                : check_step_screen(a.step_disc, t_elev, t_key, t_kl, ctr, a.crit_step);
+      const bool screen_ok = screened;
       // (the screen knows nothing about failing submap lookups: next to such a border the full function decides)
-      const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
+      const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && ci <= 2) || ((a.edge_fail & 2) && ci >= g.rows - 3) ||
                                                   ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
-      ok = (screen_ok && !near_bad_edge) || check_step(g, a.step_disc, ve, vs, i, j, a.crit_step, a.max_gap, a.edge_fail);
+      ok = (screen_ok && !near_bad_edge) || check_step(g, a.step_disc, ve, vs, ci, j, a.crit_step, a.max_gap, a.edge_fail);
       m_step = ok ? 1.0f : 0.0f;
     }
     if (ok && a.check_rough && c_rough == 0.0f) {  // checkForRoughness
-      ok = count_zero_ok(g, a.slope_disc, vr, i, j, a.ncrit_rough);
+      ok = count_zero_ok(g, a.slope_disc, vr, ci, j, a.ncrit_rough);
       m_rough = ok ? 1.0f : 0.0f;
     }
     untrav[o] = ok ? 0 : 1;

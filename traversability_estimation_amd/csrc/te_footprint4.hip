@@ -28,7 +28,8 @@ namespace fast {
 namespace {
 
 constexpr int kF4Waves = 4;
-constexpr int kF4Head = 24;  // spiral entries every lane walks on its own before the wavefront takes the long walks over
+constexpr int kF4Head = 24;
+constexpr int kF4Many = 20, kF4Few = 3;  // discs left in a row: every lane walks its own spiral from kF4Many on, down to kF4Few  // spiral entries every lane walks on its own before the wavefront takes the long walks over
 
 struct F4Args {
   const float* trav;
@@ -247,6 +248,46 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
               tq += v[q];
             }
           }
+        }
+      }
+      // (1b) MANY discs left (a row along a kerb): every lane walks its own spiral, branch-free, eight entries per trip,
+      // until few are left.  The wavefront-wide walk below costs about 270 instructions per disc, this one about 25 per
+      // table entry for all lanes together: it pays from some twenty discs on.  (A 4096^2 map with 3000 boxes: 1.12 ms in
+      // this kernel with (2) alone.)
+      if (__popcll(__ballot(!found)) >= kF4Many) {
+        unsigned tq = 0;
+        int ncells = 0, ring_first = 0;
+        bool hitw = false;
+        const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.n_spiral; k0 += 8) {
+          unsigned v[8];
+          bool in[8];
+          int ring_no[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
+            const unsigned w = ptab[kk];  // uniform: a scalar load
+            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+            ring_no[q] = (int)((w >> 16) & 0xffu);
+            const int ii = icol + di, jj = j + dj;
+            in[q] = k0 + q < a.n_spiral && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
+            v[q] = ring[slot_of(dj) * W + lane + R + (in[q] ? di : 0)];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const bool live = in[q] && !found && !hitw;
+            const bool u = (v[q] >> 24) != 0;
+            ring_first = (live && u) ? ring_no[q] : ring_first;
+            tq += (live && !u) ? v[q] : 0u;
+            ncells += (live && !u) ? 1 : 0;
+            hitw = hitw || (live && u);
+          }
+          if (__popcll(__ballot(!found && !hitw)) < kF4Few) break;  // uniform
+        }
+        if (hitw) {
+          out = value_at(ring_first, (double)tq * a.inv_scale, ncells);
+          found = true;
         }
       }
       // (2) the discs whose first untraversable cell lies further out, one at a time with the whole wavefront: lane q
