@@ -205,3 +205,30 @@ def test_streaming_tiles_async_against_the_oracle(capi, oracle):
         oracle.set_threads(1)
         for b in tiles_in + tiles_out:
             capi.unpin_host(b)
+
+
+@pytest.mark.parametrize("off_cells", [0.0, 2.0])
+def test_blocked_discs_of_a_batch(capi, oracle, off_cells):
+    """The footprint pass's list of blocked cells (k_fp_slide4 appends, k_fp_blocked walks) indexes the cells of ALL
+    maps of a batch; with radiusMin = 0 nothing is listed and a blocked disc is 0 outright (:694-704)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res, B = 150, 130, 0.05, 3
+    elevs = [obstacle_map(synth, rows, cols, 900 + 13 * b, 4 + 9 * b) for b in range(B)]
+    r = synth.benchmark_radius(3, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=synth.benchmark_radius(5, res),
+                               fp_offset=synth.benchmark_radius(off_cells, res) if off_cells else 0.0)
+    g = oracle.geom(rows, cols, res, (0.0, 0.0))
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, B, res)
+        ctx.upload_elevation(np.stack(elevs))
+        for _ in range(2):  # the second pass starts from an emptied list
+            ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = ctx.download("traversability_footprint").reshape(B, cols, rows)
+    for b in range(B):
+        want = oracle.chain(g, op, elevs[b])
+        fp = oracle.footprint(g, op, elevs[b], want)
+        bad, worst, _ = compare_layer("traversability_footprint", got[b], fp)
+        assert bad == 0, f"map {b}: {bad} cells differ (worst {worst})"
+        assert (got[b] == 0).sum() > 20

@@ -249,6 +249,7 @@ struct MaskArgs {
   int combine;  // also write traversability = w_scale*((w_slope*slope + w_step*step) + w_rough*roughness) (float32)
   float w_scale, w_slope, w_step, w_rough;
   int ti0, tj0, map;  // first tile of the launch (in tiles of MX x MY cells) and the map (< 0: blockIdx.z): region runs
+  unsigned* blocked_count;  // the first mask launch of a pass empties k_fp_slide4's list (nullptr: not this launch)
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   }
   const int tid2 = threadIdx.y * MX + threadIdx.x;
   if (tid2 == 0) ntodo = 0;
+  if (tid2 == 0 && a.blocked_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *a.blocked_count = 0u;
   __syncthreads();
   fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
@@ -949,6 +951,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.w_rough = combine ? combine->w_rough : 0.0f;
   m.ti0 = m.tj0 = 0;
   m.map = -1;
+  m.blocked_count = L.fp_blocked_count;
   if (region_done) *region_done = false;
   // A region run (te_run_chain_region with the footprint flag): isTraversableForFilters of a cell reads scores within
   // 3 cells (circle(3 res), circle(2.5 res) and the 3x3 blocks around its cells), so the mask is recomputed on the
@@ -983,6 +986,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
       hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else
       hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+    m.blocked_count = nullptr;  // (a pass in two bands: the second launch must not empty the list again)
   };
   const int t_lo = rm.j0 / my, t_hi = (rm.j1 - 1) / my + 1;
   // Whole large maps: the two kernels of the pass overlap, half a map apart.  The mask kernel is the one kernel of the
@@ -1000,16 +1004,17 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     launch_mask(t_lo, t_mid, stream);
     (void)hipEventRecord(L.ev_fp_fork, stream);
     (void)hipStreamWaitEvent(L.aux_stream, L.ev_fp_fork, 0);
-    const bool f4 = fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, L.aux_stream, &top);
+    const bool f4 = fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, L.aux_stream, &top, false);
     const bool f3 = !f4 && fast::footprint_slide3(g, p, L, spiral_table, clip_table, L.aux_stream, &top);
     (void)hipEventRecord(L.ev_fp_join, L.aux_stream);
     launch_mask(t_mid, t_hi, stream);
     if (f4 || f3) {
       if (f4)
-        (void)fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, &bot);
+        (void)fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, &bot, false);
       else
         (void)fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, &bot);
       (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);
+      if (f4) fast::footprint_blocked4(g, p, L, spiral_table, stream);  // the listed cells of both bands
       return hipGetLastError();
     }
     (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);  // neither kernel takes the shape: the whole-map kernel below, after the mask

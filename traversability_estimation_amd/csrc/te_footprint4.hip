@@ -3,7 +3,7 @@
 //   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
 //     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
 //
-// k_fp_slide4 (te_footprint3.hip) slides one DOUBLE per cell and is bound by the instructions one wave can issue: 38
+// k_fp_slide3 (te_footprint3.hip) slides one DOUBLE per cell and is bound by the instructions one wave can issue: 38
 // ds_read_b64 + 38 v_add_f64 + scalar and wait instructions per row, 3 waves per SIMD, 11 blocks per CU (13 KB rings).
 // The footprint value is a mean of at most a few hundred traversability values in [0, 1] compared at 1e-5 -- it does
 // not need 53 bits.  Here a cell is ONE 32-bit word
@@ -15,8 +15,16 @@
 // the only error is the rounding of T' to 2^-k (k = 19 at R = 9: 9.5e-7 per cell, hence for the mean).
 // Half the LDS (20 rows x 82 words = 6.5 KB: 16 blocks per CU, 4 waves per SIMD), half the LDS instructions
 // (ds_read2_b32 takes the cells e and -e of a row together), a third fewer vector instructions.
+// A disc that holds an untraversable cell: if one lies within the inner radius the value is 0 (:694-704; checked on the
+// ring, all lanes at once).  Otherwise the disc is not walked here: its cell goes onto a list and k_fp_blocked takes the
+// list afterwards, ONE CELL PER LANE, each walking its own spiral straight from the layers (L2) in double like
+// isTraversable() does.  Walking inside the march -- the row's blocked discs one after the other, 64 lanes per disc --
+// serialises exactly where the work is: a strip that runs along a kerb was busy for a millisecond while the rest of
+// the GPU had finished (4096^2 with 3000 boxes: 1.12 ms in this kernel).  The list is filled in chunks of kF4Chunk
+// entries a block reserves with one atomic (one atomic per blocked row made 10^5 of them queue on one address: 1.6 ms);
+// the unused tail of a block's last chunk holds kF4NoCell.
 // Used when the host can bound the traversability values (layer written by the chain with non-negative weights);
-// otherwise, and for radii whose k would drop below 17, k_fp_slide4 serves.
+// otherwise, and for radii whose k would drop below 17, k_fp_slide3 serves.
 #include "te_internal.h"
 #include "te_march.h"
 
@@ -28,8 +36,6 @@ namespace fast {
 namespace {
 
 constexpr int kF4Waves = 4;
-constexpr int kF4Head = 24;
-constexpr int kF4Many = 20, kF4Few = 3;  // discs left in a row: every lane walks its own spiral from kF4Many on, down to kF4Few  // spiral entries every lane walks on its own before the wavefront takes the long walks over
 
 struct F4Args {
   const float* trav;
@@ -40,13 +46,13 @@ struct F4Args {
   int nbx, strip_rows;
   // the part of the map this launch covers: block columns [bx0, bx0 + nbx_l), output rows [j_lo, j_hi), map (< 0: blockIdx.z)
   int bx0, nbx_l, j_lo, j_hi, map;
-  int n_spiral;
-  const int16_t* table;  // [n_spiral][4]: di, dj, ring (integer norm), tie flag (never set here: tie-free discs only)
-  const int* gtab;       // clip table of the disc: {n, ...} per (ky, kx)
-  double rmin, rmax, res;
+  const int* gtab;  // clip table of the disc: {n, ...} per (ky, kx)
+  double rmin;      // inner radius: 0 makes every disc with an untraversable cell 0 (:694-704), no walk needed
+  int inner_q;      // largest di^2 + dj^2 of the rings within the inner radius that the SpiralIterator takes whole (-1: none)
   float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 24, scale = 2^k
   double inv_scale;    // 2^-k
-  int inner_q;  // see the tail, step (0)
+  unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
+  unsigned* blocked_count;  // ... and how many (reset by k_fp_mask, which runs before this kernel in every footprint pass)
 };
 
 constexpr int f4_chunk_rows(int NR) {
@@ -91,14 +97,9 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   const int kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
   const int nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
 
-  // the spiral table, entry ch * 64 + lane in register ch of lane `lane`: what the wavefront-wide walk below hands out
-  constexpr int NTAB = (int)(3.2 * (R + 1) * (R + 1) / kLanes) + 1;  // >= cells of a disc of radius R + 1
-  unsigned tabreg[NTAB];
-  {
-    const unsigned* __restrict__ ptab0 = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);
-#pragma unroll
-    for (int ch = 0; ch < NTAB; ++ch) tabreg[ch] = ch * kLanes + lane < a.n_spiral ? ptab0[ch * kLanes + lane] : 0u;
-  }
+  // the last block of a row of blocks is shifted left to end at the map edge: the columns it shares with its neighbour
+  // are the neighbour's (one store, one list entry per cell)
+  const bool own = icol >= bx * kLanes;
 
   // rows are loaded C steps before they are staged (a queue slot per unrolled position): with one step of lead the
   // wave waited for memory 38 % of its time (SQ_WAIT_ANY, profiles/r02_sq_counters.json)
@@ -162,8 +163,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   });
   gfloat* p_out = (gfloat*)(a.footprint + mo + (size_t)js * a.rows + i0);
   float out = 0.0f;
+  bool skip = false;  // this lane's cell of the current row is not stored here (not its own column, or on the list)
   const float rnt = (float)(a.inv_scale / (double)nt_mid);
-  const double drmin = a.rmin, inv_span = 1.0 / (a.rmax - a.rmin);
+  const double drmin = a.rmin;
+  unsigned chunk_at = 0;  // my chunk of the list: next free entry ...
+  int chunk_left = 0;     // ... and how many are left (uniform)
+  auto fill_chunk = [&]() __attribute__((always_inline)) {
+    for (int q = lane; q < chunk_left; q += kLanes) a.blocked_list[chunk_at + (unsigned)q] = kF4NoCell;
+  };
 
   auto tail = [&](int j, int u) __attribute__((always_inline)) {
     int nt = nt_mid;
@@ -176,163 +183,48 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
     const unsigned T = X - (NU << 24);  // sum of the fixed-point traversabilities of the disc, exact
     out = (float)T * rn;  // :732-735 no untraversable cell in the footprint: the mean (T < 2^29: the conversion is good to 2^-25)
     const bool blocked = NU != 0;
+    skip = !own;
     if (__builtin_expect(__any(blocked), 0)) {
-      // walk the spiral until the first untraversable cell :687-717; logical row j+dj sits dj+R rows below the
-      // oldest row of the ring, which is row u of the chunk vb[0] points to.
-      const int slot0 = (int)((__builtin_amdgcn_readfirstlane(vb[0])) / RB) + u;
-      const unsigned* __restrict__ ptab = reinterpret_cast<const unsigned*>(a.table + 4 * kMaxSpiral);  // packed entries
-      auto slot_of = [&](int dj) __attribute__((always_inline)) {
-        int sl = slot0 + dj + R;
-        sl = sl >= NR ? sl - NR : sl;
-        return sl >= NR ? sl - NR : sl;
-      };
-      auto value_at = [&](int ring_no, double t, int ncells) __attribute__((always_inline)) {
-        const double ru = (double)ring_no * a.res;  // getCurrentRadius()
-        if (drmin == 0.0 || ru <= drmin) return 0.0f;  // :694-704
-        const double factor = ((ru - drmin) * inv_span + 1.0) / 2.0;  // :705-711
-        t *= factor / ncells;
-        return (float)t;
-      };
-      bool found = !blocked;
-      // (0) An untraversable cell within the inner radius makes the footprint 0 whatever comes before it (:694-704; the
-      // spiral visits the rings in order), so a disc is first searched for one directly: all lanes at once, a few hundred
-      // ring reads, no table.  inner_q: largest di^2 + dj^2 of the rings that lie within the inner radius and are taken
-      // whole by the SpiralIterator (-1: none).  On a map full of obstacles most discs end here.
-      if (!found && drmin == 0.0) {
-        out = 0.0f;
-        found = true;
-      }
-      if (!found && a.inner_q >= 0) {
-        const int dm = (int)__builtin_sqrtf((float)a.inner_q);
-        int hits = 0;
-        for (int dj = -dm; dj <= dm; ++dj) {
-          const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
-          const unsigned* row = ring + slot_of(dj) * W + lane + R;
+      if (drmin == 0.0) {
+        out = blocked ? 0.0f : out;  // :694-704 radiusMin = 0: the first untraversable cell, wherever it lies, gives 0
+      } else {
+        bool listed = blocked && own;
+        if (a.inner_q >= 0) {
+          // an untraversable cell within the inner radius: 0 whatever comes before it (the spiral visits the rings in
+          // order).  Logical row j+dj sits dj+R rows below the oldest row of the ring, row u of the chunk vb[0] points to.
+          const int slot0 = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)vb[0]) / (unsigned)RB) + u;
+          const int dm = (int)__builtin_sqrtf((float)a.inner_q);
+          unsigned hits = 0;
+          for (int dj = -dm; dj <= dm; ++dj) {
+            const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
+            int sl = slot0 + dj + R;
+            sl = sl >= NR ? sl - NR : sl;
+            sl = sl >= NR ? sl - NR : sl;
+            const unsigned* row = ring + sl * W + lane + R;
 #pragma unroll 8
-          for (int di = -hwi; di <= hwi; ++di) hits += (int)(row[di] >> 24);
-        }
-        if (hits > 0) {
-          out = 0.0f;
-          found = true;
-        }
-      }
-      // (1) every lane walks the head of its own spiral, eight entries per trip with their eight ring cells fetched
-      // together (one entry per trip made every lane wait for a table load and an LDS read in turn).  Pointless after (0).
-      if (!found && a.inner_q < 8) {
-        unsigned tq = 0;  // fixed-point sum of the cells before the first untraversable one (exact)
-        int ncells = 0;
-        const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
-        const int n_head = a.n_spiral < kF4Head ? a.n_spiral : kF4Head;
-        for (int k0 = 0; k0 < n_head && !found; k0 += 8) {
-          unsigned v[8];
-          bool in[8];
-          int ring_no[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int kk = k0 + q < n_head ? k0 + q : n_head - 1;
-            const unsigned w = ptab[kk];  // uniform: a scalar load
-            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-            ring_no[q] = (int)((w >> 16) & 0xffu);
-            const int ii = icol + di, jj = j + dj;
-            in[q] = k0 + q < n_head && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
-            v[q] = ring[slot_of(dj) * W + lane + R + (in[q] ? di : 0)];
+            for (int di = -hwi; di <= hwi; ++di) hits += row[di] >> 24;
           }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (found || !in[q]) continue;
-            if ((v[q] >> 24) != 0) {
-              out = value_at(ring_no[q], (double)tq * a.inv_scale, ncells);
-              found = true;
-            } else {
-              ncells++;
-              tq += v[q];
-            }
+          if (blocked && hits != 0) {
+            out = 0.0f;
+            listed = false;
           }
         }
-      }
-      // (1b) MANY discs left (a row along a kerb): every lane walks its own spiral, branch-free, eight entries per trip,
-      // until few are left.  The wavefront-wide walk below costs about 270 instructions per disc, this one about 25 per
-      // table entry for all lanes together: it pays from some twenty discs on.  (A 4096^2 map with 3000 boxes: 1.12 ms in
-      // this kernel with (2) alone.)
-      if (__popcll(__ballot(!found)) >= kF4Many) {
-        unsigned tq = 0;
-        int ncells = 0, ring_first = 0;
-        bool hitw = false;
-        const bool inner = kx == 0 && j >= R && j < a.cols - R;  // my whole disc lies inside the map
-#pragma unroll 1
-        for (int k0 = 0; k0 < a.n_spiral; k0 += 8) {
-          unsigned v[8];
-          bool in[8];
-          int ring_no[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int kk = k0 + q < a.n_spiral ? k0 + q : a.n_spiral - 1;
-            const unsigned w = ptab[kk];  // uniform: a scalar load
-            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-            ring_no[q] = (int)((w >> 16) & 0xffu);
-            const int ii = icol + di, jj = j + dj;
-            in[q] = k0 + q < a.n_spiral && (inner || (ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols));
-            v[q] = ring[slot_of(dj) * W + lane + R + (in[q] ? di : 0)];
+        // the others onto the list: k_fp_blocked walks their spirals (and stores their values)
+        const unsigned long long bm = __ballot(listed);
+        if (bm != 0ull) {
+          const int n = __popcll(bm);
+          if (n > chunk_left) {
+            fill_chunk();
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)kF4Chunk);
+            chunk_at = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            chunk_left = kF4Chunk;
           }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const bool live = in[q] && !found && !hitw;
-            const bool u = (v[q] >> 24) != 0;
-            ring_first = (live && u) ? ring_no[q] : ring_first;
-            tq += (live && !u) ? v[q] : 0u;
-            ncells += (live && !u) ? 1 : 0;
-            hitw = hitw || (live && u);
-          }
-          if (__popcll(__ballot(!found && !hitw)) < kF4Few) break;  // uniform
+          if (listed) a.blocked_list[chunk_at + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(mo + (size_t)j * a.rows + icol);
+          chunk_at += (unsigned)n;
+          chunk_left -= n;
         }
-        if (hitw) {
-          out = value_at(ring_first, (double)tq * a.inv_scale, ncells);
-          found = true;
-        }
-      }
-      // (2) the discs whose first untraversable cell lies further out, one at a time with the whole wavefront: lane q
-      // takes entry 64 ch + q (held in registers since the kernel started: a table load per chunk was a memory round
-      // trip on the critical path), the first untraversable entry comes from a ballot, the sum of the cells before it
-      // from one reduction.  A lane walking 700 entries on its own kept the other 63 waiting.
-      unsigned long long rest = __ballot(!found);
-      while (rest != 0ull) {
-        const int l = __builtin_ctzll(rest);
-        rest &= rest - 1ull;
-        const int ic = i0 + l;
-        unsigned acc = 0;
-        int cnt = 0;
-        float oc = __builtin_nanf("");
-        bool done = false;
-        static_for<NTAB>([&](auto chc) __attribute__((always_inline)) {
-          constexpr int ch = decltype(chc)::value;
-          if (done || ch * kLanes >= a.n_spiral) return;  // uniform
-          const unsigned w = tabreg[ch];
-          const bool valid = ch * kLanes + lane < a.n_spiral;
-          const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-          const int ii = ic + di, jj = j + dj;
-          const bool in = valid && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
-          const unsigned v = ring[slot_of(dj) * W + l + R + di];
-          const unsigned long long bm = __ballot(in && (v >> 24) != 0);
-          if (bm != 0ull) {
-            const int first = __builtin_ctzll(bm);
-            const int ring_first = __builtin_amdgcn_readlane((int)((w >> 16) & 0xffu), first);
-            done = true;
-            if (drmin == 0.0 || (double)ring_first * a.res <= drmin) {  // :694-704: no sum needed
-              oc = 0.0f;
-              return;
-            }
-            const bool before = in && lane < first;
-            acc += before ? v : 0u;
-            cnt += __popcll(__ballot(before));
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) acc += (unsigned)__shfl_xor((int)acc, d);  // integers: any order
-            oc = value_at(ring_first, (double)acc * a.inv_scale, cnt);
-            return;
-          }
-          acc += in ? v : 0u;
-          cnt += __popcll(__ballot(in));
-        });
-        if (lane == l) out = oc;  // an untraversable cell is in the disc, so oc was set
+        skip = skip || listed;
       }
     }
   };
@@ -388,7 +280,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       slide(uc);
       stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u], umq[u], uhq[u]);
       load_row(j + 2 + R + C, pmq[u], phq[u], umq[u], uhq[u]);
-      p_out[lane] = out;
+      if (!skip) p_out[lane] = out;
       p_out += a.rows;
       ++j;
     });
@@ -400,6 +292,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       vb[NC - 1] = v0;
     }
   }
+  fill_chunk();
 }
 
 template <int Q>
@@ -410,7 +303,7 @@ void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
   if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;
   static const int per_cu_env = getenv("TE_F4_BLOCKS_PER_CU") ? atoi(getenv("TE_F4_BLOCKS_PER_CU")) : 0;  // measurement aid
-  if (per_cu_env > 0) per_cu = per_cu_env;
+  if (per_cu_env > 0 && per_cu_env < kF4Waves * 4) per_cu = per_cu_env;
   const int capacity = per_cu * device_cus();
   const int nz = a.map >= 0 ? 1 : (batch > 0 ? batch : 1);
   const int H = a.j_hi - a.j_lo;
@@ -482,17 +375,126 @@ bool f4_launch_part3(int Q, const void* args, int batch, hipStream_t s);
 bool f4_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
+namespace {
+
+constexpr int kFBTrip = 8;
+static_assert(kMaxSpiral % kFBTrip == 0, "k_fp_blocked reads whole trips of the table");
+
+struct FBArgs {
+  const float* trav;
+  const uint8_t* untrav;
+  float* footprint;
+  const unsigned* list;
+  const unsigned* count;
+  const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16
+  int n_spiral, rows, cols;
+  unsigned map_cells;
+  double rmin, rmax, def, res;
+};
+
+// isTraversable(center, radiusMax, traversability, radiusMin) :654-746 for the cells on the list, one cell per lane: the
+// SpiralIterator order comes from the host-built table (the same entry for all lanes of a wavefront: a scalar load),
+// the cells from the layers, the sum runs in double in the iterator's order like the reference's.  kFBTrip entries per
+// trip, their loads issued together.  A wavefront leaves when all its discs have met their untraversable cell.
+__global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
+  const unsigned n = *a.count;
+  const int lane = threadIdx.x;
+  for (unsigned c0 = blockIdx.x * kLanes; c0 < n; c0 += gridDim.x * kLanes) {
+    unsigned cell = c0 + lane < n ? a.list[c0 + lane] : kF4NoCell;
+    const bool act = cell != kF4NoCell;
+    cell = act ? cell : 0u;
+    if (!__any(act)) continue;
+    const unsigned mo = (cell / a.map_cells) * a.map_cells, rem = cell - mo;
+    const int j = (int)(rem / (unsigned)a.rows), i = (int)(rem - (unsigned)j * (unsigned)a.rows);
+    double sum = 0.0;
+    int cnt = 0;
+    bool done = !act;
+    int ring_hit = -1;
+    for (int k0 = 0; k0 < a.n_spiral; k0 += kFBTrip) {
+      if (__all(done)) break;
+      unsigned w[kFBTrip];
+      bool in[kFBTrip];
+      uint8_t u[kFBTrip];
+      float t[kFBTrip];
+#pragma unroll
+      for (int q = 0; q < kFBTrip; ++q) {
+        w[q] = a.ptab[k0 + q];  // (the table has kMaxSpiral words: the entries after the last one are read and not used)
+        const int di = (int)(signed char)(w[q] & 0xffu), dj = (int)(signed char)((w[q] >> 8) & 0xffu);
+        const int ii = i + di, jj = j + dj;
+        in[q] = k0 + q < a.n_spiral && !done && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
+        const unsigned o = in[q] ? mo + (unsigned)jj * (unsigned)a.rows + (unsigned)ii : cell;
+        u[q] = a.untrav[o];
+        t[q] = a.trav[o];
+      }
+#pragma unroll
+      for (int q = 0; q < kFBTrip; ++q) {  // (no branches: the first untraversable cell :690-717 stops the lane's sum)
+        const bool live = in[q] && !done;
+        const bool hit = live && u[q] != 0;
+        ring_hit = hit ? (int)((w[q] >> 16) & 0xffu) : ring_hit;
+        done = done || hit;
+        const bool add = live && !hit;
+        const double v = __builtin_isfinite(t[q]) ? (double)t[q] : a.def;  // :719-724
+        sum += add ? v : 0.0;
+        cnt += add ? 1 : 0;
+      }
+    }
+    float out = (float)(sum / cnt);  // (no untraversable cell after all: the mean :732-735)
+    if (ring_hit >= 0) {
+      const double ru = (double)ring_hit * a.res;  // getCurrentRadius()
+      if (a.rmin == 0.0 || ru <= a.rmin) {
+        out = 0.0f;  // :694-704
+      } else {
+        const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+        out = (float)(sum * (factor / cnt));
+      }
+    }
+    if (act) a.footprint[cell] = out;
+  }
+}
+
+}  // namespace
+
+// Entries of the list beyond one per cell: a block of k_fp_slide4 may leave up to kF4Chunk - 1 entries of its last
+// chunk unused, and a launch has at most (resident blocks + one row of blocks) of them (launch_f4).
+size_t f4_list_slack(int rows, int batch) {
+  const size_t nbx = (size_t)(rows + kLanes - 1) / kLanes;
+  return (size_t)kF4Chunk * ((size_t)kF4Waves * 4 * (size_t)device_cus() + 2 * nbx * (size_t)(batch > 0 ? batch : 1));
+}
+
+// The second half of a footprint pass that used k_fp_slide4: the listed cells (see the header).
+void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, hipStream_t s) {
+  if (p.rmin == 0.0) return;  // k_fp_slide4 wrote those cells itself (0)
+  FBArgs a;
+  a.trav = L.trav;
+  a.untrav = L.untrav;
+  a.footprint = L.footprint;
+  a.list = L.fp_blocked;
+  a.count = L.fp_blocked_count;
+  a.ptab = reinterpret_cast<const unsigned*>(spiral_table + 4 * kMaxSpiral);
+  a.n_spiral = p.n_spiral;
+  a.rows = g.rows;
+  a.cols = g.cols;
+  a.map_cells = (unsigned)((size_t)g.rows * g.cols);
+  a.rmin = p.rmin;
+  a.rmax = p.rmax;
+  a.def = p.def;
+  a.res = g.res;
+  hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)(32 * device_cus())), dim3(kLanes), 0, s, a);  // 8 waves per SIMD
+}
+
 // The fixed-point sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not
 // taken.  tcap: upper bound of the finite values of the traversability layer, as the host can prove it (the layer was
 // written by the chain: w_scale * (w_slope + w_step + w_rough) with non-negative weights); < 0: unknown.
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      double tcap, hipStream_t s, const Region* region) {
+                      double tcap, hipStream_t s, const Region* region, bool finish) {
   const Disc& d = p.fp_disc;
   static const bool off = getenv("TE_NO_F4") != nullptr;
   if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
     return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
-  if (p.n_spiral > ((int)(3.2 * (d.R + 1) * (d.R + 1) / kLanes) + 1) * kLanes) return false;  // the kernel's table registers
+  // 32-bit list entries, and room for every block's unfinished chunk
+  if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch + (double)f4_list_slack(g.rows, g.batch) > (double)L.fp_blocked_cap)
+    return false;
   // the fixed-point scale: (2R+1) cells of at most cap * 2^k + 1/2 each must stay below 2^24 (the packed edge sums), and
   // the default value that replaces NaN has to fit as well
   if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
@@ -515,23 +517,21 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.j_hi = region ? region->j1 : g.cols;
   a.map = region ? region->map : -1;
   if (a.j_hi <= a.j_lo || a.nbx_l <= 0) return true;
-  a.n_spiral = p.n_spiral;
-  a.table = spiral_table;
   a.gtab = clip_table;
   a.rmin = p.rmin;
-  a.rmax = p.rmax;
+  a.inner_q = footprint_inner_q(g.res, p.rmin, p.rmax);
   a.def = (float)p.def;
   a.scale = (float)ldexp(1.0, k);
   a.inv_scale = ldexp(1.0, -k);
-  a.res = g.res;
-  a.inner_q = footprint_inner_q(g.res, p.rmin, p.rmax);
-  if (f4_launch_part0(d.Q, &a, g.batch, s)) return true;
+  a.blocked_list = L.fp_blocked;
+  a.blocked_count = L.fp_blocked_count;
+  bool launched = f4_launch_part0(d.Q, &a, g.batch, s);
 #if TE_PARTS > 1
-  if (f4_launch_part1(d.Q, &a, g.batch, s) || f4_launch_part2(d.Q, &a, g.batch, s) || f4_launch_part3(d.Q, &a, g.batch, s) ||
-      f4_launch_part4(d.Q, &a, g.batch, s))
-    return true;
+  launched = launched || f4_launch_part1(d.Q, &a, g.batch, s) || f4_launch_part2(d.Q, &a, g.batch, s) || f4_launch_part3(d.Q, &a, g.batch, s) ||
+             f4_launch_part4(d.Q, &a, g.batch, s);
 #endif
-  return false;
+  if (launched && finish) footprint_blocked4(g, p, L, spiral_table, s);
+  return launched;
 }
 #endif  // TE_PART == 0
 

@@ -79,6 +79,9 @@ struct Layers {
   float* rough_fp;
   float* step_height;  // temp layer of StepFilter (never leaves the device)
   uint8_t* untrav;     // !isTraversableForFilters per cell
+  unsigned* fp_blocked;        // k_fp_slide4's list of cells whose disc holds an untraversable cell (one entry per cell at most) ...
+  unsigned* fp_blocked_count;  // ... and its length (k_fp_mask resets it)
+  size_t fp_blocked_cap;       // entries the list holds (cells + fast::f4_list_slack)
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
   int* clip_table;     // x/y moments of the normals disc clipped by the map border (build_clip_table)
   // second stream + fork/join events: step filter || normals kernel on whole-map runs (nullptr: sequential)
@@ -211,7 +214,13 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
 // te_footprint4.hip: the same on 32-bit fixed point, when the values of the traversability layer are bounded by tcap
 // (tcap < 0: no bound known)
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
-                      double tcap, hipStream_t s, const Region* region = nullptr);
+                      double tcap, hipStream_t s, const Region* region = nullptr, bool finish = true);
+constexpr int kF4Chunk = 256;              // entries of the list a block reserves at a time
+constexpr unsigned kF4NoCell = 0xffffffffu;  // an unused entry
+size_t f4_list_slack(int rows, int batch);
+// ... its second half: the cells whose disc holds an untraversable cell (finish = false above: the caller runs it, after
+// every k_fp_slide4 launch of the pass has completed)
+void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, hipStream_t s);
 void build_clip_table(const Disc& d, int Rk, int* out);  // (2*Rk+1)^2 * 6 ints, clip codes relative to radius Rk
 }  // namespace fast
 

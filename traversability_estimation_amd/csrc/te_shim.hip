@@ -745,9 +745,13 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     gtmp.cols = cols;
     gtmp.batch = batch;
     const size_t fb = ((size_t)fast::normals_fast_max_blocks(gtmp) * sizeof(int) + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&slab, 13 * lb + ub + fb);
-    if (e != hipSuccess)
-      return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", 13 * lb + ub + fb, hipGetErrorString(e));
+    // (+ the footprint pass's list of cells with an untraversable cell in their disc: one 32-bit entry per cell at
+    // most, and its counter)
+    const size_t list_cap = elems + fast::f4_list_slack(rows, batch);
+    const size_t qb = (list_cap * sizeof(unsigned) + 255) & ~(size_t)255;
+    const size_t total = 13 * lb + ub + fb + qb + 256;
+    hipError_t e = hipMalloc(&slab, total);
+    if (e != hipSuccess) return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", total, hipGetErrorString(e));
     c->slab = slab;
     char* b = (char*)slab;
     float** ptrs[13] = {&c->L.elev, &c->L.slope, &c->L.step,     &c->L.rough,   &c->L.trav,     &c->L.footprint, &c->L.nx,
@@ -755,9 +759,13 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     for (int k = 0; k < 13; ++k) *ptrs[k] = (float*)(b + (size_t)k * lb);
     c->L.untrav = (uint8_t*)(b + 13 * lb);
     c->L.block_flags = (int*)(b + 13 * lb + ub);
+    c->L.fp_blocked = list_cap < ((size_t)1 << 32) ? (unsigned*)(b + 13 * lb + ub + fb) : nullptr;
+    c->L.fp_blocked_count = (unsigned*)(b + 13 * lb + ub + fb + qb);
+    c->L.fp_blocked_cap = list_cap;
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
     HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub + fb, c->stream));
+    HIP_TRY(hipMemsetAsync(c->L.fp_blocked_count, 0, 256, c->stream));
     // the fix-up flags are zero between launches: k_normals_fixup clears every flag it consumes
     HIP_TRY(hipMemsetAsync(c->L.block_flags, 0, fb, c->stream));
   }
