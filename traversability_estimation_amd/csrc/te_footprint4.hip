@@ -15,20 +15,20 @@
 // the only error is the rounding of T' to 2^-k (k = 19 at R = 9: 9.5e-7 per cell, hence for the mean).
 // Half the LDS (20 rows x 82 words = 6.5 KB: 16 blocks per CU, 4 waves per SIMD), half the LDS instructions
 // (ds_read2_b32 takes the cells e and -e of a row together), a third fewer vector instructions.
-// A disc that holds an untraversable cell: if one lies within the inner radius the value is 0 (:694-704; checked on the
-// ring, all lanes at once).  Otherwise the disc is not walked here: its cell goes onto a list and k_fp_blocked takes the
-// list afterwards, ONE CELL PER LANE, each walking its own spiral straight from the layers (L2) in double like
-// isTraversable() does.  Walking inside the march -- the row's blocked discs one after the other, 64 lanes per disc --
-// serialises exactly where the work is: a strip that runs along a kerb was busy for a millisecond while the rest of
-// the GPU had finished (4096^2 with 3000 boxes: 1.12 ms in this kernel).  The list is filled in chunks of kF4Chunk
-// entries a block reserves with one atomic (one atomic per blocked row made 10^5 of them queue on one address: 1.6 ms);
-// the unused tail of a block's last chunk holds kF4NoCell.
+// A disc that holds an untraversable cell: 0 if that is its own centre (:694-704).  Otherwise the disc is not walked
+// here: its cell goes onto a list and k_fp_blocked takes the list afterwards, one disc per wavefront at a time, from
+// the layers (L2) in double like isTraversable() does, on the whole GPU.  Walking inside the march serialises exactly
+// where the work is: a strip that runs along a kerb was busy for a millisecond while the rest of the GPU had finished
+// (4096^2 with 3000 boxes: 1.12 ms in this kernel).  The list is filled in chunks of kF4Chunk entries a block reserves
+// with one atomic (one atomic per blocked row made 10^5 of them queue on one address: 1.6 ms); the unused tail of a
+// block's last chunk holds kF4NoCell.
 // Used when the host can bound the traversability values (layer written by the chain with non-negative weights);
 // otherwise, and for radii whose k would drop below 17, k_fp_slide3 serves.
 #include "te_internal.h"
 #include "te_march.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace te {
 namespace fast {
@@ -48,7 +48,6 @@ struct F4Args {
   int bx0, nbx_l, j_lo, j_hi, map;
   const int* gtab;  // clip table of the disc: {n, ...} per (ky, kx)
   double rmin;      // inner radius: 0 makes every disc with an untraversable cell 0 (:694-704), no walk needed
-  int inner_q;      // largest di^2 + dj^2 of the rings within the inner radius that the SpiralIterator takes whole (-1: none)
   float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 24, scale = 2^k
   double inv_scale;    // 2^-k
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
@@ -188,27 +187,16 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       if (drmin == 0.0) {
         out = blocked ? 0.0f : out;  // :694-704 radiusMin = 0: the first untraversable cell, wherever it lies, gives 0
       } else {
-        bool listed = blocked && own;
-        if (a.inner_q >= 0) {
-          // an untraversable cell within the inner radius: 0 whatever comes before it (the spiral visits the rings in
-          // order).  Logical row j+dj sits dj+R rows below the oldest row of the ring, row u of the chunk vb[0] points to.
-          const int slot0 = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)vb[0]) / (unsigned)RB) + u;
-          const int dm = (int)__builtin_sqrtf((float)a.inner_q);
-          unsigned hits = 0;
-          for (int dj = -dm; dj <= dm; ++dj) {
-            const int hwi = (int)__builtin_sqrtf((float)(a.inner_q - dj * dj));
-            int sl = slot0 + dj + R;
-            sl = sl >= NR ? sl - NR : sl;
-            sl = sl >= NR ? sl - NR : sl;
-            const unsigned* row = ring + sl * W + lane + R;
-#pragma unroll 8
-            for (int di = -hwi; di <= hwi; ++di) hits += row[di] >> 24;
-          }
-          if (blocked && hits != 0) {
-            out = 0.0f;
-            listed = false;
-          }
-        }
+        // An untraversable centre cell is the spiral's first cell: 0 (ring 0 lies within any inner radius > 0, :694-704).
+        // Logical row j sits R rows below the oldest row of the ring, which is row u of the chunk vb[0] points to.
+        // Nothing else is decided here -- a search of the inner disc on the ring (29 reads at 3 cells) made a strip that
+        // runs along a kerb take 160 us more than its neighbours, and the kernel ends with its last strip.
+        int sl = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)vb[0]) / (unsigned)RB) + u + R;
+        sl = sl >= NR ? sl - NR : sl;
+        sl = sl >= NR ? sl - NR : sl;
+        const bool self = (ring[sl * W + lane + R] >> 24) != 0;
+        out = (blocked && self) ? 0.0f : out;
+        const bool listed = blocked && own && !self;
         // the others onto the list: k_fp_blocked walks their spirals (and stores their values)
         const unsigned long long bm = __ballot(listed);
         if (bm != 0ull) {
@@ -377,7 +365,9 @@ bool f4_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 
 namespace {
 
-constexpr int kFBTrip = 8;
+constexpr int kFBTab = 4;    // chunks of 64 spiral entries a lane keeps in registers (256 entries: radii up to 8 cells)
+constexpr int kFBTrip = 8;   // entries per trip of the per-lane walks, their loads issued together
+constexpr int kFBDense = 8;  // list entries per wavefront from which every lane walks a disc of its own
 static_assert(kMaxSpiral % kFBTrip == 0, "k_fp_blocked reads whole trips of the table");
 
 struct FBArgs {
@@ -386,69 +376,202 @@ struct FBArgs {
   float* footprint;
   const unsigned* list;
   const unsigned* count;
-  const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16
-  int n_spiral, rows, cols;
+  const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16 (kMaxSpiral words)
+  int n_spiral, rows, cols, reach;
   unsigned map_cells;
   double rmin, rmax, def, res;
 };
 
-// isTraversable(center, radiusMax, traversability, radiusMin) :654-746 for the cells on the list, one cell per lane: the
-// SpiralIterator order comes from the host-built table (the same entry for all lanes of a wavefront: a scalar load),
-// the cells from the layers, the sum runs in double in the iterator's order like the reference's.  kFBTrip entries per
-// trip, their loads issued together.  A wavefront leaves when all its discs have met their untraversable cell.
+// isTraversable(center, radiusMax, traversability, radiusMin) :654-746 for the cells on the list, straight from the
+// layers (L2), in double like the reference.  A wavefront takes `group` consecutive list entries per trip, as few as
+// keep every wavefront of the launch busy, and there are two ways to walk the SpiralIterator order (host-built table):
+//   short list (a lone kerb: group < kFBDense) -- ONE DISC PER WAVEFRONT AT A TIME: lane q takes entry 64 ch + q (the
+//     first kFBTab chunks stay in registers), a ballot finds the first untraversable entry, the sum of the cells
+//     before it -- needed only beyond the inner radius -- is one reduction.  Two or three dependent loads per disc:
+//     three boxes on a 4096^2 map take 7 us (50 us with one disc per lane: 15 dependent trips);
+//   long list -- ONE DISC PER LANE: all lanes step through the table together (scalar loads), first for the index of
+//     their first untraversable cell (a byte load and four instructions per entry), then, if any lane's lies beyond the
+//     inner radius, for the sum of the cells before it in the iterator's order.  About 25 instructions per disc; the
+//     wave-wide walk needs 250, and 3 million discs (3000 boxes) took it 1.5 ms.
 __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
   const unsigned n = *a.count;
+  if (n == 0) return;
   const int lane = threadIdx.x;
-  for (unsigned c0 = blockIdx.x * kLanes; c0 < n; c0 += gridDim.x * kLanes) {
-    unsigned cell = c0 + lane < n ? a.list[c0 + lane] : kF4NoCell;
-    const bool act = cell != kF4NoCell;
-    cell = act ? cell : 0u;
-    if (!__any(act)) continue;
-    const unsigned mo = (cell / a.map_cells) * a.map_cells, rem = cell - mo;
-    const int j = (int)(rem / (unsigned)a.rows), i = (int)(rem - (unsigned)j * (unsigned)a.rows);
-    double sum = 0.0;
-    int cnt = 0;
-    bool done = !act;
-    int ring_hit = -1;
-    for (int k0 = 0; k0 < a.n_spiral; k0 += kFBTrip) {
-      if (__all(done)) break;
-      unsigned w[kFBTrip];
-      bool in[kFBTrip];
-      uint8_t u[kFBTrip];
-      float t[kFBTrip];
+  const unsigned nwaves = gridDim.x;
+  unsigned group = 1;
+  while (group < (unsigned)kLanes && group * nwaves < n) group *= 2;
+  // my entries of the table, and their offsets from the top left corner of the disc's bounding square
+  unsigned tw[kFBTab];
+  int toff[kFBTab];
 #pragma unroll
-      for (int q = 0; q < kFBTrip; ++q) {
-        w[q] = a.ptab[k0 + q];  // (the table has kMaxSpiral words: the entries after the last one are read and not used)
-        const int di = (int)(signed char)(w[q] & 0xffu), dj = (int)(signed char)((w[q] >> 8) & 0xffu);
-        const int ii = i + di, jj = j + dj;
-        in[q] = k0 + q < a.n_spiral && !done && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
-        const unsigned o = in[q] ? mo + (unsigned)jj * (unsigned)a.rows + (unsigned)ii : cell;
-        u[q] = a.untrav[o];
-        t[q] = a.trav[o];
-      }
+  for (int ch = 0; ch < kFBTab; ++ch) {
+    const int k = ch * kLanes + lane;
+    tw[ch] = k < a.n_spiral ? a.ptab[k] : 0u;
+    const int di = (int)(signed char)(tw[ch] & 0xffu), dj = (int)(signed char)((tw[ch] >> 8) & 0xffu);
+    toff[ch] = (dj + a.reach) * a.rows + (di + a.reach);
+  }
+  const int ctr = a.reach * a.rows + a.reach;
+  const int nch = (a.n_spiral + kLanes - 1) / kLanes;
+  for (unsigned c0 = blockIdx.x * group; c0 < n; c0 += nwaves * group) {
+    const unsigned mycell = (unsigned)lane < group && c0 + lane < n ? a.list[c0 + lane] : kF4NoCell;
+    const unsigned long long actm = __ballot(mycell != kF4NoCell);
+    if (actm == 0ull) continue;
+    // (cell -> map, column j, row i) once per lane; a lane without a cell takes the first one's: a valid address, and a
+    // neighbour's.  (__shfl, not readlane: with readlane the compiler dropped the select and the empty lanes read
+    // untrav[0xffffffff] -- a memory fault on the first obstacle map.)
+    const unsigned first_cell = (unsigned)__shfl((int)mycell, __builtin_ctzll(actm));
+    const unsigned cellv = mycell != kF4NoCell ? mycell : first_cell;
+    const unsigned mapv = cellv / a.map_cells, remv = cellv - mapv * a.map_cells;
+    const unsigned jv = remv / (unsigned)a.rows, iv = remv - jv * (unsigned)a.rows;
+    float myout = 0.0f;
+    if (group >= (unsigned)kFBDense) {
+      // ---- one disc per lane
+      const bool act = mycell != kF4NoCell;
+      const int i = (int)iv, j = (int)jv;
+      const bool all_in = __all(i >= a.reach && i < a.rows - a.reach && j >= a.reach && j < a.cols - a.reach);
+      const uint8_t* up = a.untrav + cellv;
+      const float* tp = a.trav + cellv;
+      // Both walks come in two versions: every disc of the group inside the map (the offset of an entry is the same
+      // scalar for all lanes: no bounds, no selects -- 9 and 12 instructions per entry against 31), or not.
+      const int N = a.n_spiral;
+      // (1) the index of the first untraversable cell in the iterator's order :690
+      int kmin = N;  // none
+      auto first_hit = [&](auto fast) __attribute__((always_inline)) {
+        constexpr bool kFast = decltype(fast)::value;
+        for (int k0 = 0; k0 < N; k0 += kFBTrip) {
+          if (__all(kmin < N)) break;
+          uint8_t u[kFBTrip];
+          bool in[kFBTrip];
 #pragma unroll
-      for (int q = 0; q < kFBTrip; ++q) {  // (no branches: the first untraversable cell :690-717 stops the lane's sum)
-        const bool live = in[q] && !done;
-        const bool hit = live && u[q] != 0;
-        ring_hit = hit ? (int)((w[q] >> 16) & 0xffu) : ring_hit;
-        done = done || hit;
-        const bool add = live && !hit;
-        const double v = __builtin_isfinite(t[q]) ? (double)t[q] : a.def;  // :719-724
-        sum += add ? v : 0.0;
-        cnt += add ? 1 : 0;
+          for (int q = 0; q < kFBTrip; ++q) {
+            const bool valid = k0 + q < N;                // uniform
+            const unsigned w = valid ? a.ptab[k0 + q] : 0u;  // uniform: a scalar load (past the end: the centre)
+            const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+            in[q] = valid;
+            if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
+            u[q] = kFast ? up[dj * a.rows + di] : up[in[q] ? dj * a.rows + di : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < kFBTrip; ++q) {
+            const int kq = (in[q] && u[q] != 0) ? k0 + q : N;
+            kmin = kq < kmin ? kq : kmin;
+          }
+        }
+      };
+      if (all_in)
+        first_hit(std::true_type{});
+      else
+        first_hit(std::false_type{});
+      // (2) its ring decides :694-711: within the inner radius 0, beyond it the weighted mean of the cells before it
+      const bool found = kmin < N;
+      const int ring_no = found ? (int)((a.ptab[kmin] >> 16) & 0xffu) : 0;
+      const double ru = (double)ring_no * a.res;  // getCurrentRadius()
+      const bool need = act && (!found || !(a.rmin == 0.0 || ru <= a.rmin));  // (not found: cannot happen for a listed cell; the mean then)
+      if (__any(need)) {
+        // the finite cells add up in double, the others are counted and enter as n * default (the reference adds them
+        // in the iterator's order; at most a few hundred terms in [0, 1]: the order shows in the 16th digit)
+        double sum = 0.0;
+        int cnt = 0, ndef = 0;
+        const int kend = need ? kmin : 0;
+        auto sum_before = [&](auto fast) __attribute__((always_inline)) {
+          constexpr bool kFast = decltype(fast)::value;
+          for (int k0 = 0; __any(k0 < kend); k0 += kFBTrip) {
+            float t[kFBTrip];
+            bool in[kFBTrip];
+#pragma unroll
+            for (int q = 0; q < kFBTrip; ++q) {
+              const bool valid = k0 + q < N;
+              const unsigned w = valid ? a.ptab[k0 + q] : 0u;
+              const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+              in[q] = k0 + q < kend;
+              if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
+              t[q] = kFast ? tp[dj * a.rows + di] : tp[in[q] ? dj * a.rows + di : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < kFBTrip; ++q) {
+              const bool fin = __builtin_isfinite(t[q]);  // :719-724
+              sum += (double)((in[q] && fin) ? t[q] : 0.0f);
+              cnt += in[q] ? 1 : 0;
+              ndef += (in[q] && !fin) ? 1 : 0;
+            }
+          }
+        };
+        if (all_in)
+          sum_before(std::true_type{});
+        else
+          sum_before(std::false_type{});
+        if (need) {
+          sum += (double)ndef * a.def;
+          const double factor = found ? ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0 : 1.0;  // :705-711 (:732-735)
+          myout = (float)(sum * (factor / cnt));
+        }
       }
+      if (act) a.footprint[mycell] = myout;
+      continue;
     }
-    float out = (float)(sum / cnt);  // (no untraversable cell after all: the mean :732-735)
-    if (ring_hit >= 0) {
-      const double ru = (double)ring_hit * a.res;  // getCurrentRadius()
-      if (a.rmin == 0.0 || ru <= a.rmin) {
-        out = 0.0f;  // :694-704
-      } else {
-        const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
-        out = (float)(sum * (factor / cnt));
+    // ---- one disc per wavefront at a time
+    unsigned long long rest = actm;
+    while (rest != 0ull) {
+      const int l = __builtin_ctzll(rest);
+      rest &= rest - 1ull;
+      const unsigned cell = (unsigned)__builtin_amdgcn_readlane((int)cellv, l);
+      const int i = __builtin_amdgcn_readlane((int)iv, l), j = __builtin_amdgcn_readlane((int)jv, l);
+      const bool inside = i >= a.reach && i < a.rows - a.reach && j >= a.reach && j < a.cols - a.reach;  // the whole bounding square lies in the map
+      // (a pointer before the layer for a cell near the border: never dereferenced, those lanes read the centre)
+      const float* tb = a.trav + ((long long)cell - ctr);
+      const uint8_t* ub = a.untrav + ((long long)cell - ctr);
+      double acc = 0.0;
+      int cnt = 0;
+      float oc = 0.0f;
+      bool done = false;
+      auto chunk = [&](unsigned w, int off, int k0) __attribute__((always_inline)) {
+        bool in = k0 + lane < a.n_spiral;
+        if (!inside) {
+          const int ii = i + (int)(signed char)(w & 0xffu), jj = j + (int)(signed char)((w >> 8) & 0xffu);
+          in = in && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
+        }
+        const int o = in ? off : ctr;
+        const uint8_t u = ub[o];
+        const float t = tb[o];
+        const unsigned long long bm = __ballot(in && u != 0);
+        const double v = __builtin_isfinite(t) ? (double)t : a.def;  // :719-724
+        if (bm != 0ull) {  // the first untraversable cell :690-717
+          const int first = __builtin_ctzll(bm);
+          const int ring_first = __builtin_amdgcn_readlane((int)((w >> 16) & 0xffu), first);
+          const double ru = (double)ring_first * a.res;  // getCurrentRadius()
+          done = true;
+          if (a.rmin == 0.0 || ru <= a.rmin) return;  // :694-704: 0, no sum needed
+          const bool before = in && lane < first;
+          acc += before ? v : 0.0;
+          cnt += __popcll(__ballot(before));
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+          const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
+          oc = (float)(acc * (factor / cnt));
+          return;
+        }
+        acc += in ? v : 0.0;
+        cnt += __popcll(__ballot(in));
+      };
+      static_for<kFBTab>([&](auto chc) __attribute__((always_inline)) {
+        constexpr int ch = decltype(chc)::value;
+        if (done || ch >= nch) return;  // uniform
+        chunk(tw[ch], toff[ch], ch * kLanes);
+      });
+      for (int ch = kFBTab; ch < nch && !done; ++ch) {
+        const int k = ch * kLanes + lane;
+        const unsigned w = k < a.n_spiral ? a.ptab[k] : 0u;
+        const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
+        chunk(w, (dj + a.reach) * a.rows + (di + a.reach), ch * kLanes);
       }
+      if (!done) {  // (no untraversable cell after all: the mean :732-735)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        oc = (float)(acc / cnt);
+      }
+      if (lane == l) myout = oc;
     }
-    if (act) a.footprint[cell] = out;
+    if (mycell != kF4NoCell) a.footprint[mycell] = myout;
   }
 }
 
@@ -474,12 +597,14 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
   a.n_spiral = p.n_spiral;
   a.rows = g.rows;
   a.cols = g.cols;
+  a.reach = p.reach;
   a.map_cells = (unsigned)((size_t)g.rows * g.cols);
   a.rmin = p.rmin;
   a.rmax = p.rmax;
   a.def = p.def;
   a.res = g.res;
-  hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)(32 * device_cus())), dim3(kLanes), 0, s, a);  // 8 waves per SIMD
+  static const int per_cu = getenv("TE_FB_BLOCKS_PER_CU") ? atoi(getenv("TE_FB_BLOCKS_PER_CU")) : 24;  // 6 waves per SIMD: 77 registers (measurement aid)
+  hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)((per_cu > 0 ? per_cu : 24) * device_cus())), dim3(kLanes), 0, s, a);
 }
 
 // The fixed-point sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not
@@ -519,7 +644,6 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   if (a.j_hi <= a.j_lo || a.nbx_l <= 0) return true;
   a.gtab = clip_table;
   a.rmin = p.rmin;
-  a.inner_q = footprint_inner_q(g.res, p.rmin, p.rmax);
   a.def = (float)p.def;
   a.scale = (float)ldexp(1.0, k);
   a.inv_scale = ldexp(1.0, -k);
