@@ -232,3 +232,52 @@ def test_blocked_discs_of_a_batch(capi, oracle, off_cells):
         bad, worst, _ = compare_layer("traversability_footprint", got[b], fp)
         assert bad == 0, f"map {b}: {bad} cells differ (worst {worst})"
         assert (got[b] == 0).sum() > 20
+
+
+_DENSE_LIST_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+from traversability_estimation_amd import capi, synth
+from tests.helpers import compare_layer, to_te_params
+O.build()
+capi.load()
+rows, cols, res = 260, 230, 0.05
+bad_total = 0
+for fp_cells, off_cells, boxes, origin in ((6, 3, 30, (0.0, 0.0)), (9, 4, 18, (1.5, -2.0)), (4, 1, 40, (0.0, 0.0))):
+    elev = synth.with_steps(synth.perlin_elevation(rows, cols, seed=40 + boxes, amplitude=0.12), boxes, seed=47 + boxes)
+    elev[100:104, 60:75] = np.nan
+    r = synth.benchmark_radius(3, res)
+    op = O.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                          fp_radius=synth.benchmark_radius(fp_cells, res), fp_offset=synth.benchmark_radius(off_cells, res))
+    g = O.geom(rows, cols, res, origin)
+    want = O.chain(g, op, elev)
+    fp = O.footprint(g, op, elev, want)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, origin)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = ctx.download("traversability_footprint")
+    bad, worst, nn = compare_layer("traversability_footprint", got, fp)
+    partial = int(((got > 0) & (got < 1)).sum())
+    print(fp_cells, off_cells, boxes, "mismatches", bad, "worst", worst, "cells strictly between 0 and 1:", partial)
+    bad_total += bad + (0 if partial > 1000 else 1)
+sys.exit(1 if bad_total else 0)
+"""
+
+
+def test_blocked_discs_one_per_lane():
+    """k_fp_blocked walks one disc per lane when the list is long for the launch (>= 8 entries per wavefront: 49 152
+    on an MI355X, more than a map the oracle finishes in seconds can hold).  TE_FB_BLOCKS_PER_CU=1 shrinks the launch to
+    256 wavefronts, so that the test maps take that path (the variable is read once per process: a process of its own).
+    Maps with borders on all sides (the bounds-checked loops) and an interior large enough for the scalar-offset ones."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TE_FB_BLOCKS_PER_CU="1")
+    r = subprocess.run([sys.executable, "-c", _DENSE_LIST_SCRIPT, root], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
