@@ -234,6 +234,34 @@ def test_blocked_discs_of_a_batch(capi, oracle, off_cells):
         assert (got[b] == 0).sum() > 20
 
 
+@pytest.mark.parametrize("res,fp_cells,off_cells,origin", [(0.05, 4, 2, (1.5, -2.0)), (0.03, 10, 5, (0.0, 0.0)), (0.03, 12, 1, (-3.17, 8.4)),
+                                                          (0.1, 5, 0, (0.35, 0.05)), (0.04, 7, 3, (12.3, -7.7))])
+def test_fixed_point_footprint_at_tie_radii(capi, oracle, res, fp_cells, off_cells, origin):
+    """radius + offset a whole number of cells (the reference's own 0.45 m at 0.03 m): the cells exactly on the circle
+    belong to a disc or not as SpiralIterator::isInside decides from rounded positions, centre by centre -- the
+    fixed-point kernel slides the shape with its circle and takes the rejected cells out per row (k_fp_slide4<Q, true>),
+    k_fp_blocked applies the test to the flagged table entries.  Map origins that move the rounding around."""
+    from traversability_estimation_amd import synth
+    rows, cols = 200, 170
+    elev = obstacle_map(synth, rows, cols, 500 + fp_cells, 10)
+    elev[90:93, 40:60] = np.nan
+    r = synth.benchmark_radius(3, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=fp_cells * res, fp_offset=off_cells * res)
+    g = oracle.geom(rows, cols, res, origin)
+    want = oracle.chain(g, op, elev)
+    want["traversability_footprint"] = oracle.footprint(g, op, elev, want)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, origin)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS + ("traversability_footprint",)}
+    assert_layers_match(got, want, layers=list(OUT_LAYERS) + ["traversability_footprint"], ctx=f"tie radius {fp_cells}+{off_cells} cells at {res} m")
+    fp = got["traversability_footprint"]
+    assert (fp == 0).sum() > 20 and ((fp > 0) & (fp < 1)).sum() > 1000
+
+
 _DENSE_LIST_SCRIPT = r"""
 import sys
 import numpy as np
@@ -245,12 +273,15 @@ O.build()
 capi.load()
 rows, cols, res = 260, 230, 0.05
 bad_total = 0
-for fp_cells, off_cells, boxes, origin in ((6, 3, 30, (0.0, 0.0)), (9, 4, 18, (1.5, -2.0)), (4, 1, 40, (0.0, 0.0))):
+for fp_cells, off_cells, boxes, origin in ((6, 3, 30, (0.0, 0.0)), (9, 4, 18, (1.5, -2.0)), (4, 1, 40, (0.0, 0.0)), (-5, -2, 30, (0.7, 0.3))):
+    tie = fp_cells < 0  # whole-cell radii: the cells on the circle are decided per centre
+    fp_cells, off_cells = abs(fp_cells), abs(off_cells)
     elev = synth.with_steps(synth.perlin_elevation(rows, cols, seed=40 + boxes, amplitude=0.12), boxes, seed=47 + boxes)
     elev[100:104, 60:75] = np.nan
     r = synth.benchmark_radius(3, res)
     op = O.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
-                          fp_radius=synth.benchmark_radius(fp_cells, res), fp_offset=synth.benchmark_radius(off_cells, res))
+                          fp_radius=fp_cells * res if tie else synth.benchmark_radius(fp_cells, res),
+                          fp_offset=off_cells * res if tie else synth.benchmark_radius(off_cells, res))
     g = O.geom(rows, cols, res, origin)
     want = O.chain(g, op, elev)
     fp = O.footprint(g, op, elev, want)
@@ -270,14 +301,15 @@ sys.exit(1 if bad_total else 0)
 
 
 def test_blocked_discs_one_per_lane():
-    """k_fp_blocked walks one disc per lane when the list is long for the launch (>= 8 entries per wavefront: 49 152
-    on an MI355X, more than a map the oracle finishes in seconds can hold).  TE_FB_BLOCKS_PER_CU=1 shrinks the launch to
-    256 wavefronts, so that the test maps take that path (the variable is read once per process: a process of its own).
-    Maps with borders on all sides (the bounds-checked loops) and an interior large enough for the scalar-offset ones."""
+    """k_fp_blocked walks one disc per lane when the list is long for the launch (>= 8 cells per wavefront: 49 152
+    on an MI355X, more than a map the oracle finishes in seconds can hold).  TE_FB_PATH=lane forces that walk and
+    TE_FB_BLOCKS_PER_CU=1 shrinks the launch to 256 wavefronts, so that the lanes of a group are filled (the variables
+    are read once per process: a process of its own).  Maps with borders on all sides (the bounds-checked loops) and an
+    interior large enough for the scalar-offset ones; the last case is a tie radius."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TE_FB_BLOCKS_PER_CU="1")
+    env = dict(os.environ, TE_FB_BLOCKS_PER_CU="1", TE_FB_PATH="lane")
     r = subprocess.run([sys.executable, "-c", _DENSE_LIST_SCRIPT, root], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
   const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * g.rows * g.cols;
   const int i0 = ((int)blockIdx.x + a.ti0) * MX, j0 = ((int)blockIdx.y + a.tj0) * MY;
+  // (the footprint pass's list of blocked cells starts empty: k_fp_slide4 / k_fp_blocked run after this kernel)
+  if (a.blocked_count && threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    a.blocked_count[0] = a.blocked_count[1] = 0u;
   // The three scores of this thread's MY/MBY cells: issued together with the tile loads, so that they
   // are in flight during the staging and the two LDS passes (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
   constexpr int NC = MY / MBY;
@@ -470,7 +473,6 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   }
   const int tid2 = threadIdx.y * MX + threadIdx.x;
   if (tid2 == 0) ntodo = 0;
-  if (tid2 == 0 && a.blocked_count && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *a.blocked_count = 0u;
   __syncthreads();
   fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;

@@ -22,6 +22,11 @@
 // (4096^2 with 3000 boxes: 1.12 ms in this kernel).  The list is filled in chunks of kF4Chunk entries a block reserves
 // with one atomic (one atomic per blocked row made 10^5 of them queue on one address: 1.6 ms); the unused tail of a
 // block's last chunk holds kF4NoCell.
+// TIE RADII (radius / resolution a whole number of cells -- the reference's own 0.45 m at 0.03 m): the cells exactly on
+// the circle belong to a disc or not as SpiralIterator::isInside() decides from rounded positions, per centre.  The
+// kernel (TIES = true, instantiated for the whole-cell shapes Q = R^2) slides the full shape, circle included, and every
+// row takes the rejected circle cells of its centre out again: one ring read and the reference's own test per cell
+// on the circle (12 at 15 cells).  k_fp_blocked applies the same test to the table entries that carry the tie flag.
 // Used when the host can bound the traversability values (layer written by the chain with non-negative weights);
 // otherwise, and for radii whose k would drop below 17, k_fp_slide3 serves.
 #include "te_internal.h"
@@ -50,8 +55,15 @@ struct F4Args {
   double rmin;      // inner radius: 0 makes every disc with an untraversable cell 0 (:694-704), no walk needed
   float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 24, scale = 2^k
   double inv_scale;    // 2^-k
+  // tie radii (see the header): the circle of a whole-cell radius R holds (+-R, 0), (0, +-R) and n_gen offsets with both
+  // parts non-zero (gen_tab: di & 0xff | (dj & 0xff) << 8); r2, ax, ay, res: what isInside() needs.  n_ties = 0 otherwise
+  int n_ties, n_gen;
+  const int* gen_tab;
+  double r2, ax, ay, res;
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
-  unsigned* blocked_count;  // ... and how many (reset by k_fp_mask, which runs before this kernel in every footprint pass)
+  unsigned* blocked_count;  // ... [0] how many entries are reserved, [1] how many hold a cell (k_fp_mask resets both: it runs
+                            // before this kernel in every footprint pass)
+  int chunk;                // entries a block reserves at a time: kF4Chunk, less for strips shorter than four rows
 };
 
 constexpr int f4_chunk_rows(int NR) {
@@ -61,7 +73,7 @@ constexpr int f4_chunk_rows(int NR) {
   return 1;
 }
 
-template <int Q>
+template <int Q, bool TIES>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves, kF4Waves))) void k_fp_slide4(F4Args a) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
@@ -99,6 +111,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   // the last block of a row of blocks is shifted left to end at the map edge: the columns it shares with its neighbour
   // are the neighbour's (one store, one list entry per cell)
   const bool own = icol >= bx * kLanes;
+  // TIES: the lanes for which isInside() rejects (icol + R, j) / (icol - R, j) -- the same for every j (dy = 0 exactly)
+  unsigned long long xfail_p = 0ull, xfail_m = 0ull;
+  if constexpr (TIES) {
+    const double xi = a.ax + a.res * (double)(-icol);  // cell_x (te_geom.h)
+    const double dxp = (a.ax + a.res * (double)(-(icol + R))) - xi, dxm = (a.ax + a.res * (double)(-(icol - R))) - xi;
+    xfail_p = __ballot(!(dxp * dxp + 0.0 <= a.r2) && icol + R < a.rows);
+    xfail_m = __ballot(!(dxm * dxm + 0.0 <= a.r2) && icol - R >= 0);
+  }
 
   // rows are loaded C steps before they are staged (a queue slot per unrolled position): with one step of lead the
   // wave waited for memory 38 % of its time (SQ_WAIT_ANY, profiles/r02_sq_counters.json)
@@ -167,6 +187,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   const double drmin = a.rmin;
   unsigned chunk_at = 0;  // my chunk of the list: next free entry ...
   int chunk_left = 0;     // ... and how many are left (uniform)
+  int listed_total = 0;   // cells this block has put onto the list
   auto fill_chunk = [&]() __attribute__((always_inline)) {
     for (int q = lane; q < chunk_left; q += kLanes) a.blocked_list[chunk_at + (unsigned)q] = kF4NoCell;
   };
@@ -179,9 +200,52 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
       rn = (float)(a.inv_scale / (double)nt);
     }
-    const unsigned T = X - (NU << 24);  // sum of the fixed-point traversabilities of the disc, exact
+    unsigned Xc = X, NUc = NU;
+    if constexpr (TIES) {
+      // the cells on the circle that isInside() rejects for this centre (grid_map_core SpiralIterator) leave the sum
+      // again; a rejected cell outside the map was never in it (0 in the ring, not counted in nt).
+      const int slot0 = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
+      auto wrap = [&](int sl) __attribute__((always_inline)) {
+        sl = sl >= NR ? sl - NR : sl;
+        return sl >= NR ? sl - NR : sl;
+      };
+      int nfail = 0;
+      auto take_out = [&](bool fail, unsigned wd) __attribute__((always_inline)) {
+        Xc -= fail ? wd : 0u;
+        NUc -= fail ? wd >> 24 : 0u;
+        nfail += fail ? 1 : 0;
+      };
+      // (+-R, 0): decided per lane before the march
+      const unsigned* crow = ring + wrap(slot0 + R) * W + lane + R;
+      take_out(((xfail_p >> lane) & 1ull) != 0ull, crow[R]);
+      take_out(((xfail_m >> lane) & 1ull) != 0ull, crow[-R]);
+      // (0, +-R): dx = 0 exactly, the same answer for every lane of the row
+      const double yj = a.ay + a.res * (double)(-j);  // cell_y
+#pragma unroll
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int jj = j + sgn * R;
+        if ((unsigned)jj < (unsigned)a.cols) {
+          const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+          if (!(0.0 + dy * dy <= a.r2)) take_out(true, ring[wrap(slot0 + R + sgn * R) * W + lane + R]);
+        }
+      }
+      // the others (3-4-5 radii: 5, 10, 13, 15 cells): the reference's test per cell
+      if (a.n_gen != 0) {
+        const double xi = a.ax + a.res * (double)(-icol);
+#pragma unroll 1
+        for (int t = 0; t < a.n_gen; ++t) {
+          const int e = a.gen_tab[t];
+          const int di = (int)(signed char)(e & 0xff), dj = (int)(signed char)((e >> 8) & 0xff);
+          const double dx = (a.ax + a.res * (double)(-(icol + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
+          const bool fail = !(dx * dx + dy * dy <= a.r2) && (unsigned)(icol + di) < (unsigned)a.rows && (unsigned)(j + dj) < (unsigned)a.cols;
+          take_out(fail, ring[wrap(slot0 + dj + R) * W + lane + R + di]);
+        }
+      }
+      if (__builtin_expect(__any(nfail != 0), 0)) rn = nfail ? (float)(a.inv_scale / (double)(nt - nfail)) : rn;
+    }
+    const unsigned T = Xc - (NUc << 24);  // sum of the fixed-point traversabilities of the disc, exact
     out = (float)T * rn;  // :732-735 no untraversable cell in the footprint: the mean (T < 2^29: the conversion is good to 2^-25)
-    const bool blocked = NU != 0;
+    const bool blocked = NUc != 0;
     skip = !own;
     if (__builtin_expect(__any(blocked), 0)) {
       if (drmin == 0.0) {
@@ -204,13 +268,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
           if (n > chunk_left) {
             fill_chunk();
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)kF4Chunk);
+            if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
             chunk_at = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            chunk_left = kF4Chunk;
+            chunk_left = a.chunk;
           }
           if (listed) a.blocked_list[chunk_at + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(mo + (size_t)j * a.rows + icol);
           chunk_at += (unsigned)n;
           chunk_left -= n;
+          listed_total += n;
         }
         skip = skip || listed;
       }
@@ -281,12 +346,15 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
     }
   }
   fill_chunk();
+  if (listed_total != 0 && lane == 0) atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
 }
 
 template <int Q>
-void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
+bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   F4Args a = a0;
   constexpr int R = Shape<Q>::R;
+  constexpr bool kWholeCell = R * R == Q;  // the shapes a tie radius can have (its circle passes through (R, 0))
+  if (a.n_ties != 0 && !kWholeCell) return false;
   constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 4;
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
   if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;
@@ -305,8 +373,17 @@ void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
   sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
+  a.chunk = sr >= 4 ? kF4Chunk : (sr * kLanes >= kF4Chunk / 2 ? kF4Chunk / 2 : kLanes);  // (a strip of one row lists at most 64 cells)
   const int nstrips = (H + sr - 1) / sr;
-  hipLaunchKernelGGL((k_fp_slide4<Q>), dim3((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz), dim3(kLanes), 0, s, a);
+  const dim3 grid((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz);
+  if constexpr (kWholeCell) {
+    if (a.n_ties != 0) {
+      hipLaunchKernelGGL((k_fp_slide4<Q, true>), grid, dim3(kLanes), 0, s, a);
+      return true;
+    }
+  }
+  hipLaunchKernelGGL((k_fp_slide4<Q, false>), grid, dim3(kLanes), 0, s, a);
+  return true;
 }
 
 }  // namespace
@@ -344,10 +421,9 @@ void launch_f4(const F4Args& a0, int batch, hipStream_t s) {
 bool TE_F4_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
   const F4Args& a = *static_cast<const F4Args*>(args);
   switch (Q) {
-#define X(q)                  \
-  case q:                     \
-    launch_f4<q>(a, batch, s); \
-    return true;
+#define X(q) \
+  case q:    \
+    return launch_f4<q>(a, batch, s);
     TE_F4_SHAPES(X)
 #undef X
     default:
@@ -367,7 +443,7 @@ namespace {
 
 constexpr int kFBTab = 4;    // chunks of 64 spiral entries a lane keeps in registers (256 entries: radii up to 8 cells)
 constexpr int kFBTrip = 8;   // entries per trip of the per-lane walks, their loads issued together
-constexpr int kFBDense = 8;  // list entries per wavefront from which every lane walks a disc of its own
+constexpr int kFBDense = 8;  // cells per wavefront of the launch from which every lane walks a disc of its own
 static_assert(kMaxSpiral % kFBTrip == 0, "k_fp_blocked reads whole trips of the table");
 
 struct FBArgs {
@@ -376,16 +452,26 @@ struct FBArgs {
   float* footprint;
   const unsigned* list;
   const unsigned* count;
-  const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16 (kMaxSpiral words)
+  const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16 | tie << 24 (kMaxSpiral words)
   int n_spiral, rows, cols, reach;
   unsigned map_cells;
   double rmin, rmax, def, res;
+  double r2, ax, ay;  // SpiralIterator::isInside for the entries on the circle itself (tie flag)
+  int path;           // 0: by the length of the list; 1: one disc per wavefront; 2: one disc per lane (TE_FB_PATH, tests)
 };
+
+// SpiralIterator::isInside (grid_map_core) for the cell (i + di, j + dj) of the disc around (i, j): cell centres as
+// cell_x / cell_y (te_geom.h) compute them
+__device__ __forceinline__ bool fb_on_circle_inside(const FBArgs& a, int i, int j, int di, int dj) {
+  const double dx = (a.ax + a.res * (double)(-(i + di))) - (a.ax + a.res * (double)(-i));
+  const double dy = (a.ay + a.res * (double)(-(j + dj))) - (a.ay + a.res * (double)(-j));
+  return dx * dx + dy * dy <= a.r2;
+}
 
 // isTraversable(center, radiusMax, traversability, radiusMin) :654-746 for the cells on the list, straight from the
 // layers (L2), in double like the reference.  A wavefront takes `group` consecutive list entries per trip, as few as
 // keep every wavefront of the launch busy, and there are two ways to walk the SpiralIterator order (host-built table):
-//   short list (a lone kerb: group < kFBDense) -- ONE DISC PER WAVEFRONT AT A TIME: lane q takes entry 64 ch + q (the
+//   short list (a lone kerb: fewer than kFBDense cells per wavefront of the launch) -- ONE DISC PER WAVEFRONT AT A TIME: lane q takes entry 64 ch + q (the
 //     first kFBTab chunks stay in registers), a ballot finds the first untraversable entry, the sum of the cells
 //     before it -- needed only beyond the inner radius -- is one reduction.  Two or three dependent loads per disc:
 //     three boxes on a 4096^2 map take 7 us (50 us with one disc per lane: 15 dependent trips);
@@ -394,12 +480,13 @@ struct FBArgs {
 //     inner radius, for the sum of the cells before it in the iterator's order.  About 25 instructions per disc; the
 //     wave-wide walk needs 250, and 3 million discs (3000 boxes) took it 1.5 ms.
 __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
-  const unsigned n = *a.count;
+  const unsigned n = a.count[0], n_cells = a.count[1];  // entries reserved (some hold kF4NoCell) / cells
   if (n == 0) return;
   const int lane = threadIdx.x;
   const unsigned nwaves = gridDim.x;
   unsigned group = 1;
   while (group < (unsigned)kLanes && group * nwaves < n) group *= 2;
+  const bool per_lane = a.path ? a.path == 2 : n_cells >= (unsigned)kFBDense * nwaves;
   // my entries of the table, and their offsets from the top left corner of the disc's bounding square
   unsigned tw[kFBTab];
   int toff[kFBTab];
@@ -424,7 +511,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
     const unsigned mapv = cellv / a.map_cells, remv = cellv - mapv * a.map_cells;
     const unsigned jv = remv / (unsigned)a.rows, iv = remv - jv * (unsigned)a.rows;
     float myout = 0.0f;
-    if (group >= (unsigned)kFBDense) {
+    if (per_lane) {
       // ---- one disc per lane
       const bool act = mycell != kF4NoCell;
       const int i = (int)iv, j = (int)jv;
@@ -449,6 +536,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
             const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
             in[q] = valid;
             if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
+            if ((w >> 24) != 0u) in[q] = in[q] && fb_on_circle_inside(a, i, j, di, dj);  // (uniform branch)
             u[q] = kFast ? up[dj * a.rows + di] : up[in[q] ? dj * a.rows + di : 0];
           }
 #pragma unroll
@@ -485,6 +573,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
               const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
               in[q] = k0 + q < kend;
               if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
+              if ((w >> 24) != 0u) in[q] = in[q] && fb_on_circle_inside(a, i, j, di, dj);
               t[q] = kFast ? tp[dj * a.rows + di] : tp[in[q] ? dj * a.rows + di : 0];
             }
 #pragma unroll
@@ -530,6 +619,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
           const int ii = i + (int)(signed char)(w & 0xffu), jj = j + (int)(signed char)((w >> 8) & 0xffu);
           in = in && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
         }
+        if (in && (w >> 24) != 0u) in = fb_on_circle_inside(a, i, j, (int)(signed char)(w & 0xffu), (int)(signed char)((w >> 8) & 0xffu));
         const int o = in ? off : ctr;
         const uint8_t u = ub[o];
         const float t = tb[o];
@@ -603,6 +693,11 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
   a.rmax = p.rmax;
   a.def = p.def;
   a.res = g.res;
+  a.r2 = p.fp_disc.r2;
+  a.ax = g.ax;
+  a.ay = g.ay;
+  static const char* path_env = getenv("TE_FB_PATH");  // "wave" / "lane": measurement aid, and how the tests reach both walks
+  a.path = path_env ? (path_env[0] == 'l' ? 2 : 1) : 0;
   static const int per_cu = getenv("TE_FB_BLOCKS_PER_CU") ? atoi(getenv("TE_FB_BLOCKS_PER_CU")) : 24;  // 6 waves per SIMD: 77 registers (measurement aid)
   hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)((per_cu > 0 ? per_cu : 24) * device_cus())), dim3(kLanes), 0, s, a);
 }
@@ -614,8 +709,18 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
                       double tcap, hipStream_t s, const Region* region, bool finish) {
   const Disc& d = p.fp_disc;
   static const bool off = getenv("TE_NO_F4") != nullptr;
-  if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
-    return false;
+  static const bool no_ties = getenv("TE_F4_NO_TIES") != nullptr;  // measurement aid: tie radii to the general kernel as before
+  // The shape the kernel slides: the disc itself, or for a tie radius the disc with its circle (whole-cell radii only:
+  // every cell on the circle has the norm reach^2, and the runs plus the circle are the shape reach^2).
+  int shape = d.Q, R = d.R;
+  if (d.n_ties != 0) {
+    R = p.reach;
+    shape = R * R;
+    if (no_ties) return false;
+    for (int t = 0; t < d.n_ties; ++t)
+      if ((int)d.tie_di[t] * d.tie_di[t] + (int)d.tie_dj[t] * d.tie_dj[t] != shape) return false;
+  }
+  if (off || shape < 1 || R < 1 || p.reach != R || g.rows < kLanes || g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
   // 32-bit list entries, and room for every block's unfinished chunk
   if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch + (double)f4_list_slack(g.rows, g.batch) > (double)L.fp_blocked_cap)
@@ -625,7 +730,7 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
   const double cap = (tcap > p.def ? tcap : p.def) * (1.0 + 1e-6) + 1e-12;
   int k = 23;
-  while (k >= 0 && (double)(2 * d.R + 1) * (cap * ldexp(1.0, k) + 1.0) >= 16777216.0) --k;
+  while (k >= 0 && (double)(2 * R + 1) * (cap * ldexp(1.0, k) + 1.0) >= 16777216.0) --k;
   if (k < 17) return false;  // rounding each value to 2^-17 could show at the 1e-5 level: the double kernel serves
   F4Args a;
   a.trav = L.trav;
@@ -642,17 +747,25 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.j_hi = region ? region->j1 : g.cols;
   a.map = region ? region->map : -1;
   if (a.j_hi <= a.j_lo || a.nbx_l <= 0) return true;
-  a.gtab = clip_table;
+  a.gtab = d.n_ties ? clip_table + kFpClipInts : clip_table;  // (ties: the table of the shape with its circle)
   a.rmin = p.rmin;
+  a.n_ties = d.n_ties;
+  a.n_gen = 0;
+  for (int t = 0; t < d.n_ties; ++t) a.n_gen += (d.tie_di[t] != 0 && d.tie_dj[t] != 0) ? 1 : 0;
+  a.gen_tab = clip_table + 2 * kFpClipInts;  // (te_set_params put them there)
+  a.r2 = d.r2;
+  a.ax = g.ax;
+  a.ay = g.ay;
+  a.res = g.res;
   a.def = (float)p.def;
   a.scale = (float)ldexp(1.0, k);
   a.inv_scale = ldexp(1.0, -k);
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
-  bool launched = f4_launch_part0(d.Q, &a, g.batch, s);
+  bool launched = f4_launch_part0(shape, &a, g.batch, s);
 #if TE_PARTS > 1
-  launched = launched || f4_launch_part1(d.Q, &a, g.batch, s) || f4_launch_part2(d.Q, &a, g.batch, s) || f4_launch_part3(d.Q, &a, g.batch, s) ||
-             f4_launch_part4(d.Q, &a, g.batch, s);
+  launched = launched || f4_launch_part1(shape, &a, g.batch, s) || f4_launch_part2(shape, &a, g.batch, s) || f4_launch_part3(shape, &a, g.batch, s) ||
+             f4_launch_part4(shape, &a, g.batch, s);
 #endif
   if (launched && finish) footprint_blocked4(g, p, L, spiral_table, s);
   return launched;

@@ -215,6 +215,8 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
 // (tcap < 0: no bound known)
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       double tcap, hipStream_t s, const Region* region = nullptr, bool finish = true);
+constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint disc (reach <= 20); a second one follows it for a tie
+                                           // radius: the disc with the cells on its circle (k_fp_slide4<Q, true>)
 constexpr int kF4Chunk = 256;              // entries of the list a block reserves at a time
 constexpr unsigned kF4NoCell = 0xffffffffu;  // an unused entry
 size_t f4_list_slack(int rows, int batch);

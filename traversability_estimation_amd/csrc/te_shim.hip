@@ -320,7 +320,25 @@ int rebuild_footprint_tables_impl(te_ctx* c) {
       packed[k] = ((uint32_t)tab[4 * k] & 0xffu) | (((uint32_t)tab[4 * k + 1] & 0xffu) << 8) | (((uint32_t)tab[4 * k + 2] & 0xffu) << 16) |
                   (((uint32_t)tab[4 * k + 3] & 0xffu) << 24);
     HIP_TRY(hipMemcpyAsync(c->d_spiral + 4 * kMaxSpiral, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if (!c->fp_clip_table) HIP_TRY(hipMalloc((void**)&c->fp_clip_table, sizeof(int) * 6 * 41 * 41));
+    if (!c->fp_clip_table) HIP_TRY(hipMalloc((void**)&c->fp_clip_table, sizeof(int) * (2 * fast::kFpClipInts + kMaxTies)));
+    std::vector<int> ctab_full;
+    int gen_tab[kMaxTies];
+    if (d.n_ties) {  // the disc with the cells on its circle (fixed-point sliding sum of a tie radius, te_footprint4.hip)
+      Disc full = d;
+      for (int t = 0; t < d.n_ties; ++t) {
+        const int ai = abs((int)d.tie_di[t]), aj = abs((int)d.tie_dj[t]);
+        if (full.hw[aj] < ai) full.hw[aj] = ai;
+        if (full.R < aj) full.R = aj;
+      }
+      ctab_full.resize(ctab.size());
+      fast::build_clip_table(full, f.reach, ctab_full.data());
+      HIP_TRY(hipMemcpyAsync(c->fp_clip_table + fast::kFpClipInts, ctab_full.data(), ctab_full.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      // ... and the offsets on the circle with both parts non-zero, packed (the kernel handles (+-R, 0) and (0, +-R) itself)
+      int n_gen = 0;
+      for (int t = 0; t < d.n_ties; ++t)
+        if (d.tie_di[t] != 0 && d.tie_dj[t] != 0) gen_tab[n_gen++] = ((int)d.tie_di[t] & 0xff) | (((int)d.tie_dj[t] & 0xff) << 8);
+      if (n_gen) HIP_TRY(hipMemcpyAsync(c->fp_clip_table + 2 * fast::kFpClipInts, gen_tab, n_gen * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(c->d_spiral, tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->fp_clip_table, ctab.data(), ctab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
