@@ -262,6 +262,34 @@ def test_fixed_point_footprint_at_tie_radii(capi, oracle, res, fp_cells, off_cel
     assert (fp == 0).sum() > 20 and ((fp > 0) & (fp < 1)).sum() > 1000
 
 
+@pytest.mark.parametrize("res,cells,holes,origin", [(0.05, 3, False, (1.5, -2.0)), (0.03, 5, False, (0.0, 0.0)), (0.1, 5, True, (-3.17, 8.4)),
+                                                    (0.04, 9, False, (0.35, 0.05)), (0.05, 10, True, (12.3, -7.7)), (0.02, 2, False, (0.0, 0.0))])
+def test_chain_at_tie_radii(capi, oracle, res, cells, holes, origin):
+    """normals / roughness / step radii a whole number of cells: CircleIterator::isInside decides the cells exactly on
+    the circle from rounded positions, centre by centre.  k_normals3's TIES march slides the shape with its circle and
+    takes the rejected cells out of the moments row by row (5 and 10 cells: the 3-4-5 offsets as well); a strip with
+    invalid cells goes to the fix-up pass whole.  Borders on all sides, map origins that move the rounding around."""
+    from traversability_estimation_amd import synth
+    rows, cols = 210, 180
+    elev = obstacle_map(synth, rows, cols, 700 + cells, 8)
+    if holes:
+        elev[90:93, 40:60] = np.nan
+        elev[150, 100] = np.nan
+    r = cells * res
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
+                               fp_radius=synth.benchmark_radius(4, res), fp_offset=synth.benchmark_radius(2, res))
+    g = oracle.geom(rows, cols, res, origin)
+    want = oracle.chain(g, op, elev)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, origin)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(0)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+    assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx=f"chain at {cells} cells exactly, res {res}")
+
+
 _DENSE_LIST_SCRIPT = r"""
 import sys
 import numpy as np

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--holes", type=float, default=0.0)
     ap.add_argument("--boxes", type=int, default=0, help="raised / lowered rectangles of 4..40 cells a side (kerbs, crates): untraversable cells")
     ap.add_argument("--exact-cells", action="store_true", help="footprint radius and offset exactly 6 and 3 cells (a tie radius: cells on the circle decided per centre)")
+    ap.add_argument("--exact-chain", action="store_true", help="normals / roughness / step radii exactly --radius-cells cells (tie radii: the generic kernels)")
     ap.add_argument("--loops", type=str, default="", help="comma-separated K: host-timed loops of K launches + sync")
     ap.add_argument("--tag", type=str, default="")
     a = ap.parse_args()
@@ -46,6 +47,9 @@ def main():
                             fp_radius=synth.benchmark_radius(6.0, a.res), fp_offset=synth.benchmark_radius(3.0, a.res))
     if a.exact_cells:
         p = capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=6.0 * a.res, fp_offset=3.0 * a.res)
+    if a.exact_chain:
+        rr = a.radius_cells * a.res
+        p = capi.default_params(normals_radius=rr, rough_radius=rr, step_radius1=rr, step_radius2=rr, fp_radius=p.fp_radius, fp_offset=p.fp_offset)
     elevs = [synth.perlin_elevation(n, n, seed=1235 + b) for b in range(B)]
     if 0 < a.holes < 0.5:
         elevs = [synth.with_holes(e, a.holes, seed=99 + b) for b, e in enumerate(elevs)]

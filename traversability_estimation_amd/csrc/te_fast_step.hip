@@ -7,6 +7,12 @@
 // bit-identical to the reference.  Invalid cells are staged as quiet NaN and v_max/v_min ignore them,
 // which is exactly the reference's isValid() skip; cells outside the map are staged as NaN too
 // (CircleIterator clamps at the border).
+// TIE RADII (radius a whole number R of cells): CircleIterator::isInside decides the cells exactly on the circle from
+// rounded positions, centre by centre.  Maximum, minimum and count are folds, so the marching kernels run with the
+// shape WITHOUT its circle (RAW = true: they store the running maximum / minimum, or maximum / count, instead of the
+// result) and k_step_height_ties / k_step_score_ties fold the accepted circle cells in, cell by cell, and finish with
+// the kernels' own arithmetic.  One scratch layer (the minimum, then the count).
+#include "te_geom.h"
 #include "te_march.h"
 
 #include <cstdlib>
@@ -23,10 +29,10 @@ namespace {
 #endif
 constexpr int kHeightWaves = 3, kScoreWaves = TE_SCORE_WAVES;
 
-template <int Q>
+template <int Q, bool RAW = false>
 __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g, const float* __restrict__ elev,
                                                                            float* __restrict__ sh, Region rg,
-                                                                           int periods) {
+                                                                           int periods, float* __restrict__ sh_min = nullptr) {
   using S = Shape<Q>;
   using T = Strip<Q>;
   constexpr int R = S::R, P = S::P, W = T::W;
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
     const int p_lo = js - (rbase - R) > 0 ? js - (rbase - R) : 0, p_hi = jstop - (rbase - R) < P ? jstop - (rbase - R) : P;
     const unsigned emask = p_hi > p_lo ? (p_hi >= 32 ? ~0u : (1u << p_hi) - 1u) & ~((1u << p_lo) - 1u) : 0u;
     gfloat* op = (gfloat*)(sh + mo + ((long long)(rbase - R) * g.rows + i0));  // output row of period row 0 (may lie above the strip: never stored)
+    gfloat* op_min = RAW ? (gfloat*)(sh_min + mo + ((long long)(rbase - R) * g.rows + i0)) : nullptr;
     // Two rows per pass: every pending output takes the run values of both rows with ONE v_max3/v_min3.
     // Row p is at offset e1 (slot = (p+e1) mod P) and row p+1 at e1-1 of the same output; the output that
     // completes with row p (e1 == -R) is emitted in between and its slot restarts with row p+1 (offset +R).
@@ -85,8 +92,13 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
         // StepFilter.cpp:113 only valid centres; :143 double difference stored as float
         // (float)((double)vmx - (double)vmn) == vmx - vmn in float32: the double difference of two floats rounded to
         // float is the correctly rounded float difference (53 >= 2 * 24 + 2 bits: double rounding is innocuous)
-        const float out = (z0 == z0) ? __fsub_rn(vmx, vmn) : qnan();
-        op[(p & 1) ? g.rows + lane : lane] = out;
+        if constexpr (RAW) {  // the fold over the circle cells comes first (k_step_height_ties)
+          op[(p & 1) ? g.rows + lane : lane] = vmx;
+          op_min[(p & 1) ? g.rows + lane : lane] = vmn;
+        } else {
+          const float out = (z0 == z0) ? __fsub_rn(vmx, vmn) : qnan();
+          op[(p & 1) ? g.rows + lane : lane] = out;
+        }
       }
     };
     static_for<(P + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
@@ -130,16 +142,17 @@ __global__ __launch_bounds__(kLanes, kHeightWaves) void k_step_height_fast(Geo g
         amax[so] = amin[so] = qnan();
       }
       op += 2 * (long long)g.rows;
+      if constexpr (RAW) op_min += 2 * (long long)g.rows;
     });
   }
 }
 
 // crit_lo = largest float <= critical_value, so that for a float s:  (double)s > crit  <=>  s > crit_lo.
-template <int Q>
+template <int Q, bool RAW = false>
 __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, double crit, double rcrit, float crit_lo, int ncrit,
                                                                          const float* __restrict__ shl,
                                                                          float* __restrict__ out, Region rg,
-                                                                         int periods) {
+                                                                         int periods, float* __restrict__ out_count = nullptr) {
   using S = Shape<Q>;
   using T = Strip<Q>;
   constexpr int R = S::R, P = S::P, W = T::W;
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
     const int p_lo = js - (rbase - R) > 0 ? js - (rbase - R) : 0, p_hi = jstop - (rbase - R) < P ? jstop - (rbase - R) : P;
     const unsigned emask = p_hi > p_lo ? (p_hi >= 32 ? ~0u : (1u << p_hi) - 1u) & ~((1u << p_lo) - 1u) : 0u;
     gfloat* op = (gfloat*)(out + mo + ((long long)(rbase - R) * g.rows + i0));
+    gfloat* op_cnt = RAW ? (gfloat*)(out_count + mo + ((long long)(rbase - R) * g.rows + i0)) : nullptr;
     // One row = 2R+1 staged cells {value, flag}; the reads of the NEXT row are issued before the current row is
     // reduced (two row buffers alternate), so the LDS latency is covered by the reduction and the scatter.
     auto read_row = [&](int p, float2 (&raw)[2 * R + 1]) __attribute__((always_inline)) {
@@ -201,6 +215,13 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
       });
     };
     auto emit = [&](int p, float m, int count) __attribute__((always_inline)) {
+      if constexpr (RAW) {  // the fold over the circle cells comes first (k_step_score_ties)
+        if ((emask >> p) & 1u) {
+          op[(p & 1) ? g.rows + lane : lane] = m;
+          op_cnt[(p & 1) ? g.rows + lane : lane] = __int_as_float(count);
+        }
+        return;
+      }
       if ((emask >> p) & 1u) {
         // isValid: at least one valid step_height in the window (StepFilter.cpp:161), else the cell stays NaN.
         // nCells == 0: step = min(stepMax, 0 * stepMax) = 0 (:169-170) -> 1 - 0 / crit = 1 (0 if crit == 0: "0 < 0" fails);
@@ -268,8 +289,70 @@ __global__ __launch_bounds__(kLanes, kScoreWaves) void k_step_score_fast(Geo g, 
         cnt[so] = 0;
       }
       op += 2 * (long long)g.rows;
+      if constexpr (RAW) op_cnt += 2 * (long long)g.rows;
     });
   }
+}
+
+// ---- tie radii: the accepted circle cells folded in, one cell per thread ------------------------------------------
+struct TieArgs {
+  int n_ties;
+  int8_t di[kMaxTies], dj[kMaxTies];
+  double r2;
+};
+
+// CircleIterator::isInside for the cell (i + di, j + dj) of the circle around (i, j), cell centres as te_geom.h has them
+__device__ __forceinline__ bool tie_inside(const Geo& g, const TieArgs& t, int i, int j, int k) {
+  const double dx = cell_x(g, i + t.di[k]) - cell_x(g, i), dy = cell_y(g, j + t.dj[k]) - cell_y(g, j);
+  return dx * dx + dy * dy <= t.r2;
+}
+
+// StepFilter.cpp:112-144 finished: sh holds the maximum, sh_min the minimum over the valid cells of the disc without its circle
+__global__ __launch_bounds__(256) void k_step_height_ties(Geo g, TieArgs t, const float* __restrict__ elev, float* __restrict__ sh,
+                                                          const float* __restrict__ sh_min, Region rg) {
+  const int i = rg.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = rg.j0 + (int)blockIdx.y;
+  if (i >= rg.i1) return;
+  const size_t mo = (size_t)(rg.map >= 0 ? rg.map : (int)blockIdx.z) * g.rows * g.cols;
+  const size_t o = mo + (size_t)j * g.rows + i;
+  float vmx = sh[o], vmn = sh_min[o];
+  for (int k = 0; k < t.n_ties; ++k) {
+    const int ii = i + t.di[k], jj = j + t.dj[k];
+    if ((unsigned)ii >= (unsigned)g.rows || (unsigned)jj >= (unsigned)g.cols || !tie_inside(g, t, i, j, k)) continue;
+    const float z = elev[mo + (size_t)jj * g.rows + ii];
+    if (!__builtin_isfinite(z)) continue;
+    vmx = fmaxf(vmx, z);  // (NaN: no valid cell so far)
+    vmn = fminf(vmn, z);
+  }
+  const float z0 = elev[o];
+  sh[o] = __builtin_isfinite(z0) ? __fsub_rn(vmx, vmn) : qnan();  // as k_step_height_fast's emit
+}
+
+// StepFilter.cpp:147-178 finished: out holds the maximum of the valid step heights, cnt how many exceed the critical value
+__global__ __launch_bounds__(256) void k_step_score_ties(Geo g, TieArgs t, double crit, float crit_lo, int ncrit, const float* __restrict__ shl,
+                                                         float* __restrict__ out, const float* __restrict__ cnt, Region rg) {
+  const int i = rg.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = rg.j0 + (int)blockIdx.y;
+  if (i >= rg.i1) return;
+  const size_t mo = (size_t)(rg.map >= 0 ? rg.map : (int)blockIdx.z) * g.rows * g.cols;
+  const size_t o = mo + (size_t)j * g.rows + i;
+  float m = out[o];
+  int count = __float_as_int(cnt[o]);
+  for (int k = 0; k < t.n_ties; ++k) {
+    const int ii = i + t.di[k], jj = j + t.dj[k];
+    if ((unsigned)ii >= (unsigned)g.rows || (unsigned)jj >= (unsigned)g.cols || !tie_inside(g, t, i, j, k)) continue;
+    const float h = shl[mo + (size_t)jj * g.rows + ii];
+    if (!__builtin_isfinite(h)) continue;
+    m = fmaxf(m, h);
+    count += h > crit_lo ? 1 : 0;
+  }
+  // (k_step_score_fast's emit, with the division it takes from a table)
+  float res = count == 0 ? (0.0 < crit ? 1.0f : 0.0f) : 0.0f;
+  if (count > 0 && count < ncrit) {
+    const double sm = (double)(m > 0.0f ? m : 0.0f);               // stepMax starts at 0.0 (:149)
+    const double a1 = ((double)count / (double)ncrit) * sm;         // nCells / nCellCritical_ * stepMax (:169)
+    const double step = sm < a1 ? sm : a1;                          // :170
+    res = step < crit ? (float)(1.0 - step / crit) : 0.0f;
+  }
+  out[o] = (m == m) ? res : qnan();
 }
 
 // resident wave slots of the device for a kernel compiled for `waves` waves per SIMD
@@ -278,23 +361,67 @@ long wave_slots(int waves) {
   return 4L * device_cus() * (ov > 0 ? ov : waves);
 }
 
+// the shapes a whole-cell radius of 2 .. 10 cells leaves without its circle (te_march.h has them all): only these exist as RAW kernels
+constexpr bool tie_free_part(int Q) { return Q == 2 || Q == 8 || Q == 13 || Q == 20 || Q == 34 || Q == 45 || Q == 61 || Q == 80 || Q == 98; }
+
 template <int Q>
-void launch_height(const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
+bool launch_height(const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s, float* sh_min = nullptr) {
   using T = Strip<Q>;
   const unsigned nx = (unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), nz = (unsigned)(r.map >= 0 ? 1 : g.batch);
   const int periods = plan_periods(T::P, T::R, r.j1 - r.j0, (long)nx * nz, wave_slots(kHeightWaves));
   dim3 grid(nx, (unsigned)((r.j1 - r.j0 + T::out_rows(periods) - 1) / T::out_rows(periods)), nz);
-  hipLaunchKernelGGL(k_step_height_fast<Q>, grid, dim3(kLanes), 0, s, g, elev, sh, r, periods);
+  if (sh_min) {
+    if constexpr (tie_free_part(Q)) {
+      hipLaunchKernelGGL((k_step_height_fast<Q, true>), grid, dim3(kLanes), 0, s, g, elev, sh, r, periods, sh_min);
+      return true;
+    }
+    return false;
+  }
+  hipLaunchKernelGGL((k_step_height_fast<Q, false>), grid, dim3(kLanes), 0, s, g, elev, sh, r, periods, (float*)nullptr);
+  return true;
 }
 
 template <int Q>
-void launch_score(const Geo& g, double crit, float crit_lo, int ncrit, const float* sh, float* out, const Region& r,
-                  hipStream_t s) {
+bool launch_score(const Geo& g, double crit, float crit_lo, int ncrit, const float* sh, float* out, const Region& r,
+                  hipStream_t s, float* out_count = nullptr) {
   using T = Strip<Q>;
   const unsigned nx = (unsigned)((r.i1 - r.i0 + kLanes - 1) / kLanes), nz = (unsigned)(r.map >= 0 ? 1 : g.batch);
   const int periods = plan_periods(T::P, T::R, r.j1 - r.j0, (long)nx * nz, wave_slots(kScoreWaves));
   dim3 grid(nx, (unsigned)((r.j1 - r.j0 + T::out_rows(periods) - 1) / T::out_rows(periods)), nz);
-  hipLaunchKernelGGL(k_step_score_fast<Q>, grid, dim3(kLanes), 0, s, g, crit, 1.0 / crit, crit_lo, ncrit, sh, out, r, periods);
+  if (out_count) {
+    if constexpr (tie_free_part(Q)) {
+      hipLaunchKernelGGL((k_step_score_fast<Q, true>), grid, dim3(kLanes), 0, s, g, crit, 1.0 / crit, crit_lo, ncrit, sh, out, r, periods, out_count);
+      return true;
+    }
+    return false;
+  }
+  hipLaunchKernelGGL((k_step_score_fast<Q, false>), grid, dim3(kLanes), 0, s, g, crit, 1.0 / crit, crit_lo, ncrit, sh, out, r, periods, (float*)nullptr);
+  return true;
+}
+
+// the shape of a tie disc without its circle (largest norm in its runs), its ties as kernel arguments; false: not a
+// whole-cell radius this file serves
+bool tie_disc(const Disc& d, int* q_free, TieArgs* t) {
+  if (d.n_ties == 0 || d.n_ties > kMaxTies || d.R < 1) return false;
+  int q = 0;
+  for (int b = 0; b <= d.R; ++b)
+    if (d.hw[b] >= 0 && d.hw[b] * d.hw[b] + b * b > q) q = d.hw[b] * d.hw[b] + b * b;
+  const int n2 = d.reach * d.reach;
+  for (int k = 0; k < d.n_ties; ++k)
+    if ((int)d.tie_di[k] * d.tie_di[k] + (int)d.tie_dj[k] * d.tie_dj[k] != n2) return false;
+  if (!tie_free_part(q)) return false;
+  *q_free = q;
+  t->n_ties = d.n_ties;
+  for (int k = 0; k < kMaxTies; ++k) {
+    t->di[k] = k < d.n_ties ? d.tie_di[k] : 0;
+    t->dj[k] = k < d.n_ties ? d.tie_dj[k] : 0;
+  }
+  t->r2 = d.r2;
+  return true;
+}
+
+dim3 cell_grid(const Geo& g, const Region& r) {
+  return dim3((unsigned)((r.i1 - r.i0 + 255) / 256), (unsigned)(r.j1 - r.j0), (unsigned)(r.map >= 0 ? 1 : g.batch));
 }
 
 }  // namespace
@@ -304,13 +431,34 @@ bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const R
   switch (Q) {
 #define X(q) \
   case q:    \
-    launch_height<q>(g, elev, sh, r, s); \
-    return true;
+    return launch_height<q>(g, elev, sh, r, s);
     TE_DISC_SHAPES(X)
 #undef X
     default:
       return false;
   }
+}
+
+// a tie radius (see the header); scratch: one float per cell of the layer
+bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh, float* scratch, const Region& r, hipStream_t s) {
+  static const bool off = getenv("TE_STEP_NO_TIES") != nullptr;  // measurement aid: tie radii to the generic kernels as before
+  int q = 0;
+  TieArgs t;
+  if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
+  bool ok = false;
+  switch (q) {
+#define X(q_) \
+  case q_:    \
+    ok = launch_height<q_>(g, elev, sh, r, s, scratch); \
+    break;
+    TE_DISC_SHAPES(X)
+#undef X
+    default:
+      break;
+  }
+  if (!ok) return false;
+  hipLaunchKernelGGL(k_step_height_ties, cell_grid(g, r), dim3(256), 0, s, g, t, elev, sh, (const float*)scratch, r);
+  return true;
 }
 
 bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
@@ -322,13 +470,36 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
   switch (Q) {
 #define X(q) \
   case q:    \
-    launch_score<q>(g, crit, lo, ncrit, sh, out, r, s); \
-    return true;
+    return launch_score<q>(g, crit, lo, ncrit, sh, out, r, s);
     TE_DISC_SHAPES(X)
 #undef X
     default:
       return false;
   }
+}
+
+bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const float* sh, float* out, float* scratch, const Region& r,
+                     hipStream_t s) {
+  static const bool off = getenv("TE_STEP_NO_TIES") != nullptr;
+  int q = 0;
+  TieArgs t;
+  if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
+  float lo = (float)crit;
+  if ((double)lo > crit) lo = nextafterf(lo, -INFINITY);
+  bool ok = false;
+  switch (q) {
+#define X(q_) \
+  case q_:    \
+    ok = launch_score<q_>(g, crit, lo, ncrit, sh, out, r, s, scratch); \
+    break;
+    TE_DISC_SHAPES(X)
+#undef X
+    default:
+      break;
+  }
+  if (!ok) return false;
+  hipLaunchKernelGGL(k_step_score_ties, cell_grid(g, r), dim3(256), 0, s, g, t, crit, lo, ncrit, sh, out, (const float*)scratch, r);
+  return true;
 }
 
 }  // namespace fast

@@ -79,6 +79,7 @@ struct Layers {
   float* rough_fp;
   float* step_height;  // temp layer of StepFilter (never leaves the device)
   uint8_t* untrav;     // !isTraversableForFilters per cell
+  float* tie_scratch;          // one float per cell: the step filter at a tie radius (te_fast_step.hip); nullptr: not allocated
   unsigned* fp_blocked;        // k_fp_slide4's list of cells whose disc holds an untraversable cell (one entry per cell at most) ...
   unsigned* fp_blocked_count;  // ... and its length (k_fp_mask resets it)
   size_t fp_blocked_cap;       // entries the list holds (cells + fast::f4_list_slack)
@@ -196,6 +197,11 @@ namespace fast {
 bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s);
 bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
                      hipStream_t s);
+// ... at a tie radius (whole-cell radii of 2 .. 10 cells): the marching kernels on the shape without its circle, then the
+// accepted circle cells folded in per cell; scratch: one float per cell of the layer (Layers::tie_scratch)
+bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh, float* scratch, const Region& r, hipStream_t s);
+bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const float* sh, float* out, float* scratch, const Region& r,
+                     hipStream_t s);
 // normals + slope + roughness (same disc for normals and roughness, positive axis z); with `combine`
 // the traversability layer is written too (the step layer must be complete).
 // *combined tells whether it did (the k_normals3 path leaves the combine to the caller).
@@ -215,6 +221,8 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
 // (tcap < 0: no bound known)
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       double tcap, hipStream_t s, const Region* region = nullptr, bool finish = true);
+constexpr int kClipInts = 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1);  // one clip table of the normals disc; for a tie radius the
+                                                                                      // table of the disc with its circle follows, then the packed offsets
 constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint disc (reach <= 20); a second one follows it for a tie
                                            // radius: the disc with the cells on its circle (k_fp_slide4<Q, true>)
 constexpr int kF4Chunk = 256;              // entries of the list a block reserves at a time

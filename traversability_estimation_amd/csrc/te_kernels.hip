@@ -504,10 +504,12 @@ hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, in
     hipLaunchKernelGGL(k_slope_from_nz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, p.slope_crit, L.nz,
                        L.slope);
   } else if (filter == TE_FILTER_STEP) {
-    if (!(use_fast && fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r, stream)))
+    if (!(use_fast && (fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r, stream) ||
+                       fast::step_height_ties(p.step1, g, L.elev, L.step_height, L.tie_scratch, r, stream))))
       hipLaunchKernelGGL(k_step_height, tile_grid(g, r), blk, tile_bytes(p.step1.reach), stream, g, p.step1, L.elev,
                          L.step_height, r);
-    if (!(use_fast && fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r, stream)))
+    if (!(use_fast && (fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r, stream) ||
+                       fast::step_score_ties(p.step2, g, p.step_crit, p.step_ncrit, L.step_height, L.step, L.tie_scratch, r, stream))))
       hipLaunchKernelGGL(k_step_score, tile_grid(g, r), blk, tile_bytes(p.step2.reach), stream, g, p.step2, p.step_crit,
                          p.step_ncrit, L.step_height, L.step, r);
   } else if (filter == TE_FILTER_ROUGHNESS) {
@@ -562,10 +564,12 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
     (void)hipStreamWaitEvent(ss, L.ev_fork, 0);
   }
   if (!normals_only) {
-    if (!(use_fast && fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r1, ss)))
+    if (!(use_fast && (fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r1, ss) ||
+                       fast::step_height_ties(p.step1, g, L.elev, L.step_height, L.tie_scratch, r1, ss))))
       hipLaunchKernelGGL(k_step_height, tile_grid(g, r1), blk, tile_bytes(p.step1.reach), ss, g, p.step1, L.elev,
                          L.step_height, r1);
-    if (!(use_fast && fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r2, ss)))
+    if (!(use_fast && (fast::step_score_fast(p.step2.Q, g, p.step_crit, p.step_ncrit, L.step_height, L.step, r2, ss) ||
+                       fast::step_score_ties(p.step2, g, p.step_crit, p.step_ncrit, L.step_height, L.step, L.tie_scratch, r2, ss))))
       hipLaunchKernelGGL(k_step_score, tile_grid(g, r2), blk, tile_bytes(p.step2.reach), ss, g, p.step2, p.step_crit,
                          p.step_ncrit, L.step_height, L.step, r2);
   }

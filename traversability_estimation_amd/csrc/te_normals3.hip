@@ -80,6 +80,14 @@ struct N3Args {
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
   int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
+  // TIE RADII (radius a whole number R of cells): the cells exactly on the circle belong to a disc or not as
+  // CircleIterator::isInside decides from rounded positions, centre by centre.  The TIES march slides the shape R^2,
+  // circle included (gtab: its clip table), and every row takes the rejected circle cells of its centre out of the
+  // moments again before the general tail: (+-R, 0) and (0, +-R) in the kernel, the n_gen others (3-4-5 radii) from
+  // gen_tab (di & 0xff | (dj & 0xff) << 8).  r2, ax, ay: what isInside needs.  n_ties = 0: an ordinary radius.
+  int n_ties, n_gen;
+  const int* gen_tab;
+  double r2, ax, ay;
 };
 
 constexpr int n3_chunk_rows(int NR) {
@@ -109,7 +117,7 @@ typedef float __attribute__((address_space(1))) gfloat;
 //      number of holes).  A clean strip -- the common case by
 // far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
 // clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
-template <int Q, bool KEEP, bool GENERAL, int HOLES>
+template <int Q, bool KEEP, bool GENERAL, int HOLES, bool TIES = false>
 __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
                                        const int jend) {
   constexpr int R = Shape<Q>::R;
@@ -232,7 +240,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   });
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
-  if (HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
+  if (!TIES && HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
@@ -365,6 +373,102 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       flag_tiles(j);
     }
   };
+  // ---- tie radii (TIES march, clean strips): the moments of the shape with its circle minus the circle cells that
+  // isInside() rejects for this centre, general tail.  A strip with an invalid cell is left to the fix-up pass whole.
+  unsigned long long xfail_p = 0ull, xfail_m = 0ull;  // lanes for which (icol + R, j) / (icol - R, j) is rejected: dy = 0, the same for every j
+  if constexpr (TIES) {
+    const double xi = a.ax + a.res * (double)(-icol);  // cell_x (te_geom.h)
+    const double dxp = (a.ax + a.res * (double)(-(icol + R))) - xi, dxm = (a.ax + a.res * (double)(-(icol - R))) - xi;
+    xfail_p = __ballot(!(dxp * dxp + 0.0 <= a.r2) && icol + R < a.rows);
+    xfail_m = __ballot(!(dxm * dxm + 0.0 <= a.r2) && icol - R >= 0);
+  }
+  auto tail_ties = [&](int j, int ky, auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
+    auto zat = [&](int di, int dj) __attribute__((always_inline)) {
+      int sl = slot0 + dj + R;
+      sl = sl >= NR ? sl - NR : sl;
+      sl = sl >= NR ? sl - NR : sl;
+      return ring[sl * W + lane + R + di];
+    };
+    const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+    int n = gt[0], si = gt[1], sj = gt[2], sii = gt[3], sij = gt[4], sjj = gt[5];
+    double lSz = Sz, lSiz = Siz, lSjz = Sjz, lSzz = Szz;
+    auto take_out = [&](bool fail, int di, int dj, double z) __attribute__((always_inline)) {  // fail: rejected and inside the map
+      n -= fail ? 1 : 0;
+      si -= fail ? di : 0;
+      sj -= fail ? dj : 0;
+      sii -= fail ? di * di : 0;
+      sij -= fail ? di * dj : 0;
+      sjj -= fail ? dj * dj : 0;
+      const double zz = fail ? z : 0.0;
+      lSz -= zz;
+      lSiz = fma(-(double)di, zz, lSiz);
+      lSjz = fma(-(double)dj, zz, lSjz);
+      lSzz = fma(-zz, zz, lSzz);
+    };
+    take_out(((xfail_p >> lane) & 1ull) != 0ull, R, 0, zat(R, 0));
+    take_out(((xfail_m >> lane) & 1ull) != 0ull, -R, 0, zat(-R, 0));
+    const double yj = a.ay + a.res * (double)(-j);  // cell_y
+#pragma unroll
+    for (int sgn = -1; sgn <= 1; sgn += 2) {  // (0, +-R): dx = 0, the same answer for every lane
+      const int jj = j + sgn * R;
+      if ((unsigned)jj < (unsigned)a.cols) {
+        const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+        if (!(0.0 + dy * dy <= a.r2)) take_out(true, 0, sgn * R, zat(0, sgn * R));
+      }
+    }
+    if (a.n_gen != 0) {
+      const double xi = a.ax + a.res * (double)(-icol);
+#pragma unroll 1
+      for (int t = 0; t < a.n_gen; ++t) {
+        const int e = a.gen_tab[t];
+        const int di = (int)(signed char)(e & 0xff), dj = (int)(signed char)((e >> 8) & 0xff);
+        const double dx = (a.ax + a.res * (double)(-(icol + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
+        const bool fail = !(dx * dx + dy * dy <= a.r2) && (unsigned)(icol + di) < (unsigned)a.rows && (unsigned)(j + dj) < (unsigned)a.cols;
+        take_out(fail, di, dj, zat(di, dj));
+      }
+    }
+    double qs = 0.0;
+    const int unresolved = general_tail3(a.res, n, si, sj, sii, sij, sjj, lSz, lSiz, lSjz, lSzz, fx, fy, fz, qs);
+    const float sl = acosf_poly(fz);
+    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    float rq = (float)(qs * rcp_fast((double)n * (double)(n - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    o_rough = n > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;
+    if (__builtin_expect(__any(unresolved != 0 && own), 0)) {
+      const float qn = __builtin_nanf("");
+      const bool bad = unresolved != 0;
+      o_slope = bad ? qn : o_slope;
+      o_rough = bad ? qn : o_rough;
+      fx = bad ? qn : fx;
+      fy = bad ? qn : fy;
+      fz = bad ? qn : fz;
+      flag_tiles(j);
+    }
+  };
+  auto leave_to_fixup = [&](int j_from) __attribute__((always_inline)) {  // rows [j_from, jend) of this block: every tile they touch
+    // (the fix-up pass takes the valid cells of a flagged tile whose slope is NaN: a region run finds old values there)
+    // (... and an invalid centre is nobody's business there: NaN in every layer, as the march itself leaves it)
+    const size_t o0 = mo + (size_t)j_from * a.rows + i0 + lane;
+    for (int jj = j_from; jj < jend; ++jj) {
+      const size_t o = o0 + (size_t)(jj - j_from) * a.rows;
+      if (own) {
+        a.slope[o] = a.rough[o] = __builtin_nanf("");
+        if (KEEP) a.nx[o] = a.ny[o] = a.nz[o] = __builtin_nanf("");
+      }
+    }
+    for (int jj = j_from; jj < jend; jj += 16) flag_tiles(jj);
+    if (j_from < jend) flag_tiles(jend - 1);
+  };
+  if constexpr (TIES) {
+    if (__builtin_expect(dmask != 0, 0)) {  // an invalid cell among the first rows
+      leave_to_fixup(js);
+      write_flags();
+      return true;
+    }
+  }
   // ---- rows whose disc holds invalid cells ------------------------------------------------------------------------------
   // x/y moments of the VALID cells = those of the full (GENERAL: clipped) disc minus those of the invalid cells in it.
   // The invalid cells come from the bit masks of the dirty ring rows of the disc (uniform loop over those rows, one
@@ -735,7 +839,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         }
         constexpr bool out = true;
         if (out) {
-          if (GENERAL) {
+          if constexpr (TIES) {
+            const int ky = GENERAL ? (j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0)) : 0;  // uniform
+            tail_ties(j, ky, uc);
+          } else if (GENERAL) {
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
             tail_clipped(j, ky);
           } else {
@@ -756,7 +863,14 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       if (leave) break;
       rotate();
     }
-    if (aborted) return false;
+    if (aborted) {
+      if constexpr (TIES) {  // the rest of the strip belongs to the fix-up pass
+        leave_to_fixup(j);
+        write_flags();
+        return true;
+      }
+      return false;
+    }
   } else {
     bool done = false;
 #pragma unroll 1
@@ -807,7 +921,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   return true;
 }
 
-template <int Q, bool KEEP, int HM>
+template <int Q, bool KEEP, int HM, bool TIES = false>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3(N3Args a) {
   constexpr int R = Shape<Q>::R;
   __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
@@ -837,6 +951,13 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
   const int own_lo = a.i_lo + bx * kLanes;
   const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
   if (js >= jend) return;
+  if constexpr (TIES) {  // (a strip with invalid cells flags its tiles for the fix-up pass itself)
+    if (general)
+      march3<Q, KEEP, true, 0, true>(a, ring, hmask, i0, own_lo, js, jend);
+    else
+      march3<Q, KEEP, false, 0, true>(a, ring, hmask, i0, own_lo, js, jend);
+    return;
+  }
   const bool clean = general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
                              : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
   if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
@@ -897,6 +1018,16 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int nblocks = a.n_int * a.s_int + ne * a.s_edge + a.n_top + n_bottom;
   if (nblocks <= 0) return true;
   const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
+  if (a.n_ties != 0) {  // tie radius: the whole-cell shapes only
+    if constexpr (R * R == Q) {
+      if (keep)
+        hipLaunchKernelGGL((k_normals3<Q, true, 2, true>), grid, dim3(kLanes), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_normals3<Q, false, 2, true>), grid, dim3(kLanes), 0, s, a);
+      return true;
+    }
+    return false;
+  }
   // (the kernel that keeps the normals -- the plugin path -- exists with the dense march only)
   if (keep)
     hipLaunchKernelGGL((k_normals3<Q, true, 2>), grid, dim3(kLanes), 0, s, a);
@@ -975,8 +1106,18 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
                    FastGrid* fgp, hipStream_t s) {
   FastGrid& fg = *fgp;
   const Disc& d = p.normals;
-  if (d.n_ties != 0 || d.R < 1 || d.Q < 1 || d.npoints < 3) return false;
-  const int R = d.R;
+  // The shape the kernel slides: the disc, or for a tie radius the disc with its circle (whole-cell radii: every cell
+  // on the circle has the norm reach^2, the runs plus the circle are the shape reach^2)
+  int shape = d.Q, R = d.R;
+  if (d.n_ties != 0) {
+    static const bool no_ties = getenv("TE_N3_NO_TIES") != nullptr;  // measurement aid: tie radii to the generic kernel as before
+    R = d.reach;
+    shape = R * R;
+    if (no_ties) return false;
+    for (int t = 0; t < d.n_ties; ++t)
+      if ((int)d.tie_di[t] * d.tie_di[t] + (int)d.tie_dj[t] * d.tie_dj[t] != shape) return false;
+  }
+  if (R < 1 || shape < 1 || d.npoints < 3) return false;
   N3Args a;
   a.i_lo = r.i0;
   a.i_hi = r.i1;
@@ -1014,7 +1155,14 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
     while (a.edge0 < a.nbx && is_edge(a.edge0) && (a.i_lo + a.edge0 * kLanes < R)) ++a.edge0;  // left: columns that reach i < R
     while (a.edge1 < a.nbx - a.edge0 && is_edge(a.nbx - 1 - a.edge1)) ++a.edge1;
   }
-  a.gtab = L.clip_table;
+  a.gtab = d.n_ties ? L.clip_table + kClipInts : L.clip_table;  // (ties: the table of the shape with its circle)
+  a.n_ties = d.n_ties;
+  a.n_gen = 0;
+  for (int t = 0; t < d.n_ties; ++t) a.n_gen += (d.tie_di[t] != 0 && d.tie_dj[t] != 0) ? 1 : 0;
+  a.gen_tab = L.clip_table + 2 * kClipInts;
+  a.r2 = d.r2;
+  a.ax = g.ax;
+  a.ay = g.ay;
   a.res = g.res;
   a.Nd = N;
   a.Ni = d.npoints;
@@ -1034,11 +1182,11 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.fix_groups = fix_groups(fg.ntx * fg.nty * fg.nbz);
   const int maps = r.map >= 0 ? 1 : g.batch;
   bool ok = false;
-  if (n3_launch_part0(d.Q, g, &a, keep_normals, maps, s, &ok)) return ok;
+  if (n3_launch_part0(shape, g, &a, keep_normals, maps, s, &ok)) return ok;
 #if TE_PARTS > 1
-  if (n3_launch_part1(d.Q, g, &a, keep_normals, maps, s, &ok) || n3_launch_part2(d.Q, g, &a, keep_normals, maps, s, &ok) ||
-      n3_launch_part3(d.Q, g, &a, keep_normals, maps, s, &ok) || n3_launch_part4(d.Q, g, &a, keep_normals, maps, s, &ok) ||
-      n3_launch_part5(d.Q, g, &a, keep_normals, maps, s, &ok))
+  if (n3_launch_part1(shape, g, &a, keep_normals, maps, s, &ok) || n3_launch_part2(shape, g, &a, keep_normals, maps, s, &ok) ||
+      n3_launch_part3(shape, g, &a, keep_normals, maps, s, &ok) || n3_launch_part4(shape, g, &a, keep_normals, maps, s, &ok) ||
+      n3_launch_part5(shape, g, &a, keep_normals, maps, s, &ok))
     return ok;
 #endif
   return false;

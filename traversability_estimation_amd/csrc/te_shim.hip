@@ -156,6 +156,7 @@ struct te_ctx {
   long long invalid_cells = -1;
   unsigned long long* d_count = nullptr;
   char* hole_queue = nullptr;  // scratch of k_normals3's sparse-hole march (allocated when a launch first picks it)
+  float* tie_scratch = nullptr;  // one float per cell: the step filter at a tie radius (allocated when a launch first needs it, freed with the layers)
   bool tables_ready = false;
   // the circular-footprint tables are built separately: a footprint this build cannot handle (more than 20 cells) must
   // not stop the filter chain or the per-plugin entry points, which never use them (the reference has no such coupling)
@@ -220,6 +221,19 @@ bool ensure_hole_queue(te_ctx* c) {
   }
   c->hole_queue = (char*)p;
   return true;
+}
+
+// the step filter's scratch layer at a tie radius (te_fast_step.hip); without it the generic kernels serve
+void ensure_tie_scratch(te_ctx* c) {
+  if (c->tie_scratch || !c->tables_ready || c->layer_elems == 0) return;
+  if (c->cp.step1.n_ties == 0 && c->cp.step2.n_ties == 0) return;
+  if (hipSetDevice(c->device) != hipSuccess) return;
+  void* p = nullptr;
+  if (hipMalloc(&p, c->layer_elems * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  c->tie_scratch = (float*)p;
 }
 
 void drop_graph(te_ctx* c) {
@@ -381,13 +395,34 @@ int rebuild_tables(te_ctx* c) {
   c->cp.w_step = p.w_step;
   c->cp.w_rough = p.w_rough;
   // x/y moments of the normals disc clipped by the map border, for the sliding-disc kernel
-  if (c->cp.normals.n_ties == 0 && c->cp.normals.R >= 1) {
-    const int R = c->cp.normals.R;
-    std::vector<int> tab((size_t)(2 * R + 1) * (2 * R + 1) * 6);
-    fast::build_clip_table(c->cp.normals, R, tab.data());
+  // (a tie radius: the table of the disc WITH the cells on its circle behind it, then the circle's offsets with both
+  // parts non-zero -- te_normals3.hip, TIES march)
+  if (c->cp.normals.R >= 1 || c->cp.normals.n_ties != 0) {
+    const Disc& dn = c->cp.normals;
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1)));
-    HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (!c->clip_table) HIP_TRY(hipMalloc((void**)&c->clip_table, sizeof(int) * (2 * fast::kClipInts + kMaxTies)));
+    std::vector<int> tab, tab_full;
+    int gen_tab[kMaxTies];
+    if (dn.n_ties == 0) {
+      const int R = dn.R;
+      tab.resize((size_t)(2 * R + 1) * (2 * R + 1) * 6);
+      fast::build_clip_table(dn, R, tab.data());
+      HIP_TRY(hipMemcpyAsync(c->clip_table, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    } else {
+      Disc full = dn;
+      int n_gen = 0;
+      for (int t = 0; t < dn.n_ties; ++t) {
+        const int ai = abs((int)dn.tie_di[t]), aj = abs((int)dn.tie_dj[t]);
+        if (full.hw[aj] < ai) full.hw[aj] = ai;
+        if (full.R < aj) full.R = aj;
+        if (dn.tie_di[t] != 0 && dn.tie_dj[t] != 0) gen_tab[n_gen++] = ((int)dn.tie_di[t] & 0xff) | (((int)dn.tie_dj[t] & 0xff) << 8);
+      }
+      const int R = dn.reach;
+      tab_full.resize((size_t)(2 * R + 1) * (2 * R + 1) * 6);
+      fast::build_clip_table(full, R, tab_full.data());
+      HIP_TRY(hipMemcpyAsync(c->clip_table + fast::kClipInts, tab_full.data(), tab_full.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      if (n_gen) HIP_TRY(hipMemcpyAsync(c->clip_table + 2 * fast::kClipInts, gen_tab, n_gen * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   c->L.clip_table = c->clip_table;
@@ -408,6 +443,8 @@ void free_layers(te_ctx* c) {
   c->poly_stream_cap = 0;
   if (c->robot_slope) (void)hipFree(c->robot_slope);
   c->robot_slope = nullptr;
+  if (c->tie_scratch) (void)hipFree(c->tie_scratch);
+  c->tie_scratch = nullptr;
   c->have_robot_slope = false;
   memset(&c->L, 0, sizeof(c->L));
   c->layer_elems = 0;
@@ -480,6 +517,8 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.ev_fp_join = c->ev_fp_join;
   c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
   c->L.hole_queue = c->hole_queue;
+  ensure_tie_scratch(c);  // (likewise)
+  c->L.tie_scratch = c->tie_scratch;
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   c->footprint_done = false;  // the layers the footprint pass reads have changed
@@ -520,6 +559,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     HIP_TRY(hipSetDevice(c->device));
     int slot = -1;
     // (the captured launches bake in which k_normals3 variant runs: the hint is part of the key)
+    ensure_tie_scratch(c);
     const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u);
     for (int k = 0; k < te_ctx::kGraphs; ++k)
       if (c->graph_exec[k] && c->graph_flags[k] == key) slot = k;
@@ -1193,6 +1233,8 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   if ((filter == TE_FILTER_STEP || filter == TE_FILTER_ROUGHNESS || filter == TE_FILTER_NORMALS) && !c->have_elev)
     return fail(TE_ERR_NOT_READY, "te_run_filter: no elevation uploaded");
   HIP_TRY(hipSetDevice(c->device));
+  ensure_tie_scratch(c);
+  c->L.tie_scratch = c->tie_scratch;
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
   // A single plugin's filter overwrites score layers from whatever inputs are resident (TE_FILTER_NORMALS also slope
   // and roughness, with the normals radius): the layers no longer form one chain result, so region re-filters, the

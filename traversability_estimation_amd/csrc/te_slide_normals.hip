@@ -493,7 +493,18 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
                   const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s, bool* combined) {
   const Disc& d = p.normals;
-  if (d.n_ties != 0 || d.R < 1 || d.R > 16 || d.npoints < 3) return false;
+  if (d.n_ties != 0) {  // a tie radius: k_normals3's TIES march or nothing
+    static const bool no_n3_ties = getenv("TE_NO_N3") != nullptr;
+    if (no_n3_ties || !gtab || g.rows < 2 * d.reach + 1 || g.cols < 2 * d.reach + 1) return false;
+    fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
+    fg->nty = (r.j1 - r.j0 + 15) / 16;
+    fg->nbz = r.map >= 0 ? 1 : g.batch;
+    fg->frame = 0;
+    if (!normals_fast3(g, p, L, keep_normals, r, flags, fg, s)) return false;
+    *combined = false;
+    return true;
+  }
+  if (d.R < 1 || d.R > 16 || d.npoints < 3) return false;
   SlideArgs a;
   int sii = 0;
   for (int k = 0; k <= kMaxRadiusCells; ++k) {
