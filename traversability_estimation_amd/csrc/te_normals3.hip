@@ -921,8 +921,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   return true;
 }
 
+constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 bytes of scratch (local copies of the moments, the general
+                                // tail on every row); compiled for 2 waves the compiler takes all 256 and spills 500 bytes on top
 template <int Q, bool KEEP, int HM, bool TIES = false>
-__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3(N3Args a) {
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? kN3TieWaves : kN3Waves, TIES ? kN3TieWaves : kN3Waves))) void k_normals3(N3Args a) {
   constexpr int R = Shape<Q>::R;
   __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
   __shared__ unsigned long long hmask[2 * R + 2][2];  // invalid cells of the ring rows (HOLES march)
@@ -972,13 +974,14 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
 // Resident single-wave blocks per CU and CUs of the current device.  The LDS allocation granularity decides: at R = 9
 // (13 120 B) 11 blocks fit, not 12 (tools/census.hip), and a grid of 12 per CU runs in two rounds -- twice the time.
 template <int Q, bool KEEP>
-int resident_blocks() {
+int resident_blocks(bool ties = false) {
   // (hipOccupancyMaxActiveBlocksPerMultiprocessor answers 12 for 13 120 B; the hardware admits 11: the census fits an
   // allocation granule of 1280..2048 bytes, the conservative end is used here)
   constexpr int R = Shape<Q>::R;
   constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 8 + (2 * R + 2) * 16;  // ring + hole masks
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);
   if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
+  if (ties && per_cu > kN3TieWaves * 4) per_cu = kN3TieWaves * 4;
   static const int ov = getenv("TE_N3_BLOCKS_PER_CU") ? atoi(getenv("TE_N3_BLOCKS_PER_CU")) : 0;  // measurement aid
   if (ov > 0) per_cu = ov < kN3Waves * 4 ? ov : kN3Waves * 4;  // (the hole queues are allocated for kN3Waves * 4 per CU)
   return per_cu * device_cus();
@@ -990,7 +993,7 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int H = a.j_hi - a.j_lo;
   // As many blocks as fill the resident wave slots in ONE round.  Edge block columns run the general tail on every row
   // (about 1.5x the time of an interior row): their strips are 1.5x shorter so that all blocks finish together.
-  const int capacity = (keep ? resident_blocks<Q, true>() : resident_blocks<Q, false>()) / (maps > 0 ? maps : 1);
+  const int capacity = (keep ? resident_blocks<Q, true>(a.n_ties != 0) : resident_blocks<Q, false>(a.n_ties != 0)) / (maps > 0 ? maps : 1);
   const int ne = a.edge0 + a.edge1;
   constexpr int R = Shape<Q>::R;
   a.n_int = a.nbx - ne;
