@@ -115,15 +115,18 @@ def test_step_filter_cell_count_cases(capi, oracle, ncrit, crit):
             assert ((w > 0) & (w < 1)).sum() > 0  # the middle case occurs
 
 
-def test_region_run_with_the_footprint_flag(capi, oracle):
+@pytest.mark.parametrize("ties", [False, True])
+def test_region_run_with_the_footprint_flag(capi, oracle, ties):
     """te_run_chain_region(TE_RUN_FOOTPRINT): after a sequence of dirty rectangles (interior, touching borders, overlapping)
-    every layer incl. traversability_footprint and the memo layers equals the oracle's whole-map result."""
+    every layer incl. traversability_footprint and the memo layers equals the oracle's whole-map result.  ties: every
+    radius a whole number of cells (the TIES march, the step folds and the fixed-point footprint's tie variant on regions)."""
     from traversability_estimation_amd import synth
     rows, cols, res = 300, 260, 0.05
     elev = obstacle_map(synth, rows, cols, 21, 10).reshape(cols, rows)
-    r = synth.benchmark_radius(4, res)
+    r = 4 * res if ties else synth.benchmark_radius(4, res)
     op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
-                               fp_radius=synth.benchmark_radius(5, res), fp_offset=synth.benchmark_radius(2, res))
+                               fp_radius=5 * res if ties else synth.benchmark_radius(5, res),
+                               fp_offset=2 * res if ties else synth.benchmark_radius(2, res))
     g = oracle.geom(rows, cols, res)
     layers = list(OUT_LAYERS) + ["traversability_footprint", "slope_footprint", "step_footprint"]
     rng = np.random.default_rng(3)
@@ -207,7 +210,7 @@ def test_streaming_tiles_async_against_the_oracle(capi, oracle):
             capi.unpin_host(b)
 
 
-@pytest.mark.parametrize("off_cells", [0.0, 2.0])
+@pytest.mark.parametrize("off_cells", [0.0, 2.0, -2.0])
 def test_blocked_discs_of_a_batch(capi, oracle, off_cells):
     """The footprint pass's list of blocked cells (k_fp_slide4 appends, k_fp_blocked walks) indexes the cells of ALL
     maps of a batch; with radiusMin = 0 nothing is listed and a blocked disc is 0 outright (:694-704)."""
@@ -215,8 +218,11 @@ def test_blocked_discs_of_a_batch(capi, oracle, off_cells):
     rows, cols, res, B = 150, 130, 0.05, 3
     elevs = [obstacle_map(synth, rows, cols, 900 + 13 * b, 4 + 9 * b) for b in range(B)]
     r = synth.benchmark_radius(3, res)
-    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=synth.benchmark_radius(5, res),
-                               fp_offset=synth.benchmark_radius(off_cells, res) if off_cells else 0.0)
+    if off_cells < 0:  # a tie radius: 5 + 2 cells exactly
+        fpr, fpo = 5 * res, -off_cells * res
+    else:
+        fpr, fpo = synth.benchmark_radius(5, res), synth.benchmark_radius(off_cells, res) if off_cells else 0.0
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=fpr, fp_offset=fpo)
     g = oracle.geom(rows, cols, res, (0.0, 0.0))
     with capi.Context(0) as ctx:
         ctx.set_params(to_te_params(capi, op))
@@ -288,6 +294,27 @@ def test_chain_at_tie_radii(capi, oracle, res, cells, holes, origin):
         ctx.sync()
         got = {k: ctx.download(k) for k in OUT_LAYERS}
     assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx=f"chain at {cells} cells exactly, res {res}")
+
+
+@pytest.mark.parametrize("cells", [3, 5, 8])
+def test_normals_kept_at_a_tie_radius(capi, oracle, cells):
+    """TE_RUN_KEEP_NORMALS (the plugin path's normals filter) at a whole-cell radius: k_normals3<Q, true, 2, true>."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 190, 160, 0.05
+    elev = obstacle_map(synth, rows, cols, 40 + cells, 6)
+    r = cells * res
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=synth.benchmark_radius(3, res), step_radius2=synth.benchmark_radius(3, res))
+    g = oracle.geom(rows, cols, res, (2.2, -1.1))
+    want = oracle.chain(g, op, elev, want_normals=True)
+    layers = list(OUT_LAYERS) + ["surface_normal_x", "surface_normal_y", "surface_normal_z"]
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, (2.2, -1.1))
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_KEEP_NORMALS)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in layers}
+    assert_layers_match(got, want, layers=layers, ctx=f"normals kept at {cells} cells exactly")
 
 
 _DENSE_LIST_SCRIPT = r"""
