@@ -266,6 +266,10 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // straight from global memory.
   constexpr int MTH = MY + 2 * MH;
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
+  // the slow cells' list (below): entries, wavefronts past the screening pass, wavefronts with slow cells, of those the ones
+  // whose entries are in the list -- zeroed here, before the first barrier
+  __shared__ int ntodo, arrived, members, compacted;
+  if (threadIdx.x == 0 && threadIdx.y == 0) ntodo = arrived = members = compacted = 0;
   const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * g.rows * g.cols;
   const int i0 = ((int)blockIdx.x + a.ti0) * MX, j0 = ((int)blockIdx.y + a.tj0) * MY;
   // (the footprint pass's list of blocked cells starts empty: k_fp_slide4 / k_fp_blocked run after this kernel)
@@ -435,7 +439,6 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // then takes the cells thread by thread as before).
   static_assert(sizeof(t_kl) >= MX * MY * sizeof(unsigned short), "the list fits the tile it replaces");
   unsigned short* const todo = reinterpret_cast<unsigned short*>(t_kl);
-  __shared__ int ntodo;
   if (!q5) {
 #pragma unroll 1
     while (slow_mask) {
@@ -471,9 +474,20 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
     return;  // (uniform)
   }
-  const int tid2 = threadIdx.y * MX + threadIdx.x;
-  if (tid2 == 0) ntodo = 0;
-  __syncthreads();
+  // No barrier: on a map without obstacles no tile has a slow cell, and two barriers per tile cost the mask kernel 5 of
+  // its 72 us.  A wavefront (one tile row of threads) without slow cells signs off and leaves; the others wait -- LDS
+  // counters, all wavefronts of a workgroup are resident together -- until every wavefront is through the screening pass
+  // (the list lives in t_kl), put their cells into the list, wait for one another's entries and share the list.
+  const bool mine = __ballot(slow_mask != 0u) != 0ull;  // (uniform: a wavefront is the MX threads of one threadIdx.y)
+  int rank = 0;
+  if (threadIdx.x == 0) {
+    if (mine) rank = atomicAdd(&members, 1);
+    atomicAdd(&arrived, 1);  // (after my last read of t_kl and after `members`: LDS operations of a wavefront execute in order)
+  }
+  if (!mine) return;
+  rank = __builtin_amdgcn_readfirstlane(rank);
+  while (*(volatile int*)&arrived < MBY) __builtin_amdgcn_s_sleep(1);
+  const int n_members = *(volatile int*)&members;
   fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
     const bool need = ((slow_mask >> c) & 1u) != 0;
@@ -487,10 +501,11 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
             (unsigned short)(((jb + c) << 7) | ((((screen_mask >> c) & 1u) != 0 ? 1 : 0) << 6) | (int)threadIdx.x);
     }
   });
-  __syncthreads();
-  const int n_todo = ntodo;
+  if (threadIdx.x == 0) atomicAdd(&compacted, 1);  // (behind my entries)
+  while (*(volatile int*)&compacted < n_members) __builtin_amdgcn_s_sleep(1);
+  const int n_todo = *(volatile int*)&ntodo;
 #pragma unroll 1
-  for (int k = tid2; k < n_todo; k += MX * MBY) {
+  for (int k = rank * MX + (int)threadIdx.x; k < n_todo; k += n_members * MX) {
     const int e = todo[k];
     const int li = e & 63, lj = e >> 7;
     const bool screened = ((e >> 6) & 1) != 0;
