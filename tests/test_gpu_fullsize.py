@@ -20,7 +20,10 @@ def capi():
     return capi
 
 
-def bench_params(capi, synth, cells, res):
+def bench_params(capi, synth, cells, res, ties=False):
+    if ties:  # every radius a whole number of cells: the cells on the circles are decided centre by centre
+        return capi.default_params(normals_radius=cells * res, rough_radius=cells * res, step_radius1=cells * res, step_radius2=cells * res,
+                                   fp_radius=6 * res, fp_offset=3 * res)
     r = synth.benchmark_radius(cells, res)
     return capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r,
                                fp_radius=synth.benchmark_radius(6, res), fp_offset=synth.benchmark_radius(3, res))
@@ -33,13 +36,22 @@ def oracle_params(oracle, p):
     return op
 
 
-@pytest.mark.parametrize("n,cells,seed", [(1024, 5, 1234), (4096, 9, 1235)])
-def test_full_map_fast_vs_generic_and_oracle_crops(capi, oracle, n, cells, seed):
-    """configs[1] (1024^2, radius 5) and configs[2] (4096^2, radius 9 + footprint)."""
+@pytest.mark.parametrize("n,cells,seed,ties", [(1024, 5, 1234, False), (4096, 9, 1235, False), (1024, 5, 1236, True), (4096, 9, 1237, True)])
+def test_full_map_fast_vs_generic_and_oracle_crops(capi, oracle, n, cells, seed, ties):
+    """configs[1] (1024^2, radius 5) and configs[2] (4096^2, radius 9 + footprint).  ties: the same maps with every radius
+    a whole number of cells (the TIES march, the step folds, the fixed-point footprint's tie variant, hipGraph replay and
+    the two streams at full size) against the generic kernels, which the oracle checks cell by cell on small maps; a
+    crop cannot serve there: the decisions on the circles depend on the rounded cell positions, which a crop does not share."""
     from traversability_estimation_amd import synth
     res = 0.05
     elev = synth.perlin_elevation(n, n, seed=seed)
-    p = bench_params(capi, synth, cells, res)
+    if ties:  # something for the footprint's blocked discs and the step filter to find
+        rng = np.random.default_rng(seed)
+        for _ in range(40):
+            h, w = (int(v) for v in rng.integers(4, 40, size=2))
+            r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+            elev[c0:c0 + w, r0:r0 + h] += np.float32(0.3)
+    p = bench_params(capi, synth, cells, res, ties)
     with capi.Context(0) as ctx:
         ctx.set_params(p)
         ctx.set_geometry(n, n, 1, res)
@@ -58,6 +70,8 @@ def test_full_map_fast_vs_generic_and_oracle_crops(capi, oracle, n, cells, seed)
     # combine identity on the full map (float32, left to right)
     t = np.float32(p.w_scale) * ((fast["traversability_slope"] + fast["traversability_step"]) + fast["traversability_roughness"])
     assert (t.view(np.uint32) == fast["traversability"].view(np.uint32)).all()
+    if ties:
+        return
     # the chain's reach is 2*cells (step), the footprint adds 9: cells further than that from a crop's cut
     # edges see the same neighbourhood in the crop as in the full map
     m, margin = 160, 2 * cells + 10
