@@ -162,6 +162,13 @@ int te_destroy(te_ctx* ctx);
 
 int te_set_params(te_ctx* ctx, const te_params* p);
 int te_get_params(te_ctx* ctx, te_params* p);
+/* Choices between kernels that produce IDENTICAL layers (no reference counterpart: the reference has one code path).
+ * The defaults pick by input size; the options exist so that tests and measurements can reach every path through the
+ * ABI -- the library never reads the environment. */
+#define TE_OPT_FP_BLOCKED_WALK 1          /* discs with an untraversable cell: 0 by list length, 1 one disc per wavefront, 2 one disc per lane */
+#define TE_OPT_FP_BLOCKED_BLOCKS_PER_CU 2 /* grid of that kernel: 0 default (24), 1 .. 32 */
+#define TE_OPT_POLYGON_PER_CELL 3         /* polygon footprint layers: 1 evaluates every cell of every bounding box instead of the offset table */
+int te_set_option(te_ctx* ctx, int option, int value);
 /* rows = size(0), cols = size(1) of every map of the batch; (pos_x,pos_y) = map centre. */
 int te_set_geometry(te_ctx* ctx, int rows, int cols, int batch, double resolution, double pos_x, double pos_y);
 
@@ -171,7 +178,11 @@ int te_upload_elevation(te_ctx* ctx, const float* host, int map0, int nmaps);
  * column-major h x w host tile (dirty-region update). */
 int te_upload_tile(te_ctx* ctx, const float* host_tile, int map, int row0, int col0, int h, int w);
 /* Device pointer of a layer ([batch][cols][rows] float32) for zero-copy producers/consumers
- * (e.g. a torch tensor filled on the same device); valid until te_set_geometry/te_destroy. */
+ * (e.g. a torch tensor filled on the same device); valid until te_set_geometry/te_destroy.
+ * Writers order their work against the context themselves (te_sync, or the same device stream order).  Handing out
+ * TE_LAYER_TRAVERSABILITY marks that layer as caller-writable until the next te_set_geometry: te_run_footprint and
+ * region runs then no longer assume its values are bounded by the chain's weights (they use the double-precision
+ * footprint kernel); te_run_chain with TE_RUN_FOOTPRINT rewrites every cell first and is unaffected. */
 int te_device_ptr(te_ctx* ctx, int layer, void** dptr, size_t* bytes);
 /* The optional input layer robot_slope (checkInclination, TraversabilityMap.cpp:748-762; it travels with the elevation
  * map when the caller has one) is present after an upload.  present = 0 declares it absent again -- an elevation map that

@@ -341,6 +341,8 @@ for fp_cells, off_cells, boxes, origin in ((6, 3, 30, (0.0, 0.0)), (9, 4, 18, (1
     want = O.chain(g, op, elev)
     fp = O.footprint(g, op, elev, want)
     with capi.Context(0) as ctx:
+        ctx.set_option(capi.OPT_FP_BLOCKED_WALK, 2)           # one disc per lane
+        ctx.set_option(capi.OPT_FP_BLOCKED_BLOCKS_PER_CU, 1)  # 256 wavefronts: the lanes of a group are filled
         ctx.set_params(to_te_params(capi, op))
         ctx.set_geometry(rows, cols, 1, res, origin)
         ctx.upload_elevation(elev)
@@ -357,14 +359,14 @@ sys.exit(1 if bad_total else 0)
 
 def test_blocked_discs_one_per_lane():
     """k_fp_blocked walks one disc per lane when the list is long for the launch (>= 8 cells per wavefront: 49 152
-    on an MI355X, more than a map the oracle finishes in seconds can hold).  TE_FB_PATH=lane forces that walk and
-    TE_FB_BLOCKS_PER_CU=1 shrinks the launch to 256 wavefronts, so that the lanes of a group are filled (the variables
-    are read once per process: a process of its own).  Maps with borders on all sides (the bounds-checked loops) and an
-    interior large enough for the scalar-offset ones; the last case is a tie radius."""
+    on an MI355X, more than a map the oracle finishes in seconds can hold).  te_set_option(TE_OPT_FP_BLOCKED_WALK, 2)
+    forces that walk and TE_OPT_FP_BLOCKED_BLOCKS_PER_CU = 1 shrinks the launch to 256 wavefronts, so that the lanes of
+    a group are filled.  Maps with borders on all sides (the bounds-checked loops) and an interior large enough for the
+    scalar-offset ones; the last case is a tie radius."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TE_FB_BLOCKS_PER_CU="1", TE_FB_PATH="lane")
+    env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", _DENSE_LIST_SCRIPT, root], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -180,13 +180,13 @@ def gpu_setup(capi, oracle, rows, cols, res, pos, elev, **over):
          over=dict(fp_radius=0.2, fp_offset=0.1)),  # 72 x 48 cells: too large for the offset table
 ])
 @pytest.mark.parametrize("per_cell", [False, True])
-def test_polygon_footprint_layers(capi, oracle, case, per_cell, monkeypatch):
+def test_polygon_footprint_layers(capi, oracle, case, per_cell):
     """Both kernels (offset table + LDS tile; every cell of every bounding box) against the oracle, bit for bit."""
     rows, cols, res = case["rows"], case["cols"], case["res"]
     elev = terrain(rows, cols, seed=rows + cols)
     ctx, g, op, layers = gpu_setup(capi, oracle, rows, cols, res, (0.7, -0.2), elev, fp_default=0.3, **case.get("over", {}))
-    monkeypatch.setenv("TE_POLYGON_PER_CELL", "1" if per_cell else "0")
     with ctx:
+        ctx.set_option(capi.OPT_POLYGON_PER_CELL, 1 if per_cell else 0)
         ctx.run_polygon_footprint(case["pts"], case["yaw"])
         ctx.sync()
         got_x, got_rot = ctx.download("traversability_x"), ctx.download("traversability_rot")

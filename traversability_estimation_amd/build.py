@@ -3,6 +3,10 @@
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels with
 the gpurun snapshot, so the GPU box uses the prebuilt file.  Every source is compiled to its own object
 (in parallel, cached under _build/ by modification time) and the objects are linked into the library.
+
+`python -m traversability_estimation_amd.build --lab` builds libtravgpu_lab.so (-DTE_LAB, objects under _build_lab/): the
+same sources with their measurement switches (environment variables such as TE_NO_F4, TE_N3_BLOCKS_PER_CU) compiled in.
+The shipped libtravgpu.so never reads the environment; tools/ load the lab library through TRAVGPU_LIB.
 """
 import os
 import shutil
@@ -14,7 +18,9 @@ _ROOT = os.path.dirname(_HERE)
 SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
+LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")
 OBJDIR = os.path.join(_HERE, "_build")
+LAB_OBJDIR = os.path.join(_HERE, "_build_lab")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-ldl"]
 # per-source flags.  te_normals3: keep the ring reads as single ds_read_b64 -- a merged ds_read2_b64 halves the LDS rate
@@ -37,10 +43,11 @@ def _mtime(rel):
     return os.path.getmtime(os.path.join(_HERE, rel))
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lab=False):
+    lib = LAB_LIB if lab else LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(_mtime(f) > t for f in SOURCES + HEADERS)
 
 
@@ -49,41 +56,46 @@ def _units():
     return [(s, k) for s in SOURCES for k in (range(PARTS[s]) if s in PARTS else [None])]
 
 
-def _obj(src, part=None):
+def _obj(src, part=None, lab=False):
     base = os.path.basename(src)
     if part is not None:
         base = base[:-len(".hip")] + ".p%d.hip" % part
-    return os.path.join(OBJDIR, base + ".o")
+    return os.path.join(LAB_OBJDIR if lab else OBJDIR, base + ".o")
 
 
-def _compile(unit, verbose):
+def _compile(unit, verbose, lab=False):
     src, part = unit
     defs = [] if part is None else ["-DTE_PARTS=%d" % PARTS[src], "-DTE_PART=%d" % part]
+    if lab:
+        defs.append("-DTE_LAB")
+    out = _obj(src, part, lab)
     cmd = [hipcc()] + CFLAGS + EXTRA_CFLAGS.get(src, []) + defs + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-c",
-                               os.path.join(_HERE, src), "-o", _obj(src, part) + ".tmp"]
+                               os.path.join(_HERE, src), "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(_obj(src, part) + ".tmp", _obj(src, part))
+    os.replace(out + ".tmp", out)
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
+def build_lib(force=False, verbose=False, lab=False):
+    lib = LAB_LIB if lab else LIB
+    if not force and not stale(lab):
+        return lib
+    os.makedirs(LAB_OBJDIR if lab else OBJDIR, exist_ok=True)
     newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
     todo = [u for u in _units()
-            if not os.path.exists(_obj(*u)) or os.path.getmtime(_obj(*u)) < max(_mtime(u[0]), newest_header)]
+            if not os.path.exists(_obj(*u, lab=lab)) or os.path.getmtime(_obj(*u, lab=lab)) < max(_mtime(u[0]), newest_header)]
     todo.sort(key=lambda u: u[0] not in PARTS)  # the long ones first
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
-        list(pool.map(lambda u: _compile(u, verbose), todo))
-    cmd = [hipcc()] + LDFLAGS + [_obj(*u) for u in _units()] + ["-o", LIB + ".tmp"]
+        list(pool.map(lambda u: _compile(u, verbose, lab), todo))
+    cmd = [hipcc()] + LDFLAGS + [_obj(*u, lab=lab) for u in _units()] + ["-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+    print(build_lib(force="--force" in sys.argv or "--lab" not in sys.argv, verbose=True, lab="--lab" in sys.argv))

@@ -26,10 +26,11 @@ RUN_GENERIC_KERNELS = 0x4
 RUN_FOOTPRINT_MEMO = 0x8
 RUN_SEQUENTIAL = 0x10
 RUN_NORMALS_ONLY = 0x20
+OPT_FP_BLOCKED_WALK, OPT_FP_BLOCKED_BLOCKS_PER_CU, OPT_POLYGON_PER_CELL = 1, 2, 3
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
-           "te_set_params", "te_get_params", "te_set_geometry", "te_upload_elevation", "te_upload_tile", "te_download_tile",
+           "te_set_params", "te_get_params", "te_set_option", "te_set_geometry", "te_upload_elevation", "te_upload_tile", "te_download_tile",
            "te_upload_tile_async", "te_download_tile_async",
            "te_device_ptr", "te_set_layer_present", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
@@ -125,6 +126,7 @@ def load():
         L.te_destroy.argtypes = [vp]
         L.te_set_params.argtypes = [vp, pp]
         L.te_get_params.argtypes = [vp, pp]
+        L.te_set_option.argtypes = [vp, C.c_int, C.c_int]
         L.te_set_geometry.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.te_upload_elevation.argtypes = [vp, fp, C.c_int, C.c_int]
         L.te_upload_tile.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -332,6 +334,9 @@ class Context:
 
     def set_params(self, p):
         _check(load().te_set_params(self._h, C.byref(p)))
+
+    def set_option(self, option, value):
+        _check(load().te_set_option(self._h, int(option), int(value)))
 
     def get_params(self):
         p = TeParams()

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_step_score_ties(Geo g, TieArgs t, doubl
 
 // resident wave slots of the device for a kernel compiled for `waves` waves per SIMD
 long wave_slots(int waves) {
-  static const int ov = getenv("TE_STEP_WAVES") ? atoi(getenv("TE_STEP_WAVES")) : 0;  // measurement aid: strips sized for this many waves per SIMD
+  static const int ov = lab_int("TE_STEP_WAVES", 0);  // measurement aid: strips sized for this many waves per SIMD
   return 4L * device_cus() * (ov > 0 ? ov : waves);
 }
 
@@ -441,7 +441,7 @@ bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const R
 
 // a tie radius (see the header); scratch: one float per cell of the layer
 bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh, float* scratch, const Region& r, hipStream_t s) {
-  static const bool off = getenv("TE_STEP_NO_TIES") != nullptr;  // measurement aid: tie radii to the generic kernels as before
+  static const bool off = lab_flag("TE_STEP_NO_TIES");  // measurement aid: tie radii to the generic kernels as before
   int q = 0;
   TieArgs t;
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
@@ -480,7 +480,7 @@ bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* s
 
 bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const float* sh, float* out, float* scratch, const Region& r,
                      hipStream_t s) {
-  static const bool off = getenv("TE_STEP_NO_TIES") != nullptr;
+  static const bool off = lab_flag("TE_STEP_NO_TIES");
   int q = 0;
   TieArgs t;
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;

@@ -480,6 +480,9 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // (the list lives in t_kl), put their cells into the list, wait for one another's entries and share the list.
   const bool mine = __ballot(slow_mask != 0u) != 0ull;  // (uniform: a wavefront is the MX threads of one threadIdx.y)
   int rank = 0;
+  // (release / acquire at workgroup scope around the counters: the LDS executes a wavefront's operations in order, the
+  // fences keep the COMPILER from moving the plain accesses to t_kl / todo across the relaxed atomics and volatile reads)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (threadIdx.x == 0) {
     if (mine) rank = atomicAdd(&members, 1);
     atomicAdd(&arrived, 1);  // (after my last read of t_kl and after `members`: LDS operations of a wavefront execute in order)
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   if (!mine) return;
   rank = __builtin_amdgcn_readfirstlane(rank);
   while (*(volatile int*)&arrived < MBY) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const int n_members = *(volatile int*)&members;
   fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
@@ -501,8 +505,10 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
             (unsigned short)(((jb + c) << 7) | ((((screen_mask >> c) & 1u) != 0 ? 1 : 0) << 6) | (int)threadIdx.x);
     }
   });
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (threadIdx.x == 0) atomicAdd(&compacted, 1);  // (behind my entries)
   while (*(volatile int*)&compacted < n_members) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const int n_todo = *(volatile int*)&ntodo;
 #pragma unroll 1
   for (int k = rank * MX + (int)threadIdx.x; k < n_todo; k += n_members * MX) {
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
 
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
                             const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream,
-                            const Region* region, bool* region_done) {
+                            const Region* region) {
   MaskArgs m;
   m.slope_disc = p.slope_disc;
   m.step_disc = p.step_disc;
@@ -969,7 +975,6 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.ti0 = m.tj0 = 0;
   m.map = -1;
   m.blocked_count = L.fp_blocked_count;
-  if (region_done) *region_done = false;
   // A region run (te_run_chain_region with the footprint flag): isTraversableForFilters of a cell reads scores within
   // 3 cells (circle(3 res), circle(2.5 res) and the 3x3 blocks around its cells), so the mask is recomputed on the
   // region grown by MH; the footprint of a cell reads the mask and the traversability within the footprint's reach.
@@ -988,7 +993,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     m.map = region->map;
   }
   const long tiles32 = (long)((rm.i1 - rm.i0 + MX - 1) / MX) * ((rm.j1 - rm.j0 + 31) / 32) * (region ? 1 : (g.batch > 0 ? g.batch : 1));
-  static const int small_env = getenv("TE_MASK_SMALL_TILES") ? atoi(getenv("TE_MASK_SMALL_TILES")) : -1;
+  static const int small_env = lab_int("TE_MASK_SMALL_TILES", -1);
   const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
   const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : 32);  // a very small map: one cell per thread
   // the mask kernel on the tile rows [t0, t1) (tiles of my cells) of the region
@@ -1003,41 +1008,12 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
       hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else
       hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
-    m.blocked_count = nullptr;  // (a pass in two bands: the second launch must not empty the list again)
   };
   const int t_lo = rm.j0 / my, t_hi = (rm.j1 - 1) / my + 1;
-  // Whole large maps: the two kernels of the pass overlap, half a map apart.  The mask kernel is the one kernel of the
-  // chain that is near the memory bandwidth, the sliding sum is bound by its LDS reads and instruction issue: the
-  // upper half's sliding sum runs beside the lower half's mask kernel on the second stream.
-  // MEASURED (MI355X, 4096^2, same box): 0.418 ms per chain launch with the two bands against 0.385 ms without -- the
-  // two kernels slow each other down by more than they overlap, and the half-length strips of the sliding sum pay
-  // their start-up twice.  Off unless TE_FP_BANDS=2 asks for it.
-  static const int bands_env = getenv("TE_FP_BANDS") ? atoi(getenv("TE_FP_BANDS")) : 1;
-  if (!region && bands_env >= 2 && my == 32 && L.aux_stream && L.ev_fp_fork && L.ev_fp_join && g.cols >= 1024) {
-    const int j_mid = ((g.cols / 2 + 31) / 32) * 32;
-    int t_mid = (j_mid + p.reach + my - 1) / my;  // the upper half's discs read the mask down to row j_mid + reach - 1
-    t_mid = t_mid < t_hi ? t_mid : t_hi;
-    const Region top = {-1, 0, 0, g.rows, j_mid}, bot = {-1, 0, j_mid, g.rows, g.cols};
-    launch_mask(t_lo, t_mid, stream);
-    (void)hipEventRecord(L.ev_fp_fork, stream);
-    (void)hipStreamWaitEvent(L.aux_stream, L.ev_fp_fork, 0);
-    const bool f4 = fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, L.aux_stream, &top, false);
-    const bool f3 = !f4 && fast::footprint_slide3(g, p, L, spiral_table, clip_table, L.aux_stream, &top);
-    (void)hipEventRecord(L.ev_fp_join, L.aux_stream);
-    launch_mask(t_mid, t_hi, stream);
-    if (f4 || f3) {
-      if (f4)
-        (void)fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, &bot, false);
-      else
-        (void)fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, &bot);
-      (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);
-      if (f4) fast::footprint_blocked4(g, p, L, spiral_table, stream);  // the listed cells of both bands
-      return hipGetLastError();
-    }
-    (void)hipStreamWaitEvent(stream, L.ev_fp_join, 0);  // neither kernel takes the shape: the whole-map kernel below, after the mask
-  } else {
-    launch_mask(t_lo, t_hi, stream);
-  }
+  // (A pass in two bands -- the upper half's sliding sum on the second stream beside the lower half's mask kernel -- was
+  // measured in round 3: 0.418 ms per launch against 0.385; the two kernels slow each other down by more than they
+  // overlap.  Removed.)
+  launch_mask(t_lo, t_hi, stream);
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;
   const Disc& d = p.fp_disc;
@@ -1057,12 +1033,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.inner_q = fast::footprint_inner_q(g.res, p.rmin, p.rmax);
   // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
   if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, rfp) ||
-      fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, rfp)) {
-    if (region_done) *region_done = true;
+      fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, rfp))
     return hipGetLastError();
-  }
-  // (the kernel below always covers the whole map: a region run falls back to it, correct and slower)
-  if (region && g.batch > 1) return hipErrorNotSupported;  // it would also redo the other maps of the batch: not a region run
+  // (the kernel below always covers every cell of every map: a region run falls back to it -- the cells outside the
+  // region get the values they had, recomputed from unchanged inputs: correct, and slower)
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
     const int Rk = p.reach;
@@ -1074,7 +1048,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     int rows_per = (g.cols + strips - 1) / strips;
     // (a small map cannot fill the wave slots anyway: every block is resident at once and the launch takes one warm-up
     // plus the rows of one strip, so the shortest strips win -- each wave's spiral walks are serial)
-    static const int min_rows = getenv("TE_FP_MIN_STRIP") ? atoi(getenv("TE_FP_MIN_STRIP")) : 1;
+    static const int min_rows = lab_int("TE_FP_MIN_STRIP", 1);
     a.out_rows = rows_per < min_rows ? min_rows : (rows_per > 512 ? 512 : rows_per);
     a.out_rows = a.out_rows < 1 ? 1 : a.out_rows;
   }

@@ -352,7 +352,7 @@ void launch_f3(const F3Args& a0, int batch, hipStream_t s) {
   int sr = (H + strips - 1) / strips;
   // small maps cannot fill the wave slots: every resident block runs at once, so the launch takes one warm-up plus the
   // rows of one strip -- the shortest strips win (the spiral walks of a row are serial within its wavefront)
-  static const int min_strip = getenv("TE_F3_MIN_STRIP") ? atoi(getenv("TE_F3_MIN_STRIP")) : 1;
+  static const int min_strip = lab_int("TE_F3_MIN_STRIP", 1);
   sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
   sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
@@ -427,7 +427,7 @@ int footprint_inner_q(double res, double rmin, double rmax) {
 bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       hipStream_t s, const Region* region) {
   const Disc& d = p.fp_disc;
-  static const bool off = getenv("TE_NO_F3") != nullptr;
+  static const bool off = lab_flag("TE_NO_F3");
   if (off || d.n_ties != 0 || d.Q < 1 || d.R < 1 || p.reach != d.R || g.rows < kLanes || g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1)
     return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;

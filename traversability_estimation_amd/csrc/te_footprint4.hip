@@ -64,6 +64,7 @@ struct F4Args {
   unsigned* blocked_count;  // ... [0] how many entries are reserved, [1] how many hold a cell (k_fp_mask resets both: it runs
                             // before this kernel in every footprint pass)
   int chunk;                // entries a block reserves at a time: kF4Chunk, less for strips shorter than four rows
+  size_t list_cap;          // entries the list holds (host side: launch_f4 refuses a grid whose unfinished chunks might not fit)
 };
 
 constexpr int f4_chunk_rows(int NR) {
@@ -265,14 +266,21 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
         const unsigned long long bm = __ballot(listed);
         if (bm != 0ull) {
           const int n = __popcll(bm);
+          const int rank = __popcll(bm & ((1ull << lane) - 1ull));
+          // A row that does not fit the rest of the chunk fills it to the last entry and continues in a new one: every
+          // closed chunk is full, so a launch reserves at most (listed cells + one chunk per block) entries -- the bound
+          // footprint_slide4 checks against the capacity of the list before it launches.
+          unsigned at = chunk_at + (unsigned)rank;
           if (n > chunk_left) {
-            fill_chunk();
+            const int old_left = chunk_left;
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
-            chunk_at = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            chunk_left = a.chunk;
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (rank >= old_left) at = base + (unsigned)(rank - old_left);
+            chunk_at = base - (unsigned)old_left;  // (+ n below: the entries of this row that went into the new chunk)
+            chunk_left = a.chunk + old_left;
           }
-          if (listed) a.blocked_list[chunk_at + (unsigned)__popcll(bm & ((1ull << lane) - 1ull))] = (unsigned)(mo + (size_t)j * a.rows + icol);
+          if (listed) a.blocked_list[at] = (unsigned)(mo + (size_t)j * a.rows + icol);
           chunk_at += (unsigned)n;
           chunk_left -= n;
           listed_total += n;
@@ -358,7 +366,7 @@ bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 4;
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
   if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;
-  static const int per_cu_env = getenv("TE_F4_BLOCKS_PER_CU") ? atoi(getenv("TE_F4_BLOCKS_PER_CU")) : 0;  // measurement aid
+  static const int per_cu_env = lab_int("TE_F4_BLOCKS_PER_CU", 0);  // measurement aid
   if (per_cu_env > 0 && per_cu_env < kF4Waves * 4) per_cu = per_cu_env;
   const int capacity = per_cu * device_cus();
   const int nz = a.map >= 0 ? 1 : (batch > 0 ? batch : 1);
@@ -369,12 +377,16 @@ bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   int sr = (H + strips - 1) / strips;
   // small maps cannot fill the wave slots: every resident block runs at once, so the launch takes one warm-up plus the
   // rows of one strip -- the shortest strips win (the spiral walks of a row are serial within its wavefront)
-  static const int min_strip = getenv("TE_F4_MIN_STRIP") ? atoi(getenv("TE_F4_MIN_STRIP")) : 1;
+  static const int min_strip = lab_int("TE_F4_MIN_STRIP", 1);
   sr = sr < min_strip ? min_strip : (sr > 512 ? 512 : sr);
   sr = sr < 1 ? 1 : sr;
   a.strip_rows = sr;
   a.chunk = sr >= 4 ? kF4Chunk : (sr * kLanes >= kF4Chunk / 2 ? kF4Chunk / 2 : kLanes);  // (a strip of one row lists at most 64 cells)
   const int nstrips = (H + sr - 1) / sr;
+  // every listed cell takes one entry and every block may leave one chunk unfinished (closed chunks are full): the list
+  // must hold both, whatever the grid (strips clamped to 512 rows on a very tall map or a small device: more blocks
+  // than one round of resident ones).  false: the double kernel serves.
+  if ((double)a.nbx_l * (double)nstrips * (double)nz * (double)a.chunk + (double)a.map_cells * (double)nz > (double)a.list_cap) return false;
   const dim3 grid((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz);
   if constexpr (kWholeCell) {
     if (a.n_ties != 0) {
@@ -667,11 +679,14 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
 
 }  // namespace
 
-// Entries of the list beyond one per cell: a block of k_fp_slide4 may leave up to kF4Chunk - 1 entries of its last
-// chunk unused, and a launch has at most (resident blocks + one row of blocks) of them (launch_f4).
-size_t f4_list_slack(int rows, int batch) {
-  const size_t nbx = (size_t)(rows + kLanes - 1) / kLanes;
-  return (size_t)kF4Chunk * ((size_t)kF4Waves * 4 * (size_t)device_cus() + 2 * nbx * (size_t)(batch > 0 ? batch : 1));
+// Entries of the list beyond one per cell: every block of k_fp_slide4 may leave one chunk unfinished, and a launch has
+// at most (resident blocks + one row of blocks) of them -- or, when the strips are clamped to 512 rows (a very tall
+// map, a small device), one block per 512 rows of every block column (launch_f4 checks the actual grid against it).
+size_t f4_list_slack(int rows, int cols, int batch) {
+  const size_t nbx = (size_t)(rows + kLanes - 1) / kLanes, nb = (size_t)(batch > 0 ? batch : 1);
+  const size_t one_round = (size_t)kF4Waves * 4 * (size_t)device_cus() + 2 * nbx * nb;
+  const size_t clamped = nbx * nb * ((size_t)(cols + 511) / 512 + 1);
+  return (size_t)kF4Chunk * (one_round > clamped ? one_round : clamped);
 }
 
 // The second half of a footprint pass that used k_fp_slide4: the listed cells (see the header).
@@ -696,10 +711,9 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
   a.r2 = p.fp_disc.r2;
   a.ax = g.ax;
   a.ay = g.ay;
-  static const char* path_env = getenv("TE_FB_PATH");  // "wave" / "lane": measurement aid, and how the tests reach both walks
-  a.path = path_env ? (path_env[0] == 'l' ? 2 : 1) : 0;
-  static const int per_cu = getenv("TE_FB_BLOCKS_PER_CU") ? atoi(getenv("TE_FB_BLOCKS_PER_CU")) : 24;  // 6 waves per SIMD: 77 registers (measurement aid)
-  hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)((per_cu > 0 ? per_cu : 24) * device_cus())), dim3(kLanes), 0, s, a);
+  a.path = L.fb_walk == 1 || L.fb_walk == 2 ? L.fb_walk : 0;  // te_set_option(TE_OPT_FP_BLOCKED_WALK): both walks give the same values
+  const int per_cu = L.fb_blocks_per_cu > 0 && L.fb_blocks_per_cu <= 32 ? L.fb_blocks_per_cu : 24;  // 6 waves per SIMD: 77 registers
+  hipLaunchKernelGGL(k_fp_blocked, dim3((unsigned)(per_cu * device_cus())), dim3(kLanes), 0, s, a);
 }
 
 // The fixed-point sliding-sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not
@@ -708,8 +722,8 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       double tcap, hipStream_t s, const Region* region, bool finish) {
   const Disc& d = p.fp_disc;
-  static const bool off = getenv("TE_NO_F4") != nullptr;
-  static const bool no_ties = getenv("TE_F4_NO_TIES") != nullptr;  // measurement aid: tie radii to the general kernel as before
+  static const bool off = lab_flag("TE_NO_F4");
+  static const bool no_ties = lab_flag("TE_F4_NO_TIES");  // measurement aid: tie radii to the general kernel as before
   // The shape the kernel slides: the disc itself, or for a tie radius the disc with its circle (whole-cell radii only:
   // every cell on the circle has the norm reach^2, and the runs plus the circle are the shape reach^2).
   int shape = d.Q, R = d.R;
@@ -723,8 +737,7 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   if (off || shape < 1 || R < 1 || p.reach != R || g.rows < kLanes || g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
   // 32-bit list entries, and room for every block's unfinished chunk
-  if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch + (double)f4_list_slack(g.rows, g.batch) > (double)L.fp_blocked_cap)
-    return false;
+  if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch > (double)L.fp_blocked_cap) return false;
   // the fixed-point scale: (2R+1) cells of at most cap * 2^k + 1/2 each must stay below 2^24 (the packed edge sums), and
   // the default value that replaces NaN has to fit as well
   if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
@@ -762,6 +775,7 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.inv_scale = ldexp(1.0, -k);
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
+  a.list_cap = L.fp_blocked_cap;
   bool launched = f4_launch_part0(shape, &a, g.batch, s);
 #if TE_PARTS > 1
   launched = launched || f4_launch_part1(shape, &a, g.batch, s) || f4_launch_part2(shape, &a, g.batch, s) || f4_launch_part3(shape, &a, g.batch, s) ||

@@ -3,12 +3,28 @@
 #include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
 #include "travgpu.h"
 
 namespace te {
+
+// Measurement switches: environment variables read once per process, in a LAB build only (-DTE_LAB: build.py --lab ->
+// libtravgpu_lab.so, which tools/ load through TRAVGPU_LIB).  In the shipped library they are compile-time constants:
+// nothing the product does depends on the environment.  (Choices between kernels with identical results that the tests
+// need to reach are part of the C-ABI instead: te_set_option.)
+#ifdef TE_LAB
+inline int lab_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline bool lab_flag(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr int lab_int(const char*, int dflt) { return dflt; }
+constexpr bool lab_flag(const char*) { return false; }
+#endif
 
 constexpr int kMaxRadiusCells = 32;  // largest stencil radius (in cells) a launch supports
 constexpr int kMaxTies = 32;         // offsets lying exactly on the circle (tie radii)
@@ -88,7 +104,7 @@ struct Layers {
   // second stream + fork/join events: step filter || normals kernel on whole-map runs (nullptr: sequential)
   hipStream_t aux_stream;
   hipEvent_t ev_fork, ev_join;
-  hipEvent_t ev_fp_fork, ev_fp_join;  // mask kernel of the lower half || sliding-sum kernel of the upper half (launch_footprint)
+  int fb_walk, fb_blocks_per_cu;  // te_set_option: k_fp_blocked's walk (0: by the length of the list, 1: per wavefront, 2: per lane) and grid (0: default)
   int sparse_holes;  // 1: at most a few per mille of the elevation cells are invalid (counted at upload): k_normals3 takes its sparse march
   char* hole_queue;  // its scratch: normals_hole_queue_bytes() (te_normals3.hip), nullptr: the dense march serves
 };
@@ -177,11 +193,10 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
 // spiral_table: [n_spiral][4] int16 {di, dj, ring, tie}; clip_table: build_clip_table(fp_disc, reach)
 // trav_cap: upper bound of the finite traversability values if the layer was written by the chain (see footprint_slide4), else < 0
 // region (nullptr: all maps, all cells): the cells whose scores changed; the mask is recomputed within 3 cells of them
-// and the footprint within the footprint's reach of those -- false is returned in *region_done if the kernels at hand
-// cannot restrict themselves to a region (the caller then runs the whole-map pass)
+// and the footprint within the footprint's reach of those (a footprint shape only the general kernel serves: on every cell)
 hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table,
                             const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream,
-                            const Region* region = nullptr, bool* region_done = nullptr);
+                            const Region* region = nullptr);
 int chain_max_reach(const ChainParams& p);
 // te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map;
 // robot_slope: the layer checkInclination reads (nullptr: footprint/check_robot_inclination off)
@@ -227,7 +242,7 @@ constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint dis
                                            // radius: the disc with the cells on its circle (k_fp_slide4<Q, true>)
 constexpr int kF4Chunk = 256;              // entries of the list a block reserves at a time
 constexpr unsigned kF4NoCell = 0xffffffffu;  // an unused entry
-size_t f4_list_slack(int rows, int batch);
+size_t f4_list_slack(int rows, int cols, int batch);
 // ... its second half: the cells whose disc holds an untraversable cell (finish = false above: the caller runs it, after
 // every k_fp_slide4 launch of the pass has completed)
 void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, hipStream_t s);

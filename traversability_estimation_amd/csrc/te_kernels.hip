@@ -600,8 +600,6 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream, &combined)) {
     na.combine = combined ? 1 : 0;
-    static const bool skip_fixup = getenv("TE_DEBUG_SKIP_FIXUP") != nullptr;  // measurement aid: what the march left undone
-    if (!skip_fixup)
     hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {

@@ -982,7 +982,7 @@ int resident_blocks(bool ties = false) {
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);
   if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
   if (ties && per_cu > kN3TieWaves * 4) per_cu = kN3TieWaves * 4;
-  static const int ov = getenv("TE_N3_BLOCKS_PER_CU") ? atoi(getenv("TE_N3_BLOCKS_PER_CU")) : 0;  // measurement aid
+  static const int ov = lab_int("TE_N3_BLOCKS_PER_CU", 0);  // measurement aid
   if (ov > 0) per_cu = ov < kN3Waves * 4 ? ov : kN3Waves * 4;  // (the hole queues are allocated for kN3Waves * 4 per CU)
   return per_cu * device_cus();
 }
@@ -1003,8 +1003,8 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int n_bottom = a.j_hi > a.jf_hi ? a.n_int : 0;
   const int Hf = a.jf_hi - a.jf_lo;
   int rows_int = 512;
-  static const char* ev = getenv("TE_N3_EDGE_PERCENT");  // measurement aid: strip height of the edge columns in percent
-  const int pct = ev && atoi(ev) > 0 ? atoi(ev) : 50;
+  static const int pct_env = lab_int("TE_N3_EDGE_PERCENT", 50);  // measurement aid: strip height of the edge columns in percent
+  const int pct = pct_env > 0 ? pct_env : 50;
   auto edge_rows = [&](int h) { return (pct * h + 99) / 100; };
   for (int h = 8; h <= 512; ++h) {  // smallest strip height whose block count fits (small maps: short strips, low latency)
     const int he = edge_rows(h);
@@ -1032,9 +1032,14 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
     return false;
   }
   // (the kernel that keeps the normals -- the plugin path -- exists with the dense march only)
+  // The sparse march indexes its queue scratch by block (blockIdx.x + gridDim.x * blockIdx.z) and the scratch holds one
+  // queue per RESIDENT block of the device (normals_hole_queue_bytes): a grid that did not fit one round -- no strip
+  // height up to 512 rows fits `capacity` on a large batch, a very large map or a small / partitioned device -- has more
+  // blocks than queues and takes the dense march, which needs no scratch.
+  const bool queues_fit = (long long)nblocks * (long long)(maps > 0 ? maps : 1) <= (long long)(kN3Waves * 4) * (long long)device_cus();
   if (keep)
     hipLaunchKernelGGL((k_normals3<Q, true, 2>), grid, dim3(kLanes), 0, s, a);
-  else if (a.sparse_holes)
+  else if (a.sparse_holes && queues_fit)
     hipLaunchKernelGGL((k_normals3<Q, false, 1>), grid, dim3(kLanes), 0, s, a);
   else
     hipLaunchKernelGGL((k_normals3<Q, false, 2>), grid, dim3(kLanes), 0, s, a);
@@ -1113,7 +1118,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   // on the circle has the norm reach^2, the runs plus the circle are the shape reach^2)
   int shape = d.Q, R = d.R;
   if (d.n_ties != 0) {
-    static const bool no_ties = getenv("TE_N3_NO_TIES") != nullptr;  // measurement aid: tie radii to the generic kernel as before
+    static const bool no_ties = lab_flag("TE_N3_NO_TIES");  // measurement aid: tie radii to the generic kernel as before
     R = d.reach;
     shape = R * R;
     if (no_ties) return false;

@@ -129,7 +129,7 @@ struct te_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fp_fork = nullptr, ev_fp_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   te_params params;
   bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
   float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
@@ -152,6 +152,12 @@ struct te_ctx {
   // the traversability layer was written from outside (upload, device pointer, a per-plugin combine of uploaded scores):
   // its values are then not bounded by the weights, and the fixed-point footprint kernel must not be used
   bool trav_external = false;
+  // te_device_ptr handed out the traversability layer: the caller may write it at any time from then on, so only a
+  // footprint pass that runs right behind a chain that rewrote EVERY cell (te_run_chain with the footprint flag) may
+  // still assume the bound; te_run_footprint and region runs take the double kernel.  Reset with the layers.
+  bool trav_ptr_out = false;
+  // te_set_option: choices between kernels that give identical results (tests reach both; never read from the environment)
+  int opt_fb_walk = 0, opt_fb_blocks_per_cu = 0, opt_polygon_per_cell = 0;
   // invalid cells of the elevation layer as of the last whole upload (-1: unknown -- tiles, device pointer): see sparse_holes()
   long long invalid_cells = -1;
   unsigned long long* d_count = nullptr;
@@ -205,7 +211,7 @@ int count_invalid_elevation(te_ctx* c) {
 // (A map without invalid cells takes the dense kernel too: its clean march is the same code, and a tile with invalid
 // cells uploaded later -- tiles are not counted -- is then in safe hands.)
 bool sparse_holes(const te_ctx* c) {
-  static const int force = getenv("TE_N3_HOLES") ? atoi(getenv("TE_N3_HOLES")) : 0;  // measurement aid: 1 sparse, 2 dense
+  static const int force = lab_int("TE_N3_HOLES", 0);  // measurement aid: 1 sparse, 2 dense
   if (force == 1 || force == 2) return force == 1;
   return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems;
 }
@@ -448,6 +454,7 @@ void free_layers(te_ctx* c) {
   c->have_robot_slope = false;
   memset(&c->L, 0, sizeof(c->L));
   c->layer_elems = 0;
+  c->trav_ptr_out = false;
   c->have_elev = false;
   c->chain_done = false;
   c->footprint_done = false;
@@ -500,7 +507,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   // Two streams (step filter || normals kernel) pay from about 2^21 cells: below that the launch is a handful of
   // short kernels and the fork / join events cost more than the overlap gains -- one stream, the combine fused into the
   // normals kernel (MI355X, R = 5, chain: 256^2 0.045 -> 0.030 ms, 512^2 0.042 -> 0.032, 1024^2 0.052 -> 0.046, 2048^2 equal).
-  static const bool force_two = getenv("TE_TWO_STREAMS") != nullptr;  // measurement aid
+  static const bool force_two = lab_flag("TE_TWO_STREAMS");  // measurement aid
   const bool small = !force_two && (size_t)c->geo.rows * c->geo.cols * c->geo.batch < ((size_t)1 << 21);
   c->L.aux_stream = ((flags & TE_RUN_SEQUENTIAL) || small) ? nullptr : c->aux_stream;
   // whole-map run with the footprint pass right behind: the mask kernel writes the combined layer
@@ -513,8 +520,8 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   if (c->combine_deferred) flags |= kDeferCombine;
   c->L.ev_fork = c->ev_fork;
   c->L.ev_join = c->ev_join;
-  c->L.ev_fp_fork = c->ev_fp_fork;
-  c->L.ev_fp_join = c->ev_fp_join;
+  c->L.fb_walk = c->opt_fb_walk;
+  c->L.fb_blocks_per_cu = c->opt_fb_blocks_per_cu;
   c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
   c->L.hole_queue = c->hole_queue;
   ensure_tie_scratch(c);  // (likewise)
@@ -526,14 +533,15 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   return TE_OK;
 }
 
-int run_footprint_locked(te_ctx* c, unsigned flags) {
+// fresh: called right behind a whole-map chain in the same entry point (the combined layer is the chain's, cell for cell)
+int run_footprint_locked(te_ctx* c, unsigned flags, bool fresh = false) {
   if (!c->chain_done || !c->tables_ready)
     return fail(TE_ERR_NOT_READY, "te_run_footprint: run the filter chain first (it produces the layers the footprint reads)");
   if (!c->fp_tables_ready) return fail(c->fp_tables_rc ? c->fp_tables_rc : TE_ERR_NOT_READY, "%s", c->fp_tables_err);
   HIP_TRY(hipSetDevice(c->device));
   // bound of the combined layer, if the chain wrote it: scores lie in [0, 1], so w_scale * (w_slope + w_step + w_rough)
   const ChainParams& q = c->cp;
-  const bool bounded = !c->trav_external && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
+  const bool bounded = !c->trav_external && (fresh || !c->trav_ptr_out) && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
   const double trav_cap = bounded ? (double)q.w_scale * ((double)q.w_slope + (double)q.w_step + (double)q.w_rough) : -1.0;
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0,
                            c->combine_deferred ? &c->cp : nullptr, trav_cap, c->stream));
@@ -548,7 +556,7 @@ int run_footprint_locked(te_ctx* c, unsigned flags) {
 // capture problem switches the context back to direct launches for good.
 int run_whole_locked(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
-  static const bool no_graph = getenv("TE_NO_GRAPH") != nullptr;
+  static const bool no_graph = lab_flag("TE_NO_GRAPH");
   const bool large = (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23);
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
   if (!no_graph && large && !(flags & TE_RUN_NORMALS_ONLY) && c->graph_ok && c->have_params && c->have_geo && c->have_elev) {
@@ -573,7 +581,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
       hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
       if (e == hipSuccess) {
         rc = run_chain_locked(c, flags, r);
-        if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags);
+        if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags, true);
         e = hipStreamEndCapture(c->stream, &graph);
       }
       if (e == hipSuccess && rc == TE_OK && graph) e = hipGraphInstantiate(&c->graph_exec[slot], graph, nullptr, nullptr, 0);
@@ -589,6 +597,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     }
     if (slot >= 0) {
       HIP_TRY(hipGraphLaunch(c->graph_exec[slot], c->stream));
+      c->trav_external = false;  // (as run_chain_locked: every cell of the combined layer now comes from the chain)
       c->chain_done = true;
       c->footprint_done = (flags & TE_RUN_FOOTPRINT) != 0;
       c->combine_deferred = false;
@@ -596,7 +605,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     }
   }
   int rc = run_chain_locked(c, flags, r);
-  if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags);
+  if (!rc && (flags & TE_RUN_FOOTPRINT)) rc = run_footprint_locked(c, flags, true);
   return rc;
 }
 
@@ -707,8 +716,6 @@ int te_create(int device, te_ctx** out) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fp_fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fp_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
     return fail(TE_ERR_HIP, "te_create: %s", hipGetErrorString(e));
@@ -734,8 +741,6 @@ int te_destroy(te_ctx* c) {
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_fp_fork) (void)hipEventDestroy(c->ev_fp_fork);
-    if (c->ev_fp_join) (void)hipEventDestroy(c->ev_fp_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     for (hipStream_t st : {c->in_stream, c->out_stream})
       if (st) {
@@ -774,6 +779,28 @@ int te_set_params(te_ctx* c, const te_params* p) {
   return TE_OK;
 }
 
+int te_set_option(te_ctx* c, int option, int value) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_option: NULL ctx");
+  std::lock_guard<std::mutex> lk(c->mu);
+  switch (option) {
+    case TE_OPT_FP_BLOCKED_WALK:
+      if (value < 0 || value > 2) return fail(TE_ERR_INVALID_ARG, "te_set_option: TE_OPT_FP_BLOCKED_WALK takes 0 (by list length), 1 (per wavefront), 2 (per lane)");
+      c->opt_fb_walk = value;
+      break;
+    case TE_OPT_FP_BLOCKED_BLOCKS_PER_CU:
+      if (value < 0 || value > 32) return fail(TE_ERR_INVALID_ARG, "te_set_option: TE_OPT_FP_BLOCKED_BLOCKS_PER_CU takes 0 (default) .. 32");
+      c->opt_fb_blocks_per_cu = value;
+      break;
+    case TE_OPT_POLYGON_PER_CELL:
+      c->opt_polygon_per_cell = value != 0;
+      break;
+    default:
+      return fail(TE_ERR_INVALID_ARG, "te_set_option: unknown option %d", option);
+  }
+  drop_graph(c);  // (captured launches bake the choice in)
+  return TE_OK;
+}
+
 int te_get_params(te_ctx* c, te_params* p) {
   if (!c || !p) return fail(TE_ERR_INVALID_ARG, "te_get_params: NULL");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -805,7 +832,7 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     const size_t fb = ((size_t)fast::normals_fast_max_blocks(gtmp) * sizeof(int) + 255) & ~(size_t)255;
     // (+ the footprint pass's list of cells with an untraversable cell in their disc: one 32-bit entry per cell at
     // most, and its counter)
-    const size_t list_cap = elems + fast::f4_list_slack(rows, batch);
+    const size_t list_cap = elems + fast::f4_list_slack(rows, cols, batch);
     const size_t qb = (list_cap * sizeof(unsigned) + 255) & ~(size_t)255;
     const size_t total = 13 * lb + ub + fb + qb + 256;
     hipError_t e = hipMalloc(&slab, total);
@@ -875,6 +902,7 @@ int te_upload_tile(te_ctx* c, const float* host_tile, int map, int row0, int col
                            (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_elev = true;
+  c->invalid_cells = -1;  // tiles are not counted: the count of the last whole upload says nothing about them (dense march)
   return TE_OK;
 }
 
@@ -949,6 +977,7 @@ int te_upload_tile_async(te_ctx* c, const float* host_tile, int map, int row0, i
   sl.used = true;
   c->tiles_pending = true;
   c->have_elev = true;
+  c->invalid_cells = -1;  // (as te_upload_tile)
   return TE_OK;
 }
 
@@ -989,7 +1018,7 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
   *dptr = p;
   if (bytes) *bytes = c->layer_elems * sizeof(float);
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
   if (layer == TE_LAYER_ELEVATION) {  // caller fills the elevation in place (zero-copy producer)
     c->invalid_cells = -1;
     c->have_elev = true;
@@ -1023,7 +1052,7 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
   HIP_TRY(hipMemcpyAsync(p + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
   return TE_OK;
 }
 
@@ -1086,7 +1115,7 @@ static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host
     c->footprint_done = false;
   }
   if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = true;
+  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
   return TE_OK;
 }
 
@@ -1282,11 +1311,10 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
   changed.i1 = r.i1 + grow > c->geo.rows ? c->geo.rows : r.i1 + grow;
   changed.j1 = r.j1 + grow > c->geo.cols ? c->geo.cols : r.j1 + grow;
   const ChainParams& q = c->cp;
-  const bool bounded = !c->trav_external && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
+  const bool bounded = !c->trav_external && !c->trav_ptr_out && q.w_scale >= 0.0f && q.w_slope >= 0.0f && q.w_step >= 0.0f && q.w_rough >= 0.0f;
   const double trav_cap = bounded ? (double)q.w_scale * ((double)q.w_slope + (double)q.w_step + (double)q.w_rough) : -1.0;
-  bool region_done = false;
   HIP_TRY(launch_footprint(c->geo, c->fp, c->L, c->d_spiral, c->fp_clip_table, (flags & TE_RUN_FOOTPRINT_MEMO) != 0, nullptr, trav_cap,
-                           c->stream, &changed, &region_done));
+                           c->stream, &changed));
   c->footprint_done = true;  // complete before, refreshed where it could change
   return TE_OK;
 }
@@ -1407,13 +1435,12 @@ int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, d
   a.def = c->params.fp_default;
   rotate_footprint(n_points, points_xy, 0.0, a.off[0]);
   rotate_footprint(n_points, points_xy, yaw, a.off[1]);
-  // offset tables (te_polygon.hip); polygons that do not fit the table format, or TE_POLYGON_PER_CELL=1 (a debugging
+  // offset tables (te_polygon.hip); polygons that do not fit the table format, or te_set_option(TE_OPT_POLYGON_PER_CELL) (a debugging
   // aid: both kernels give identical layers), take the kernel that evaluates every cell of every bounding box
   PolygonTables tabs;
   HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's table upload has been consumed
   c->poly_stream_host.clear();
-  const char* per_cell = getenv("TE_POLYGON_PER_CELL");
-  bool table = !(per_cell && per_cell[0] == '1');
+  bool table = !c->opt_polygon_per_cell;
   for (int w = 0; w < 2 && table; ++w) table = build_polygon_table(c->geo, n_points, a.off[w], c->poly_stream_host, tabs.t[w]);
   if (!table) {
     HIP_TRY(launch_polygon_footprint(c->geo, a, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot, c->stream));
@@ -1684,7 +1711,7 @@ int te_sync(te_ctx* c) {
   // A blocking hipStreamSynchronize parks the thread and is woken by an interrupt; for the launches of this library
   // (a few hundred microseconds) that wake-up is a visible part of the latency, so the stream is polled first
   // (TE_SYNC_SPIN_US microseconds, default 2000; 0: block at once).
-  static const long spin_us = getenv("TE_SYNC_SPIN_US") ? atol(getenv("TE_SYNC_SPIN_US")) : 2000;
+  static const long spin_us = lab_int("TE_SYNC_SPIN_US", 2000);
   if (spin_us > 0) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {

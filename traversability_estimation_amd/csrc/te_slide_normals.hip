@@ -494,7 +494,7 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
                   const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s, bool* combined) {
   const Disc& d = p.normals;
   if (d.n_ties != 0) {  // a tie radius: k_normals3's TIES march or nothing
-    static const bool no_n3_ties = getenv("TE_NO_N3") != nullptr;
+    static const bool no_n3_ties = lab_flag("TE_NO_N3");
     if (no_n3_ties || !gtab || g.rows < 2 * d.reach + 1 || g.cols < 2 * d.reach + 1) return false;
     fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
     fg->nty = (r.j1 - r.j0 + 15) / 16;
@@ -537,7 +537,7 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.gtab = gtab;
   if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
   // cells whose disc lies inside the map: k_normals3 (3 waves per SIMD); this file keeps the frame
-  static const bool no_n3 = getenv("TE_NO_N3") != nullptr;
+  static const bool no_n3 = lab_flag("TE_NO_N3");
   fg->frame = 0;
   if (!no_n3 && normals_fast3(g, p, L, keep_normals, r, flags, fg, s)) {
     *combined = false;  // k_normals3 does not combine: the caller runs k_combine (or the footprint mask kernel does)
