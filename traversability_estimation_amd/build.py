@@ -15,8 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
-HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
+SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
+HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")
 OBJDIR = os.path.join(_HERE, "_build")
@@ -29,7 +29,7 @@ _SINGLE_DS_READS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", 
 EXTRA_CFLAGS = {"csrc/te_normals3.hip": _SINGLE_DS_READS, "csrc/te_footprint3.hip": _SINGLE_DS_READS}
 # sources compiled in several parts (-DTE_PARTS=n -DTE_PART=k, one object each): their shape-specialised kernels take
 # minutes in one translation unit, and the parts compile side by side
-PARTS = {"csrc/te_normals3.hip": 6, "csrc/te_footprint3.hip": 5, "csrc/te_footprint4.hip": 5}
+PARTS = {"csrc/te_normals3.hip": 6, "csrc/te_footprint3.hip": 5, "csrc/te_footprint4.hip": 5, "csrc/te_footprint5.hip": 5}
 
 
 def hipcc():

@@ -427,6 +427,8 @@ dim3 cell_grid(const Geo& g, const Region& r) {
 }  // namespace
 
 bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s) {
+  static const bool old_step = lab_flag("TE_OLD_STEP");  // measurement aid: the round-1 marching kernels of this file
+  if (!old_step) return step_height5(Q, g, elev, sh, nullptr, r, s);
   if (r.i1 - r.i0 < kLanes) return false;  // the blocks are 64 cells wide and never mask a lane (the last one is shifted)
   switch (Q) {
 #define X(q) \
@@ -445,16 +447,21 @@ bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh,
   int q = 0;
   TieArgs t;
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
+  static const bool old_step = lab_flag("TE_OLD_STEP");
   bool ok = false;
-  switch (q) {
+  if (!old_step) {
+    ok = step_height5(q, g, elev, sh, scratch, r, s);
+  } else {
+    switch (q) {
 #define X(q_) \
   case q_:    \
     ok = launch_height<q_>(g, elev, sh, r, s, scratch); \
     break;
-    TE_DISC_SHAPES(X)
+      TE_DISC_SHAPES(X)
 #undef X
-    default:
-      break;
+      default:
+        break;
+    }
   }
   if (!ok) return false;
   hipLaunchKernelGGL(k_step_height_ties, cell_grid(g, r), dim3(256), 0, s, g, t, elev, sh, (const float*)scratch, r);
@@ -463,6 +470,8 @@ bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh,
 
 bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
                      hipStream_t s) {
+  static const bool old_step = lab_flag("TE_OLD_STEP");
+  if (!old_step) return step_score5(Q, g, crit, ncrit, sh, out, nullptr, r, s);
   if (r.i1 - r.i0 < kLanes) return false;
   // largest float <= crit
   float lo = (float)crit;
@@ -486,16 +495,21 @@ bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const 
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
   float lo = (float)crit;
   if ((double)lo > crit) lo = nextafterf(lo, -INFINITY);
+  static const bool old_step = lab_flag("TE_OLD_STEP");
   bool ok = false;
-  switch (q) {
+  if (!old_step) {
+    ok = step_score5(q, g, crit, ncrit, sh, out, scratch, r, s);
+  } else {
+    switch (q) {
 #define X(q_) \
   case q_:    \
     ok = launch_score<q_>(g, crit, lo, ncrit, sh, out, r, s, scratch); \
     break;
-    TE_DISC_SHAPES(X)
+      TE_DISC_SHAPES(X)
 #undef X
-    default:
-      break;
+      default:
+        break;
+    }
   }
   if (!ok) return false;
   hipLaunchKernelGGL(k_step_score_ties, cell_grid(g, r), dim3(256), 0, s, g, t, crit, lo, ncrit, sh, out, (const float*)scratch, r);

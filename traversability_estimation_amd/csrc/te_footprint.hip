@@ -1031,7 +1031,15 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   a.rmax = p.rmax;
   a.def = p.def;
   a.inner_q = fast::footprint_inner_q(g.res, p.rmin, p.rmax);
-  // tie-free disc of an instantiated shape on a map at least one block wide: the k_normals3-style kernel
+  // tie-free disc of an instantiated shape on a map at least one block wide: the scatter-form sum on fixed point, ...
+  {
+    bool needs_blocked = false;
+    if (fast::footprint_slide5(g, p, L, clip_table, trav_cap, stream, rfp, &needs_blocked)) {
+      if (needs_blocked) fast::footprint_blocked4(g, p, L, spiral_table, stream);
+      return hipGetLastError();
+    }
+  }
+  // ... the sliding sum on fixed point (tie radii; radii of 16 cells), the sliding sum in double (unbounded layers)
   if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, rfp) ||
       fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, rfp))
     return hipGetLastError();

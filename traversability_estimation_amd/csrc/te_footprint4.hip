@@ -684,7 +684,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
 // map, a small device), one block per 512 rows of every block column (launch_f4 checks the actual grid against it).
 size_t f4_list_slack(int rows, int cols, int batch) {
   const size_t nbx = (size_t)(rows + kLanes - 1) / kLanes, nb = (size_t)(batch > 0 ? batch : 1);
-  const size_t one_round = (size_t)kF4Waves * 4 * (size_t)device_cus() + 2 * nbx * nb;
+  const size_t one_round = (size_t)32 * (size_t)device_cus() + 2 * nbx * nb;  // (up to 8 waves per SIMD: k_fp_slide5 runs at 5)
   const size_t clamped = nbx * nb * ((size_t)(cols + 511) / 512 + 1);
   return (size_t)kF4Chunk * (one_round > clamped ? one_round : clamped);
 }

@@ -1,0 +1,394 @@
+// te_footprint5.hip -- the sum of the circular footprint pass in SCATTER form (te_march5.h), 32-bit fixed point.
+//
+//   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
+//     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
+//
+// k_fp_slide4 (te_footprint4.hip) SLIDES the disc sum: 2(2R+1) LDS reads per row from a ring of 2R+2 rows (6.5 KB per
+// wave: 4 waves per SIMD) and is bound by those reads (ds_read2_b32: 4 LDS cycles each, SQ_WAIT_INST_LDS 29 %).  A sum
+// can be folded like the step filter's maxima instead: every row is reduced ONCE along i into its nested run sums
+// (2R reads, R v_add3_u32) and the run sum of the matching half-width is added to each of the 2R+1 pending output rows.
+// Half the LDS instructions, two rows of LDS per wave instead of twenty, under 96 registers: 5 waves per SIMD.
+// A cell is one word
+//     cell = round(T' * 2^k) | U << 27        T' = traversability (NaN -> default), U = 1: fails isTraversableForFilters
+// with k chosen by the host such that the T-sum of a whole disc stays below 2^27 (k = 19 at R = 9, as in k_fp_slide4:
+// the two kernels give the same bits).  A run sum holds at most 2R+1 <= 31 cells and cannot overflow 32 bits; the
+// accumulators add with SATURATION (v_add_u32 ... clamp), so a disc's word is
+//     < 2^27:  no untraversable cell, and the word IS the exact T-sum  ->  mean = T * 2^-k / n   (:732-735)
+//     >= 2^27: at least one untraversable cell (however many: the sum sticks at 2^32 - 1 instead of wrapping)
+// and nothing else is needed from it: a disc with an untraversable cell is 0 if that cell is its own centre or the
+// inner radius is 0 (:694-704); otherwise its cell goes onto the list k_fp_blocked walks afterwards (te_footprint4.hip),
+// exactly as k_fp_slide4 does.  Tie radii (cells exactly on the circle, decided per centre) stay with k_fp_slide4<Q, true>.
+#include "te_internal.h"
+#include "te_march5.h"
+
+#include <type_traits>
+
+namespace te {
+namespace fast {
+
+namespace {
+
+constexpr int kF5Waves = 5;
+constexpr int kF5UBit = 27;
+
+struct F5Args {
+  const float* trav;
+  const uint8_t* untrav;
+  float* footprint;
+  int rows, cols;
+  long long map_cells;
+  int strip_rows;
+  // the part of the map this launch covers: block columns [bx0, bx0 + nbx_l), output rows [j_lo, j_hi), map (< 0: blockIdx.z)
+  int bx0, nbx_l, j_lo, j_hi, map;
+  const int* gtab;  // clip table of the disc: {n, ...} per (ky, kx)
+  double rmin;      // inner radius: 0 makes every disc with an untraversable cell 0 (:694-704), no walk needed
+  float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 27, scale = 2^k
+  double inv_scale;    // 2^-k
+  unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
+  unsigned* blocked_count;  // ... [0] entries reserved, [1] entries that hold a cell (k_fp_mask resets both)
+  int chunk;                // entries a block reserves at a time
+  size_t list_cap;          // (host side: the launcher refuses a grid whose unfinished chunks might not fit)
+};
+
+template <int Q>
+struct SlideK {
+  static constexpr int R = Shape<Q>::R, W = kLanes + 2 * R, C = 2;
+  typedef unsigned Acc;
+  typedef unsigned Run;
+  const F5Args& a;
+  M5Lane<R> L;   // float layers
+  unsigned ob_main0, ob_main1, ob_halo;  // the same offsets in the byte layer
+  brsrc rs_t, rs_u, rs_out;       // window column 0 of map row js - R (inputs) / js - 2R (output)
+  unsigned row_bytes;
+  int js, nout, r0;               // r0 = js - R: the strip's first input row (the descriptors' row 0)
+  float tm0[C], tm1[C], th[C];
+  unsigned um0[C], um1[C], uh[C];
+  unsigned* lds;   // [2][W]
+  unsigned c0, c1;
+  unsigned ubits;  // my own cells' U, newest row in bit 0
+  size_t mo;
+  int icol, kx, nt_mid;
+  bool own, rmin_zero;
+  float rnt;
+  // the list
+  unsigned chunk_at;
+  int chunk_left, listed_total;
+
+  __device__ __forceinline__ SlideK(const F5Args& a_) : a(a_) {}
+
+  __device__ __forceinline__ void init(int lane, int i0, int own_lo, int js_, int jend, size_t mo_, unsigned* lds_) {
+    L.init(lane, i0, a.rows);
+    ob_main0 = L.o_main0 / 4u;
+    ob_main1 = L.o_main1 / 4u;
+    ob_halo = L.o_halo / 4u;
+    js = js_;
+    nout = jend - js_;
+    mo = mo_;
+    lds = lds_;
+    r0 = js_ - R;
+    row_bytes = (unsigned)a.rows * 4u;
+    rs_t = make_rsrc(a.trav + mo + ((long long)(js_ - R) * a.rows + (i0 - R)));
+    rs_u = make_rsrc(a.untrav + mo + ((long long)(js_ - R) * a.rows + (i0 - R)));
+    rs_out = make_rsrc(a.footprint + mo + ((long long)(js_ - 2 * R) * a.rows + (i0 - R)));
+    icol = i0 + lane;
+    own = icol >= own_lo;
+    rmin_zero = a.rmin == 0.0;
+    kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
+    nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
+    rnt = (float)(a.inv_scale / (double)nt_mid);
+    ubits = 0;
+    chunk_at = 0;
+    chunk_left = 0;
+    listed_total = 0;
+  }
+  // (unconditional: see Step5Base::load_pair in te_step5.hip and kSlabGuardRows)
+  template <int q>
+  __device__ __forceinline__ void load_pair(int r, ic<q>) {
+    const unsigned sb = (unsigned)(r - r0) * (unsigned)a.rows, so = sb * 4u;  // (uniform; the mask is one byte per cell)
+    tm0[q] = bload_f(rs_t, L.o_main0, so);
+    tm1[q] = bload_f(rs_t, L.o_main1, so);
+    th[q] = bload_f(rs_t, L.o_halo, so);
+    um0[q] = bload_u8(rs_u, ob_main0, sb);
+    um1[q] = bload_u8(rs_u, ob_main1, sb);
+    uh[q] = bload_u8(rs_u, ob_halo, sb);
+  }
+  template <int n>
+  __device__ __forceinline__ void rotate_queue(ic<n>) {
+    if constexpr (n % C != 0) {
+      static_assert(C == 2, "a queue of two passes");
+      const float f0 = tm0[0], f1 = tm1[0], fh = th[0];
+      const unsigned u0 = um0[0], u1 = um1[0], u2 = uh[0];
+      tm0[0] = tm0[1];
+      tm1[0] = tm1[1];
+      th[0] = th[1];
+      um0[0] = um0[1];
+      um1[0] = um1[1];
+      uh[0] = uh[1];
+      tm0[1] = f0;
+      tm1[1] = f1;
+      th[1] = fh;
+      um0[1] = u0;
+      um1[1] = u1;
+      uh[1] = u2;
+    }
+  }
+  __device__ __forceinline__ unsigned pack(float t, unsigned u) const {
+    const float tt = __builtin_isfinite(t) ? t : a.def;  // :719-724
+    // round(T' * 2^k): the product is exact, + 0.5 is exact below 2^23, the conversion truncates (and clamps at 0)
+    return (unsigned)__builtin_fmaf(tt, a.scale, 0.5f) | (u << kF5UBit);
+  }
+  template <int q>
+  __device__ __forceinline__ void stage_pair(int r, ic<q>) {
+    c0 = pack(tm0[q], um0[q]);
+    c1 = pack(tm1[q], um1[q]);
+    unsigned vh = L.halo_in ? pack(th[q], uh[q]) : 0u;  // cells outside the map: nothing
+    unsigned u0 = um0[q], u1 = um1[q];
+    if (__builtin_expect((unsigned)r >= (unsigned)(a.cols - 1), 0)) {  // a row of the pass outside the map
+      const bool in0 = (unsigned)r < (unsigned)a.cols, in1 = (unsigned)(r + 1) < (unsigned)a.cols;
+      c0 = in0 ? c0 : 0u;
+      c1 = in1 ? c1 : 0u;
+      u0 = in0 ? u0 : 0u;
+      u1 = in1 ? u1 : 0u;
+      vh = (L.hrow ? in1 : in0) ? vh : 0u;
+    }
+    lds[R + L.lane] = c0;
+    lds[W + R + L.lane] = c1;
+    lds[L.hlds] = vh;
+    ubits = (ubits << 2) | (u0 << 1) | u1;
+  }
+  template <int slot>
+  __device__ __forceinline__ void build(ic<slot>, Run (&s)[R + 1]) {
+    const unsigned* row = lds + slot * W + R + L.lane;
+    s[0] = slot ? c1 : c0;
+    static_for<R>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value + 1;
+      s[d] = s[d - 1] + row[-d] + row[d];  // (at most 2R+1 <= 31 cells: no overflow)
+    });
+  }
+  __device__ __forceinline__ void reset(Acc& x) { x = 0u; }
+  template <int E, int ROW>
+  __device__ __forceinline__ void start(Acc& x, const Run& s) {
+    x = s;
+  }
+  template <int E>
+  __device__ __forceinline__ void fold1(Acc& x, const Run& s) {
+    x = __builtin_elementwise_add_sat(x, s);
+  }
+  template <int E>
+  __device__ __forceinline__ void fold2(Acc& x, const Run& s1, const Run& s2) {
+    x = __builtin_elementwise_add_sat(__builtin_elementwise_add_sat(x, s1), s2);
+  }
+  __device__ __forceinline__ void fill_chunk() {
+    for (int q = L.lane; q < chunk_left; q += kLanes) a.blocked_list[chunk_at + (unsigned)q] = kF4NoCell;
+  }
+  template <int second>
+  __device__ __forceinline__ void emit(ic<second>, int j, const Acc& x) {
+    if (!((unsigned)(j - js) < (unsigned)nout)) return;  // (uniform)
+    float rn = rnt;
+    if (__builtin_expect((unsigned)(j - R) >= (unsigned)(a.cols - 2 * R), 0)) {  // a row of the top / bottom frame (uniform)
+      const int ky = j < R ? R - j : -(R - (a.cols - 1 - j));
+      const int nt = a.gtab[((ky + R) * (2 * R + 1) + (kx + R)) * 6];
+      rn = (float)(a.inv_scale / (double)nt);
+    }
+    float out = (float)x * rn;  // :732-735 no untraversable cell in the footprint: the mean (T < 2^27: the conversion is good to 2^-25)
+    const bool blocked = x >= (1u << kF5UBit);
+    const unsigned so = (unsigned)(j - (r0 - R)) * row_bytes;
+    if (__builtin_expect(__any(blocked), 0)) {
+      if (rmin_zero) {
+        out = blocked ? 0.0f : out;  // :694-704 radiusMin = 0: the first untraversable cell, wherever it lies, gives 0
+      } else {
+        // An untraversable centre cell is the spiral's first cell: 0 (ring 0 lies within any inner radius > 0, :694-704).
+        // My own cell of row j: the rows of this pass are bits 1 and 0 of ubits, row j is R rows above the one that
+        // completed it.  The other discs with an untraversable cell go onto the list: k_fp_blocked walks their spirals
+        // and stores their values after this kernel; nothing is stored for them here -- not by the block that lists them
+        // and not by a shifted last block that shares the column (on a region run its neighbour need not be part of
+        // the launch, and the cell then keeps the value it has).
+        const bool self = ((ubits >> (second ? R : R + 1)) & 1u) != 0u;
+        out = (blocked && self) ? 0.0f : out;
+        const bool walk = blocked && !self;
+        const bool listed = walk && own;
+        const unsigned long long bm = __ballot(listed);
+        if (bm != 0ull) {
+          const int n = __popcll(bm);
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+          // a row that does not fit the rest of the chunk fills it to the last entry and continues in a new one: every
+          // closed chunk is full, so a launch reserves at most (listed cells + one chunk per block) entries
+          unsigned at = chunk_at + (unsigned)rank;
+          if (n > chunk_left) {
+            const int old_left = chunk_left;
+            unsigned base = 0;
+            if (L.lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (rank >= old_left) at = base + (unsigned)(rank - old_left);
+            chunk_at = base - (unsigned)old_left;
+            chunk_left = a.chunk + old_left;
+          }
+          if (listed) a.blocked_list[at] = (unsigned)(mo + (size_t)j * a.rows + icol);
+          chunk_at += (unsigned)n;
+          chunk_left -= n;
+          listed_total += n;
+        }
+        if (!walk) bstore_f(rs_out, L.o_main0, so, out);
+        return;
+      }
+    }
+    // (a shifted last block stores the columns it shares with its neighbour too: the same bits)
+    bstore_f(rs_out, L.o_main0, so, out);
+  }
+  __device__ __forceinline__ void finish() {
+    fill_chunk();
+    if (listed_total != 0 && L.lane == 0) atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
+  }
+};
+
+template <int Q>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF5Waves, kF5Waves))) void k_fp_slide5(F5Args a) {
+  constexpr int R = Shape<Q>::R, W = kLanes + 2 * R;
+  __shared__ unsigned lds[2 * W];
+  const int lane = threadIdx.x;
+  const int bx = a.bx0 + (int)blockIdx.x % a.nbx_l, strip = (int)blockIdx.x / a.nbx_l;
+  int i0 = bx * kLanes;
+  i0 = i0 + kLanes > a.rows ? a.rows - kLanes : i0;  // the last block ends at the map edge (rows >= 64)
+  const int js = a.j_lo + strip * a.strip_rows;
+  if (js >= a.j_hi) return;
+  const int jend = js + a.strip_rows < a.j_hi ? js + a.strip_rows : a.j_hi;
+  const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
+  SlideK<Q> k(a);
+  // the last block of a row of blocks is shifted left: the columns it shares with its neighbour are the neighbour's
+  // (one list entry per cell; both store the same value)
+  k.init(lane, i0, bx * kLanes, js, jend, mo, lds);
+  march5<Q>(k, js, jend);
+  k.finish();
+}
+
+template <int Q>
+bool launch_f5(const F5Args& a0, int batch, hipStream_t s) {
+  F5Args a = a0;
+  constexpr int R = Shape<Q>::R;
+  static_assert(2 * R + 1 <= 31, "a run sum of 2R+1 cells with the untraversable flag at bit 27 must fit 32 bits");
+  static const int waves_env = lab_int("TE_F5_WAVES", 0);  // measurement aid: strips sized for this many waves per SIMD
+  const int capacity = (waves_env > 0 ? waves_env : kF5Waves) * 4 * device_cus();
+  const int nz = a.map >= 0 ? 1 : (batch > 0 ? batch : 1);
+  const int H = a.j_hi - a.j_lo;
+  static const int max_strip = lab_int("TE_F5_MAX_STRIP", 512);
+  a.strip_rows = plan_strip_rows(H, (long)a.nbx_l * nz, capacity, max_strip > 0 ? max_strip : 512);
+  const int sr = a.strip_rows;
+  a.chunk = sr >= 4 ? kF4Chunk : (sr * kLanes >= kF4Chunk / 2 ? kF4Chunk / 2 : kLanes);  // (a strip of one row lists at most 64 cells)
+  const int nstrips = (H + sr - 1) / sr;
+  // every listed cell takes one entry and every block may leave one chunk unfinished (closed chunks are full)
+  if ((double)a.nbx_l * (double)nstrips * (double)nz * (double)a.chunk + (double)a.map_cells * (double)nz > (double)a.list_cap) return false;
+  const dim3 grid((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz);
+  hipLaunchKernelGGL((k_fp_slide5<Q>), grid, dim3(kLanes), 0, s, a);
+  return true;
+}
+
+}  // namespace
+
+// Shapes: every disc shape up to radius 10 (te_march.h) except the single cell, and for radii 11 .. 15 every sum of two
+// squares below 256.  Compiled in TE_PARTS parts like te_footprint4.hip (build.py).
+#define TE_F5_P0(X) X(4) X(16) X(26) X(37) X(50) X(65) X(73) X(85) X(100) X(121) X(136) X(148) X(162) X(178) X(193) X(202) X(212) X(229)
+#define TE_F5_P1(X) X(10) X(13) X(25) X(36) X(49) X(64) X(82) X(98) X(109) X(117) X(130) X(146) X(160) X(173) X(185) X(200) X(226) X(241) X(250)
+#define TE_F5_P2(X) X(9) X(20) X(34) X(45) X(58) X(61) X(81) X(97) X(106) X(116) X(128) X(145) X(157) X(170) X(181) X(197) X(225) X(234) X(245)
+#define TE_F5_P3(X) X(2) X(8) X(18) X(32) X(41) X(53) X(72) X(80) X(90) X(104) X(113) X(125) X(144) X(153) X(169) X(196) X(208) X(221) X(233) X(244)
+#define TE_F5_P4(X) X(1) X(5) X(17) X(29) X(40) X(52) X(68) X(74) X(89) X(101) X(122) X(137) X(149) X(164) X(180) X(194) X(205) X(218) X(232) X(242)
+#if !defined(TE_PARTS) || defined(TE_F5_SHAPES)
+#undef TE_PARTS
+#undef TE_PART
+#define TE_PARTS 1
+#define TE_PART 0
+#endif
+#if TE_PARTS != 1 && TE_PARTS != 5
+#error "te_footprint5.hip is cut into 1 or 5 parts"
+#endif
+#ifndef TE_F5_SHAPES
+#if TE_PARTS == 1
+#define TE_F5_SHAPES(X) TE_F5_P0(X) TE_F5_P1(X) TE_F5_P2(X) TE_F5_P3(X) TE_F5_P4(X)
+#else
+#define TE_F5_CAT2(a, b) a##b
+#define TE_F5_CAT(a, b) TE_F5_CAT2(a, b)
+#define TE_F5_SHAPES(X) TE_F5_CAT(TE_F5_P, TE_PART)(X)
+#endif
+#endif
+#define TE_F5_NAME2(k) f5_launch_part##k
+#define TE_F5_NAME(k) TE_F5_NAME2(k)
+
+// launches shape Q if it belongs to this part
+bool TE_F5_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
+  const F5Args& a = *static_cast<const F5Args*>(args);
+  switch (Q) {
+#define X(q) \
+  case q:    \
+    return launch_f5<q>(a, batch, s);
+    TE_F5_SHAPES(X)
+#undef X
+    default:
+      return false;
+  }
+}
+
+#if TE_PART == 0
+#if TE_PARTS > 1
+bool f5_launch_part1(int Q, const void* args, int batch, hipStream_t s);
+bool f5_launch_part2(int Q, const void* args, int batch, hipStream_t s);
+bool f5_launch_part3(int Q, const void* args, int batch, hipStream_t s);
+bool f5_launch_part4(int Q, const void* args, int batch, hipStream_t s);
+#endif
+
+// The scatter-form sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken
+// (the caller tries k_fp_slide4, then the double kernel).  tcap: upper bound of the finite values of the traversability
+// layer, as the host can prove it (the layer was written by the chain: w_scale * (w_slope + w_step + w_rough) with
+// non-negative weights); < 0: unknown.  On success the caller still owes footprint_blocked4 (finish = false) for the
+// listed cells.
+bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, const int* clip_table, double tcap, hipStream_t s,
+                      const Region* region, bool* needs_blocked) {
+  const Disc& d = p.fp_disc;
+  static const bool off = lab_flag("TE_NO_F5");  // measurement aid: k_fp_slide4 as in round 3
+  if (off || d.n_ties != 0) return false;
+  const int shape = d.Q, R = d.R;
+  if (shape < 1 || R < 1 || 2 * R + 1 > 31 || p.reach != R || g.rows < kLanes || g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;
+  if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;  // 32-bit list entries and byte offsets within a pass
+  if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch > (double)L.fp_blocked_cap) return false;
+  // the fixed-point scale: the T-sum of a whole disc (npoints cells of at most cap * 2^k + 1/2 each) must stay below
+  // 2^27 -- the untraversable flag's bit -- and the default value that replaces NaN has to fit as well
+  if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
+  const double cap = (tcap > p.def ? tcap : p.def) * (1.0 + 1e-6) + 1e-12;
+  int k = 23;
+  while (k >= 0 && (double)d.npoints * (cap * ldexp(1.0, k) + 1.0) >= (double)(1u << kF5UBit)) --k;
+  if (k < 17) return false;  // rounding each value to 2^-17 could show at the 1e-5 level: the double kernel serves
+  F5Args a;
+  a.trav = L.trav;
+  a.untrav = L.untrav;
+  a.footprint = L.footprint;
+  a.rows = g.rows;
+  a.cols = g.cols;
+  a.map_cells = (long long)g.rows * g.cols;
+  a.strip_rows = 0;
+  const int nbx = (g.rows + kLanes - 1) / kLanes;
+  a.bx0 = region ? region->i0 / kLanes : 0;
+  a.nbx_l = region ? (region->i1 - 1) / kLanes - a.bx0 + 1 : nbx;
+  a.j_lo = region ? region->j0 : 0;
+  a.j_hi = region ? region->j1 : g.cols;
+  a.map = region ? region->map : -1;
+  *needs_blocked = false;
+  if (a.j_hi <= a.j_lo || a.nbx_l <= 0) return true;
+  a.gtab = clip_table;
+  a.rmin = p.rmin;
+  a.def = (float)p.def;
+  a.scale = (float)ldexp(1.0, k);
+  a.inv_scale = ldexp(1.0, -k);
+  a.blocked_list = L.fp_blocked;
+  a.blocked_count = L.fp_blocked_count;
+  a.chunk = kF4Chunk;
+  a.list_cap = L.fp_blocked_cap;
+  bool launched = f5_launch_part0(shape, &a, g.batch, s);
+#if TE_PARTS > 1
+  launched = launched || f5_launch_part1(shape, &a, g.batch, s) || f5_launch_part2(shape, &a, g.batch, s) || f5_launch_part3(shape, &a, g.batch, s) ||
+             f5_launch_part4(shape, &a, g.batch, s);
+#endif
+  *needs_blocked = launched;
+  return launched;
+}
+#endif  // TE_PART == 0
+
+}  // namespace fast
+}  // namespace te

@@ -27,6 +27,10 @@ constexpr bool lab_flag(const char*) { return false; }
 #endif
 
 constexpr int kMaxRadiusCells = 32;  // largest stencil radius (in cells) a launch supports
+// The marching kernels of te_march5.h load the rows above / below a map unconditionally (and stage them as "nothing
+// there"): up to the stencil radius above the first row, and the radius plus the prefetch distance below the last.  The
+// context's slab therefore starts and ends with this many rows of slack (te_set_geometry).
+constexpr int kSlabGuardRows = kMaxRadiusCells + 16;
 constexpr int kMaxTies = 32;         // offsets lying exactly on the circle (tie radii)
 constexpr int kMaxSpiral = 4096;     // ordered offsets of the footprint spiral
 
@@ -212,6 +216,9 @@ namespace fast {
 bool step_height_fast(int Q, const Geo& g, const float* elev, float* sh, const Region& r, hipStream_t s);
 bool step_score_fast(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, const Region& r,
                      hipStream_t s);
+// te_step5.hip: the marching kernels behind the two functions above (and, RAW -- second output pointer set -- behind the two below)
+bool step_height5(int Q, const Geo& g, const float* elev, float* sh, float* sh_min, const Region& r, hipStream_t s);
+bool step_score5(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, float* out_count, const Region& r, hipStream_t s);
 // ... at a tie radius (whole-cell radii of 2 .. 10 cells): the marching kernels on the shape without its circle, then the
 // accepted circle cells folded in per cell; scratch: one float per cell of the layer (Layers::tie_scratch)
 bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh, float* scratch, const Region& r, hipStream_t s);
@@ -236,6 +243,10 @@ bool footprint_slide3(const Geo& g, const FootprintParams& p, const Layers& L, c
 // (tcap < 0: no bound known)
 bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, const int16_t* spiral_table, const int* clip_table,
                       double tcap, hipStream_t s, const Region* region = nullptr, bool finish = true);
+// te_footprint5.hip: the same sum in scatter form (tie-free discs up to 15 cells); *needs_blocked: the caller owes
+// footprint_blocked4 for the listed cells (after every launch of the pass)
+bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, const int* clip_table, double tcap, hipStream_t s,
+                      const Region* region, bool* needs_blocked);
 constexpr int kClipInts = 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1);  // one clip table of the normals disc; for a tie radius the
                                                                                       // table of the disc with its circle follows, then the packed offsets
 constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint disc (reach <= 20); a second one follows it for a tie

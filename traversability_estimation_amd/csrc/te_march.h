@@ -40,10 +40,12 @@ struct Shape {
 constexpr int kLanes = 64;
 
 // The disc shapes (Q = largest di^2+dj^2 in the disc) with radius up to 10 cells: every sum of two squares <= 100.
+#ifndef TE_DISC_SHAPES  // (tools: -D'TE_DISC_SHAPES(X)=X(81)' compiles one shape)
 #define TE_DISC_SHAPES(X) \
   X(0) X(1) X(2) X(4) X(5) X(8) X(9) X(10) X(13) X(16) X(17) X(18) X(20) X(25) X(26) X(29) X(32) X(34) X(36) X(37) \
   X(40) X(41) X(45) X(49) X(50) X(52) X(53) X(58) X(61) X(64) X(65) X(68) X(72) X(73) X(74) X(80) X(81) X(82) X(85) \
   X(89) X(90) X(97) X(98) X(100)
+#endif
 
 // A strip is `periods` unrolled periods of P rows; the first and last R rows visited only feed the halo.
 // The number of periods is a launch parameter: the launcher picks it so that the grid fills the resident

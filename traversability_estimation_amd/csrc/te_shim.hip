@@ -834,11 +834,13 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     // most, and its counter)
     const size_t list_cap = elems + fast::f4_list_slack(rows, cols, batch);
     const size_t qb = (list_cap * sizeof(unsigned) + 255) & ~(size_t)255;
-    const size_t total = 13 * lb + ub + fb + qb + 256;
+    // (guard: kSlabGuardRows rows of slack before the first and behind the last layer -- te_internal.h)
+    const size_t guard = ((size_t)kSlabGuardRows * (size_t)rows * sizeof(float) + 255) & ~(size_t)255;
+    const size_t total = guard + 13 * lb + ub + fb + qb + 256 + guard;
     hipError_t e = hipMalloc(&slab, total);
     if (e != hipSuccess) return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", total, hipGetErrorString(e));
     c->slab = slab;
-    char* b = (char*)slab;
+    char* b = (char*)slab + guard;
     float** ptrs[13] = {&c->L.elev, &c->L.slope, &c->L.step,     &c->L.rough,   &c->L.trav,     &c->L.footprint, &c->L.nx,
                         &c->L.ny,   &c->L.nz,    &c->L.slope_fp, &c->L.step_fp, &c->L.rough_fp, &c->L.step_height};
     for (int k = 0; k < 13; ++k) *ptrs[k] = (float*)(b + (size_t)k * lb);
@@ -849,7 +851,8 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     c->L.fp_blocked_cap = list_cap;
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
-    HIP_TRY(hipMemsetAsync(slab, 0xFF, 13 * lb + ub + fb, c->stream));
+    HIP_TRY(hipMemsetAsync(slab, 0xFF, guard + 13 * lb + ub + fb, c->stream));
+    HIP_TRY(hipMemsetAsync(b + 13 * lb + ub + fb + qb + 256, 0xFF, guard, c->stream));
     HIP_TRY(hipMemsetAsync(c->L.fp_blocked_count, 0, 256, c->stream));
     // the fix-up flags are zero between launches: k_normals_fixup clears every flag it consumes
     HIP_TRY(hipMemsetAsync(c->L.block_flags, 0, fb, c->stream));
