@@ -277,3 +277,129 @@ def test_cfg5_true_size_streaming_8192(capi, oracle):
                     assert n_bad == 0, (tick, k, n_bad, mx)
     finally:
         oracle.set_threads(1)
+
+
+def _rough_map(synth, n, seed, kind, amount):
+    """The 4096^2 maps round 3 timed without a parity check (profiles/r03_holes.json, r03_obstacles.json), as ab_chain.py builds them."""
+    elev = synth.perlin_elevation(n, n, seed=seed)
+    if kind == "speckle":
+        return synth.with_holes(elev, amount, seed=99)
+    rng = np.random.default_rng(99 if kind == "unobserved" else 7)
+    if kind == "unobserved":  # rectangles of 100..400 cells a side until `amount` of the area is covered
+        area = 0
+        while area < amount * n * n:
+            h, w = (int(v) for v in rng.integers(100, 400, size=2))
+            r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+            elev[c0:c0 + w, r0:r0 + h] = np.nan
+            area += h * w
+        return elev
+    for _ in range(int(amount)):  # boxes: raised / lowered rectangles of 4..40 cells a side (kerbs, crates)
+        h, w = (int(v) for v in rng.integers(4, 40, size=2))
+        r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
+        elev[c0:c0 + w, r0:r0 + h] += np.float32(rng.uniform(0.15, 0.5) * rng.choice([-1.0, 1.0]))
+    return elev
+
+
+@pytest.mark.parametrize("kind,amount", [("speckle", 0.001), ("speckle", 0.01), ("unobserved", 0.15), ("boxes", 300), ("boxes", 3000)])
+def test_full_size_holes_and_obstacles_against_oracle_bands(capi, oracle, kind, amount):
+    """The paths round 3 optimised and timed at 4096^2 without an oracle check at that size: the sparse march and its hole
+    queue (0.1 % speckle), the dense march (1 % speckle, unobserved rectangles), k_fp_blocked's long list and the mask
+    kernel's tile-wide list of slow cells (300 / 3000 boxes) -- on the bench-sized map, against the oracle on full-width
+    and full-height bands (every block column and every strip boundary is crossed).  res = 2^-4 m: checkForStep's
+    geometric ties depend on the rounded ABSOLUTE cell positions at 0.05 m, which a band does not share with the map
+    (DESIGN.md section 2); at a dyadic resolution every position is exact and band and map agree on every cell."""
+    import os
+    from traversability_estimation_amd import synth
+    n, cells, res = 4096, 9, 2.0 ** -4
+    elev = _rough_map(synth, n, 1235, kind, amount)
+    p = bench_params(capi, synth, cells, res)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(n, n, 1, res)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        fast = {k: ctx.download(k) for k in ALL}
+    if kind == "boxes":  # the obstacle paths really ran: discs with an untraversable cell, partial footprint values
+        fp = fast["traversability_footprint"]
+        assert (fp == 0).sum() > 1000 * amount / 300 and ((fp > 0) & (fp < 0.3)).sum() > 0
+    else:
+        assert np.isnan(fast["traversability_slope"]).sum() >= np.isnan(elev).sum() > 0
+    op = oracle_params(oracle, p)
+    margin, band = 2 * cells + 10 + 8, 96  # (+ max_gap_width / res + 3: the rays of checkForStep)
+    img = lambda a: a.reshape(n, n)
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    try:
+        for axis, starts in ((0, (0, 1777, n - band)), (1, (1300, n - band))):
+            for s0 in starts:
+                sl = (slice(s0, s0 + band), slice(0, n)) if axis == 0 else (slice(0, n), slice(s0, s0 + band))
+                crop = np.ascontiguousarray(elev[sl])
+                g = oracle.geom(crop.shape[1], crop.shape[0], res)
+                want = oracle.chain(g, op, crop)
+                want["traversability_footprint"] = oracle.footprint(g, op, crop, want)
+                lo = 0 if s0 == 0 else margin
+                hi = band if s0 + band == n else band - margin
+                keep = (slice(lo, hi), slice(0, n)) if axis == 0 else (slice(0, n), slice(lo, hi))
+                for k in ALL:
+                    a = img(fast[k])[sl][keep]
+                    b = want[k].reshape(crop.shape)[keep]
+                    n_bad, mx, nn = compare_layer(k, a, b)
+                    assert n_bad == 0, (kind, amount, k, "band", axis, s0, n_bad, mx, nn)
+    finally:
+        oracle.set_threads(1)
+
+
+def test_whole_map_oracle_at_tie_radii_1024(capi, oracle):
+    """Tie radii at a BASELINE size against the ORACLE on the whole map (the 4096^2 tie test above compares fast with generic
+    GPU kernels: a crop does not share the rounded positions that decide the cells on the circles): 1024^2, every radius
+    exactly 5 cells (a 3-4-5 radius: twelve circle cells), footprint 6 + 3 cells exactly, 40 boxes; the OpenMP oracle
+    takes about a minute on the GPU box's host cores."""
+    import os
+    from traversability_estimation_amd import synth
+    n, res = 1024, 0.05
+    elev = _rough_map(synth, n, 1236, "boxes", 40)
+    p = bench_params(capi, synth, 5, res, ties=True)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(n, n, 1, res)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        fast = {k: ctx.download(k) for k in ALL}
+    op = oracle_params(oracle, p)
+    oracle.set_threads(min(os.cpu_count() or 1, 128))
+    try:
+        g = oracle.geom(n, n, res)
+        want = oracle.chain(g, op, elev)
+        want["traversability_footprint"] = oracle.footprint(g, op, elev, want)
+    finally:
+        oracle.set_threads(1)
+    assert_layers_match(fast, want, layers=ALL, ctx="1024^2 at tie radii, whole map against the oracle")
+
+
+def test_batch_with_sparse_holes(capi, oracle):
+    """A batch whose maps carry sensor speckle (0.1 %: the sparse-hole march of k_normals3 and its per-block queues).  With
+    96 maps of 512^2 the grid no longer fits one round of resident blocks, which the queue scratch is sized for: the
+    launcher must fall back to the dense march instead of indexing queues that do not exist."""
+    from traversability_estimation_amd import synth
+    rows = cols = 512
+    res, B = 0.05, 96
+    elevs = np.stack([synth.with_holes(synth.perlin_elevation(rows, cols, seed=2000 + b), 0.001, seed=b) for b in range(B)])
+    p = bench_params(capi, synth, 5, res)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(rows, cols, B, res)
+        ctx.upload_elevation(elevs)
+        ctx.run_chain(0)
+        ctx.sync()
+        fast = {k: ctx.download(k) for k in OUT_LAYERS}
+    op = oracle_params(oracle, p)
+    oracle.set_threads(8)
+    try:
+        g = oracle.geom(rows, cols, res)
+        per = rows * cols
+        for b in (0, 41, 95):
+            want = oracle.chain(g, op, elevs[b])
+            assert_layers_match({k: fast[k][b * per:(b + 1) * per] for k in OUT_LAYERS}, want, ctx=f"sparse holes, map {b}")
+    finally:
+        oracle.set_threads(1)

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--exact-chain", action="store_true", help="normals / roughness / step radii exactly --radius-cells cells (tie radii: the generic kernels)")
     ap.add_argument("--loops", type=str, default="", help="comma-separated K: host-timed loops of K launches + sync")
     ap.add_argument("--tag", type=str, default="")
+    ap.add_argument("--check", action="store_true", help="after the timing, compare what the launches left on the device with the "
+                    "oracle (bench.py's parity_check: a corner crop and a full-width band; exit code 1 on a mismatch) -- no number "
+                    "goes into profiles/ from an unchecked run")
     a = ap.parse_args()
     from traversability_estimation_amd import capi, synth
     capi.load()
@@ -109,7 +112,20 @@ def main():
                     best = d if best is None or d < best else best
                 loops[str(K)] = {"ms_total_best_of_5": best, "ms_per_step": best / K}
             out["host_loops"] = loops
+        if a.check and not a.normals_only:
+            import types
+            import bench
+            ctx.run_chain(flags)
+            ctx.sync()
+            args = types.SimpleNamespace(radius_cells=a.radius_cells, res=a.res)
+            rep = bench.parity_check(args, ctx, elevs[0], p, not a.no_footprint, n)
+            out["parity_check"] = {"ok": rep["ok"], "windows": rep["windows"],
+                                   "mismatches": {k: v["mismatches"] for k, v in rep["layers"].items()},
+                                   "max_abs_err": max(v["max_abs_err"] for v in rep["layers"].values()),
+                                   "cells_per_layer": next(iter(rep["layers"].values()))["cells"]}
     print(json.dumps(out), flush=True)
+    if a.check and not out.get("parity_check", {"ok": True})["ok"]:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

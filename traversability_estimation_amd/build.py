@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
+SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")

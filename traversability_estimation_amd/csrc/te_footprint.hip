@@ -1011,8 +1011,9 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   };
   const int t_lo = rm.j0 / my, t_hi = (rm.j1 - 1) / my + 1;
   // (A pass in two bands -- the upper half's sliding sum on the second stream beside the lower half's mask kernel -- was
-  // measured in round 3: 0.418 ms per launch against 0.385; the two kernels slow each other down by more than they
-  // overlap.  Removed.)
+  // measured in round 3 with k_fp_slide4 (0.418 ms per launch against 0.385) and again in round 4 with k_fp_slide5 and
+  // 2 / 3 / 4 / 6 bands on two streams (0.393 / 0.425 / 0.462 / 0.589 against 0.375, profiles/r04_experiments.json): the two
+  // kernels slow each other down by more than they overlap, and every band pays the strips' 2R lead-in rows again.)
   launch_mask(t_lo, t_hi, stream);
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;

@@ -173,6 +173,24 @@ struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 
               // only discs that lie inside the map), whatever the flags and the slope layer say
 };
 
+// te_stage.hip: whole-layer transfers through pageable caller buffers -- a ring of page-locked slots per context, chunked,
+// the host-side copies on a process-wide pool of threads beside the DMA of the neighbouring chunk
+struct HostStager {
+  static constexpr size_t kChunk = (size_t)8 << 20, kMinBytes = (size_t)4 << 20;
+  static constexpr int kSlots = 4;
+  char* slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_order = nullptr;
+  hipStream_t stream = nullptr;
+  ~HostStager();
+  void release();      // (with the context's device current)
+  hipError_t ensure();
+  // host -> device behind everything queued on `compute`; `compute` is made to wait for the data; returns once `host` may be reused
+  hipError_t upload(void* dev, const void* host, size_t bytes, hipStream_t compute);
+  // device -> host behind everything queued on `compute`; returns once `host` holds the data
+  hipError_t download(void* host, const void* dev, size_t bytes, hipStream_t compute);
+};
+
 // Compute units of the CURRENT device (hipGetDevice), cached per device; the launchers size their grids from it.
 // (A function-local static of the first device's count would be a data race with one context per thread and the
 // wrong capacity on a node with different devices.)

@@ -1,4 +1,6 @@
-// te_march.h -- the "marching wavefront" framework shared by the fast (shape-specialised) kernels.
+// te_march.h -- what the shape-specialised kernels share: the disc shapes, compile-time loops, NaN-ignoring min / max.
+// (The marching framework itself is te_march5.h; the round-1 one -- PeriodLoader, a period of rows in LDS -- was retired
+// with its last users in round 4.)  The scheme, for reference:
 //
 // One 64-lane wavefront owns 64 adjacent cells along the fast axis (grid_map row index i) and
 // marches down the slow axis (column index j) over a strip of rows.  For a disc
@@ -47,16 +49,6 @@ constexpr int kLanes = 64;
   X(89) X(90) X(97) X(98) X(100)
 #endif
 
-// A strip is `periods` unrolled periods of P rows; the first and last R rows visited only feed the halo.
-// The number of periods is a launch parameter: the launcher picks it so that the grid fills the resident
-// wave slots of the chip in one round (plan_periods below).
-template <int Q>
-struct Strip {
-  static constexpr int R = Shape<Q>::R, P = Shape<Q>::P;
-  static constexpr int W = kLanes + 2 * R;  // staged row width
-  __host__ __device__ static constexpr int out_rows(int periods) { return periods * P - 2 * R; }
-};
-
 __device__ __forceinline__ float qnan() { return __builtin_nanf(""); }
 
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Used where every
@@ -69,93 +61,6 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// Loads of one period (P rows x W columns starting at map row r0, map column c0) into registers; NaN
-// outside the map.  All loads are issued back to back (they stay in flight while the previous period is
-// processed); store() writes them to LDS later.
-//   main part: row rr, columns c0+R .. c0+R+63  -> one 256-byte coalesced load per row, address =
-//              uniform row base + lane*4 (no per-load address arithmetic)
-//   halo part: the 2R border columns of all P rows, flattened over the lanes: NH loads whose per-lane
-//              byte offset and LDS slot never change and are computed once (init)
-// A period completely inside the map (wave-uniform test) takes the unchecked path.
-template <int Q>
-struct PeriodLoader {
-  static constexpr int R = Shape<Q>::R, P = Shape<Q>::P, W = Strip<Q>::W, H = 2 * R;
-  static constexpr int NH = (P * H + kLanes - 1) / kLanes, NLD = P + NH;
-  unsigned hoff[NH ? NH : 1];  // byte offset of the lane's m-th halo cell relative to (r0, c0)
-  int hpos[NH ? NH : 1];       // its slot in the staged period (row * W + column), -1 = none
-
-  __device__ __forceinline__ void init(const Geo& g, int lane) {
-    static_for<NH>([&](auto mc) __attribute__((always_inline)) {
-      constexpr int m = decltype(mc)::value;
-      const int h = lane + m * kLanes;
-      const int hr = h / (H ? H : 1), hc = h - hr * H;
-      const int cc = hc < R ? hc : hc + kLanes;
-      const bool used = h < P * H;
-      hoff[m] = used ? 4u * (unsigned)(hr * g.rows + cc) : 0u;
-      hpos[m] = used ? hr * W + cc : -1;
-    });
-  }
-
-  __device__ __forceinline__ void load(float (&v)[NLD], const float* __restrict__ layer, const Geo& g, int r0, int c0,
-                                       int lane) const {
-    if (r0 >= 0 && r0 + P <= g.cols && c0 >= 0 && c0 + W <= g.rows) {
-      const float* base = layer + (size_t)r0 * g.rows + c0;
-      static_for<P>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int rr = decltype(rc)::value;
-        v[rr] = (base + (size_t)rr * g.rows + R)[lane];
-      });
-      static_for<NH>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value;
-        v[P + m] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + hoff[m]);
-      });
-    } else {
-      static_for<P>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int rr = decltype(rc)::value;
-        const int r = r0 + rr, ci = c0 + R + lane;
-        float t = qnan();
-        if (r >= 0 && r < g.cols && ci >= 0 && ci < g.rows) t = layer[(size_t)r * g.rows + ci];
-        v[rr] = t;
-      });
-      static_for<NH>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int m = decltype(mc)::value;
-        const int hr = hpos[m] / W, cc = hpos[m] - hr * W;
-        const int r = r0 + hr, ci = c0 + cc;
-        float t = qnan();
-        if (hpos[m] >= 0 && r >= 0 && r < g.cols && ci >= 0 && ci < g.rows) t = layer[(size_t)r * g.rows + ci];
-        v[P + m] = t;
-      });
-    }
-  }
-
-  // rowbuf[slot] = f(value) for every staged cell of the period
-  template <class E, class F>
-  __device__ __forceinline__ void store(E* rowbuf, const float (&v)[NLD], int lane, F&& f) const {
-    static_for<P>([&](auto rc) __attribute__((always_inline)) {
-      constexpr int rr = decltype(rc)::value;
-      rowbuf[rr * W + R + lane] = f(v[rr]);
-    });
-    static_for<NH>([&](auto mc) __attribute__((always_inline)) {
-      constexpr int m = decltype(mc)::value;
-      if (hpos[m] >= 0) rowbuf[hpos[m]] = f(v[P + m]);
-    });
-  }
-};
-
-// Number of periods per strip for a region of `rows` output rows and `columns` 64-lane column blocks
-// (x batch): the smallest strip count whose grid still fits the `slots` resident waves of the device in
-// one round gives the longest strips (least halo re-reading) without a second, mostly empty round.
-inline int plan_periods(int P, int R, int rows, long columns, long slots) {
-  const int min_periods = (2 * R + P) / P + 1;  // at least P output rows or so
-  long strips = slots / (columns > 0 ? columns : 1);
-  if (strips < 1) strips = 1;
-  // rows per strip if `strips` strips cover the region, rounded up to whole periods
-  long per = ((rows + strips - 1) / strips + 2 * R + P - 1) / P;
-  const long max_periods = (128 + 2 * R + P - 1) / P;  // more than ~128 rows per strip gains nothing
-  if (per > max_periods) per = max_periods;
-  if (per < min_periods) per = min_periods;
-  return (int)per;
 }
 
 // min/max that ignore (quiet) NaN operands, without the canonicalisation instruction the compiler

@@ -186,6 +186,7 @@ struct te_ctx {
   TileSlot in_slot[2], out_slot[2];
   int in_next = 0, out_next = 0;
   bool tiles_pending = false;  // te_sync has copy streams to wait for
+  HostStager stager;           // whole-layer transfers through pageable host buffers (te_stage.hip)
 };
 
 namespace {
@@ -731,6 +732,7 @@ int te_destroy(te_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_layers(c);
+    c->stager.release();
     if (c->d_spiral) (void)hipFree(c->d_spiral);
     if (c->d_count) (void)hipFree(c->d_count);
     if (c->hole_queue) (void)hipFree(c->hole_queue);
@@ -881,7 +883,7 @@ int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
     return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
   HIP_TRY(hipSetDevice(c->device));
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(hipMemcpyAsync(c->L.elev + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c->stager.upload(c->L.elev + per * map0, host, per * nmaps * sizeof(float), c->stream));
   // (the count also waits for the copy: the host buffer may be reused as soon as we return)
   if (const int rc = count_invalid_elevation(c)) return rc;
   c->have_elev = true;
@@ -1052,7 +1054,7 @@ int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps
     return fail(TE_ERR_INVALID_ARG, "te_upload_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
   HIP_TRY(hipSetDevice(c->device));
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(hipMemcpyAsync(p + per * map0, host, per * nmaps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c->stager.upload(p + per * map0, host, per * nmaps * sizeof(float), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
   if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
@@ -1738,8 +1740,7 @@ int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
     return fail(TE_ERR_INVALID_ARG, "te_download_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
   HIP_TRY(hipSetDevice(c->device));
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(hipMemcpyAsync(host, p + per * map0, per * nmaps * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(c->stager.download(host, p + per * map0, per * nmaps * sizeof(float), c->stream));
   return TE_OK;
 }
 

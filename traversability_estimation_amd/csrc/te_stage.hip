@@ -1,0 +1,186 @@
+// te_stage.hip -- host <-> device transfers of whole layers through PAGEABLE caller buffers.
+//
+// The reference's plugins hand over grid_map::Matrix buffers (Eigen heap memory, pageable):
+//   mapOut = mapIn; mapOut.add(type_)     traversability_estimation_filters/src/SlopeFilter.cpp:62-63 (every plugin)
+//   TraversabilityMap::setElevationMap     traversability_estimation/src/TraversabilityMap.cpp:135-154
+// hipMemcpyAsync from / to pageable memory goes through the runtime's own staging, one bounce at a time: 64 MB up and
+// 5 x 64 MB down took 51 ms per 4096^2 frame in round 3 (7.5 GB/s), 131 x the resident launch.  Here the shim keeps a ring
+// of page-locked slots per context and a small pool of copy threads per process: chunk k is copied host -> slot by the
+// pool while chunk k - 1 crosses PCIe from its slot (uploads), or the DMA of chunk k + kSlots - 1 runs while the pool
+// copies chunk k slot -> host (downloads).  Buffers the caller has page-locked (te_pin_host) skip all of this.
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "te_internal.h"
+
+namespace te {
+
+namespace {
+
+// memcpy split over a few persistent threads (one job at a time: the contexts' transfers queue up on the mutex)
+class CopyPool {
+ public:
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool;  // (never destroyed: its threads sleep on its condition variables until the process ends)
+    return *p;
+  }
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (1u << 20) || workers_.empty()) {
+      memcpy(dst, src, bytes);
+      return;
+    }
+    std::lock_guard<std::mutex> job(job_mu_);
+    const size_t parts = workers_.size() + 1;
+    const size_t piece = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      dst_ = (char*)dst;
+      src_ = (const char*)src;
+      bytes_ = bytes;
+      piece_ = piece;
+      pending_ = (int)workers_.size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    part(parts - 1);  // the caller takes the last piece
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  CopyPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    // (a copy thread moves 5-8 GB/s; PCIe takes 50: about a dozen of them keep the DMA engine fed.  More threads than the
+    // container may really use do harm -- the GPU boxes of this pool show 256 cores and run OpenMP fastest on 32 --
+    // hence the modest numbers)
+    int n = hw >= 64 ? 11 : (hw >= 32 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0)));
+    for (int k = 0; k < n; ++k) workers_.emplace_back([this, k] { run(k); });
+    for (auto& t : workers_) t.detach();  // (process-lifetime pool: the library may be unloaded at exit while they sleep)
+  }
+  void part(size_t k) {
+    const size_t off = k * piece_;
+    if (off < bytes_) memcpy(dst_ + off, src_ + off, bytes_ - off < piece_ ? bytes_ - off : piece_);
+  }
+  void run(int k) {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      part((size_t)k);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  char* dst_ = nullptr;
+  const char* src_ = nullptr;
+  size_t bytes_ = 0, piece_ = 0;
+  int pending_ = 0;
+  unsigned long long generation_ = 0;
+};
+
+bool host_is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  const hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary malloc'ed pointer: "invalid value")
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+HostStager::~HostStager() { release(); }
+
+void HostStager::release() {
+  for (int s = 0; s < kSlots; ++s) {
+    if (slot[s]) (void)hipHostFree(slot[s]);
+    if (ev[s]) (void)hipEventDestroy(ev[s]);
+    slot[s] = nullptr;
+    ev[s] = nullptr;
+  }
+  if (ev_order) (void)hipEventDestroy(ev_order);
+  ev_order = nullptr;
+  if (stream) (void)hipStreamDestroy(stream);
+  stream = nullptr;
+}
+
+hipError_t HostStager::ensure() {
+  if (stream) return hipSuccess;
+  hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_order, hipEventDisableTiming);
+  for (int s = 0; s < kSlots && e == hipSuccess; ++s) {
+    e = hipHostMalloc((void**)&slot[s], kChunk, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[s], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    release();
+  }
+  return e;
+}
+
+// host -> device, ordered after everything queued on `compute` so far; `compute` waits for the last chunk
+hipError_t HostStager::upload(void* dev, const void* host, size_t bytes, hipStream_t compute) {
+  if (bytes < kMinBytes || host_is_pinned(host) || ensure() != hipSuccess) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, compute);
+  hipError_t e = hipEventRecord(ev_order, compute);  // (kernels queued earlier may still read the layer)
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_order, 0);
+  const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+  for (size_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+    const int s = (int)(k % kSlots);
+    const size_t off = k * kChunk, n = bytes - off < kChunk ? bytes - off : kChunk;
+    if (k >= (size_t)kSlots) e = hipEventSynchronize(ev[s]);  // the slot's previous chunk has left it
+    if (e != hipSuccess) break;
+    CopyPool::get().copy(slot[s], (const char*)host + off, n);
+    e = hipMemcpyAsync((char*)dev + off, slot[s], n, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[s], stream);
+  }
+  if (e == hipSuccess) e = hipEventRecord(ev_order, stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(compute, ev_order, 0);
+  // the slots are reused by the next transfer, and the caller may reuse `host` as soon as we return: both are safe --
+  // every chunk has been copied out of `host`, and a slot is only rewritten after its event
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  return e;
+}
+
+// device -> host, ordered after everything queued on `compute` so far; returns when `host` holds the data
+hipError_t HostStager::download(void* host, const void* dev, size_t bytes, hipStream_t compute) {
+  if (bytes < kMinBytes || host_is_pinned(host) || ensure() != hipSuccess) {
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, compute);
+    return e == hipSuccess ? hipStreamSynchronize(compute) : e;
+  }
+  hipError_t e = hipEventRecord(ev_order, compute);
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_order, 0);
+  const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+  auto issue = [&](size_t k) {
+    const int s = (int)(k % kSlots);
+    const size_t off = k * kChunk, n = bytes - off < kChunk ? bytes - off : kChunk;
+    hipError_t r = hipMemcpyAsync(slot[s], (const char*)dev + off, n, hipMemcpyDeviceToHost, stream);
+    return r == hipSuccess ? hipEventRecord(ev[s], stream) : r;
+  };
+  for (size_t k = 0; k < nchunks && k < (size_t)kSlots && e == hipSuccess; ++k) e = issue(k);
+  for (size_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+    const int s = (int)(k % kSlots);
+    const size_t off = k * kChunk, n = bytes - off < kChunk ? bytes - off : kChunk;
+    e = hipEventSynchronize(ev[s]);
+    if (e != hipSuccess) break;
+    CopyPool::get().copy((char*)host + off, slot[s], n);
+    if (k + kSlots < nchunks) e = issue(k + kSlots);
+  }
+  return e;
+}
+
+}  // namespace te

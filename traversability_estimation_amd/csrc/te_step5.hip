@@ -20,7 +20,7 @@ namespace fast {
 namespace {
 
 constexpr int kHeight5Waves = 4, kScore5Waves = 4;  // waves per SIMD the kernels are compiled for
-constexpr int kStep5Queue = 2;                       // passes in the prefetch queue
+constexpr int kStep5Queue = 2;                       // passes in the prefetch queue (3 and 4 measured the same: profiles/r04_experiments.json)
 
 struct Step5Args {
   const float* in;   // elevation / step_height
@@ -354,22 +354,6 @@ bool launch_step5(bool score, const Geo& g, Step5Args a, const Region& r, hipStr
     }
     return false;
   }
-#ifdef TE_LAB
-  static const int c_env = lab_int("TE_M5_C", C);  // measurement aid: passes in the prefetch queue (2 / 3 / 4)
-  if (c_env != C && (c_env == 2 || c_env == 3 || c_env == 4)) {
-    if (c_env == 2) {
-      if (score) hipLaunchKernelGGL((k_step_score5<Q, false, 2>), grid, dim3(kLanes), 0, s, a);
-      else hipLaunchKernelGGL((k_step_height5<Q, false, 2>), grid, dim3(kLanes), 0, s, a);
-    } else if (c_env == 3) {
-      if (score) hipLaunchKernelGGL((k_step_score5<Q, false, 3>), grid, dim3(kLanes), 0, s, a);
-      else hipLaunchKernelGGL((k_step_height5<Q, false, 3>), grid, dim3(kLanes), 0, s, a);
-    } else {
-      if (score) hipLaunchKernelGGL((k_step_score5<Q, false, 4>), grid, dim3(kLanes), 0, s, a);
-      else hipLaunchKernelGGL((k_step_height5<Q, false, 4>), grid, dim3(kLanes), 0, s, a);
-    }
-    return true;
-  }
-#endif
   if (score)
     hipLaunchKernelGGL((k_step_score5<Q, false, C>), grid, dim3(kLanes), 0, s, a);
   else
