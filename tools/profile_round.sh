@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): GPU test suite, bench lines, rocprofv3 kernel statistics and PMC passes of the bench
 # workload.  Usage: tools/profile_round.sh <tag> [quick]   -> gpurun_out/<tag>/...
 # PMC passes are separate runs with --pmc only (never combined with trace domains).
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
@@ -18,7 +18,6 @@ timeout 900 $BENCH --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_overlap -o p --output-format csv -- $BENCH $PROF_ARGS > $OUT/kt_overlap.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_seq -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/kt_seq.log 2>&1
 if [ -z "$QUICK" ]; then
-  TE_NO_N3=1 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_seq_no_n3 -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/kt_seq_no_n3.log 2>&1
   P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
   P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM"
   P3="GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_ACTIVE_INST_VMEM"
@@ -28,13 +27,9 @@ if [ -z "$QUICK" ]; then
     SEQ=--sequential
     [ $i -ge 4 ] && SEQ=   # the traffic passes measure the default (two-stream, combine in the mask kernel) launch sequence
     timeout 600 rocprofv3 --pmc $P -d $OUT/pmc/p$i -o p --output-format csv -- $BENCH $PROF_ARGS $SEQ > $OUT/pmc_p$i.log 2>&1
-    if [ -n "$PMC_ALSO_OLD" ]; then
-      TE_NO_N3=1 timeout 600 rocprofv3 --pmc $P -d $OUT/pmc_no_n3/p$i -o p --output-format csv -- $BENCH $PROF_ARGS --sequential > $OUT/pmc_no_n3_p$i.log 2>&1
-    fi
   done
   python $ROOT/tools/sq_counters.py $OUT/pmc > $OUT/sq_counters.json 2> $OUT/sq_counters.err
   python $ROOT/tools/hbm_traffic.py $OUT/pmc/p4 $OUT/pmc/p5 > $OUT/hbm_traffic.json 2>> $OUT/sq_counters.err
-  [ -n "$PMC_ALSO_OLD" ] && python $ROOT/tools/sq_counters.py $OUT/pmc_no_n3 > $OUT/sq_counters_no_n3.json 2>> $OUT/sq_counters.err
 fi
 # keep what is merged back small: drop the raw per-dispatch traces, keep the statistics
 find $OUT -name "*kernel_trace.csv" -delete
@@ -44,7 +39,7 @@ cat $OUT/pytest.log | tail -5
 cat $OUT/bench_default.json
 python - <<PY
 import csv, glob, re
-for d in ("kt_overlap", "kt_seq", "kt_seq_no_n3"):
+for d in ("kt_overlap", "kt_seq"):
     for f in glob.glob("$OUT/" + d + "/**/*kernel_stats.csv", recursive=True):
         print("==", d)
         for r in csv.DictReader(open(f)):

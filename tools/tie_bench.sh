@@ -10,7 +10,9 @@ run() { name=$1; shift; env "$@" > /dev/null 2>&1; }
 one() {  # name, env..., -- args
   name=$1; shift
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  env "${envs[@]}" $AB --tag "$name" "$@" > $O/$name.json 2> $O/$name.err
+  # (the switches are read by the lab build of the library only: libtravgpu.so never reads the environment)
+  lib=(); [ ${#envs[@]} -gt 0 ] && [ -f $ROOT/traversability_estimation_amd/libtravgpu_lab.so ] && lib=(TRAVGPU_LIB=$ROOT/traversability_estimation_amd/libtravgpu_lab.so)
+  env "${lib[@]}" "${envs[@]}" $AB --tag "$name" "$@" > $O/$name.json 2> $O/$name.err
 }
 one tie_free -- 
 one footprint_9_cells -- --exact-cells
