@@ -320,3 +320,87 @@ def test_pinned_host_buffers(capi):
         capi.unpin_host(dst)
     with pytest.raises(capi.TeError):
         capi.unpin_host(dst)  # not registered any more
+
+
+def _roughness_given_numpy(elev, nx, ny, nz, rows, cols, res, radius, crit, cells):
+    """RoughnessFilter::update (RoughnessFilter.cpp:84-126) for the listed cells, normals taken from the layers.
+    Layout: o = j * rows + i; grid_map positions x = -res * i, y = -res * j (any common shift cancels)."""
+    R = int(np.floor(radius / res))
+    out = {}
+    for (i, j) in cells:
+        o = j * rows + i
+        if not np.isfinite(nx[o]):
+            out[(i, j)] = np.nan
+            continue
+        pts = []
+        for dj in range(-R, R + 1):
+            for di in range(-R, R + 1):
+                a, b = i + di, j + dj
+                if a < 0 or a >= rows or b < 0 or b >= cols:
+                    continue
+                if (di * di + dj * dj) * res * res > radius * radius:
+                    continue
+                z = elev[b * rows + a]
+                if np.isfinite(z):
+                    pts.append((-res * a, -res * b, float(z)))
+        P = np.array(pts, dtype=np.float64).reshape(-1, 3)
+        n = np.array([nx[o], ny[o], nz[o]], dtype=np.float64)
+        if len(P) == 0:
+            out[(i, j)] = 1.0 if crit > 0 else 0.0
+            continue
+        mean = P.sum(axis=0) / len(P)
+        d = P @ n - mean @ n
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rough = np.sqrt(np.float64((d * d).sum()) / np.float64(len(P) - 1)) if len(P) > 1 else np.inf
+        out[(i, j)] = 1.0 - rough / crit if rough < crit else 0.0
+    return out
+
+
+@pytest.mark.parametrize("radius_cells", [3.6, 5.4, 9.2])
+def test_roughness_plugin_with_given_normals(capi, radius_cells):
+    """te_run_filter(roughness) with normals that are NOT the chain's own (the unchanged-YAML case: they come from the
+    upstream host filter): the sliding kernel's closed form n^T C n + fix-up pass against the generic kernel on every
+    cell and against a numpy restatement of RoughnessFilter.cpp:84-126 on a sample -- the frame, cells beside holes,
+    invalid centres under a valid normal, cells without a normal."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 330, 270, 0.05
+    rng = np.random.default_rng(17)
+    elev = synth.with_holes(synth.with_steps(synth.perlin_elevation(rows, cols, seed=71), 6, seed=72), 0.01, seed=73)
+    elev = np.ascontiguousarray(elev, dtype=np.float32).reshape(-1)
+    n = rows * cols
+    v = rng.normal(size=(n, 3)) * np.array([0.3, 0.3, 0.0]) + np.array([0.0, 0.0, 1.0])
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    nx, ny, nz = (np.ascontiguousarray(v[:, k], dtype=np.float32) for k in range(3))
+    gone = rng.random(n) < 0.03
+    nx[gone] = np.nan
+    radius = radius_cells * res
+    p = capi.default_params(rough_radius=radius)
+    with capi.Context(0) as ctx:
+        ctx.set_params(p)
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(elev)
+        for k, a in (("surface_normal_x", nx), ("surface_normal_y", ny), ("surface_normal_z", nz)):
+            ctx.upload_layer(k, a)
+        ctx.run_filter("roughness")
+        ctx.sync()
+        fast = ctx.download("traversability_roughness")
+        ctx.run_filter("roughness", capi.RUN_GENERIC_KERNELS)
+        ctx.sync()
+        generic = ctx.download("traversability_roughness")
+        # the input layers are untouched
+        assert np.array_equal(ctx.download("surface_normal_x").view(np.uint32), nx.view(np.uint32))
+        assert np.array_equal(ctx.download("surface_normal_z").view(np.uint32), nz.view(np.uint32))
+    assert np.array_equal(np.isnan(fast), np.isnan(generic))
+    assert np.array_equal(np.isnan(fast), gone)
+    ok = ~gone
+    assert np.max(np.abs(fast[ok] - generic[ok])) <= 1e-5
+    # a sample against the reference's own arithmetic
+    invalid = np.flatnonzero(~np.isfinite(elev) & ok)
+    cells = [(0, 0), (rows - 1, cols - 1), (0, cols // 2), (rows // 2, 0), (3, 5), (rows - 2, 7)]
+    cells += [(int(o % rows), int(o // rows)) for o in invalid[:40]]
+    cells += [(int(o % rows), int(o // rows)) for o in rng.integers(0, n, size=150)]
+    crit = float(p.rough_critical)
+    want = _roughness_given_numpy(elev, nx, ny, nz, rows, cols, res, radius, crit, cells)
+    for (i, j), w in want.items():
+        g = fast[j * rows + i]
+        assert (np.isnan(w) and np.isnan(g)) or abs(float(g) - w) <= 1e-5, ((i, j), float(g), w)

@@ -247,6 +247,8 @@ bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const 
 // *combined tells whether it did (the k_normals3 path leaves the combine to the caller).
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
                   const Region& r, int* block_flags, const int* clip_table, FastGrid* fg, hipStream_t s, bool* combined);
+// te_slide_normals.hip: RoughnessFilter alone with the normals of the layers (false: shape / map not taken)
+bool roughness_given_fast(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, int* block_flags, FastGrid* fg, hipStream_t s);
 // te_normals3.hip: the cells whose disc lies inside the map (false: shape / region not taken)
 int footprint_inner_q(double res, double rmin, double rmax);  // te_footprint3.hip
 bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags,

@@ -369,10 +369,14 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       bool need = false;
       if (i < rg.i1 && j < jb1) {
         const float z0 = tile[(lj + K) * tw + (threadIdx.x + K)];
-        const float s = slope[mo + (size_t)j * g.rows + i];
+        const size_t oc = mo + (size_t)j * g.rows + i;
+        // (given normals: the sliding kernel left NaN in the ROUGHNESS layer of the cells it could not finish; a cell takes
+        // part if its normal is valid, whatever its own elevation is -- RoughnessFilter.cpp:84)
+        const float s = a.given_normals ? rough[oc] : slope[oc];
+        const bool have = a.given_normals ? __builtin_isfinite(onx[oc]) : (z0 == z0);
         const bool in_frame = fg.frame > 0 && (i < fg.frame || j < fg.frame || i >= g.rows - fg.frame || j >= g.cols - fg.frame);
-        need = (z0 == z0) && (!(s == s) || in_frame);
-        if (in_frame && !(z0 == z0)) {  // nobody else writes the frame: an invalid centre has no normal, slope or roughness
+        need = have && (!(s == s) || in_frame);
+        if (!a.given_normals && in_frame && !(z0 == z0)) {  // nobody else writes the frame: an invalid centre has no normal, slope or roughness
           const size_t o = mo + (size_t)j * g.rows + i;
           const float qn = __builtin_nanf("");
           slope[o] = qn;
@@ -523,8 +527,15 @@ hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, in
     na.w_scale = na.w_slope = na.w_step = na.w_rough = 0.0f;
     na.combine = 0;
     na.given_normals = 1;
-    hipLaunchKernelGGL(k_normals, tile_grid(g, r), blk, tile_bytes(p.rough.reach), stream, g, na, L.elev, L.step, L.slope,
-                       L.rough, L.trav, L.nx, L.ny, L.nz, r);
+    // tie-free discs: the sliding kernel with the layers' normals (interior, hole-free discs in closed form from the
+    // moments), the fix-up pass for the frame and the holes; otherwise the generic kernel on every cell
+    FastGrid fg;
+    if (use_fast && fast::roughness_given_fast(g, p, L, r, L.block_flags, &fg, stream))
+      hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(p.rough.reach), stream, g, na,
+                         L.elev, L.step, L.slope, L.rough, L.trav, L.nx, L.ny, L.nz, L.block_flags, fg, r);
+    else
+      hipLaunchKernelGGL(k_normals, tile_grid(g, r), blk, tile_bytes(p.rough.reach), stream, g, na, L.elev, L.step, L.slope,
+                         L.rough, L.trav, L.nx, L.ny, L.nz, r);
   } else if (filter == TE_FILTER_NORMALS) {
     // the normals pass alone, normals kept: the sliding kernel computes slope and roughness on the way (same disc), the
     // plugins that want those layers compute them from their own inputs later

@@ -48,6 +48,11 @@ struct SlideArgs {
   double slope_crit, inv_slope_crit, rough_crit, inv_rough_crit;
   float w_scale, w_slope, w_step, w_rough;
   int combine;
+  // RoughnessFilter as a stand-alone plugin (RoughnessFilter.cpp:84-119): surface_normal_{x,y,z} are INPUT layers and the
+  // only output is the roughness score of the plane through the disc's mean with THAT normal.  Discs that lie inside the
+  // map and hold no invalid cell take the closed form  n^T C n  from the sliding moments; everything else (the frame,
+  // holes, an invalid centre under a valid normal) is left NaN, flagged, and recomputed by the fix-up pass.
+  int given;
   const int* gtab;  // [(2R+1)^2][6] x/y moments {n, si, sj, sii, sij, sjj} of the disc clipped by the map border
   int fi0, fj0, ntx, nty;  // fix-up flag grid: 64x16 tiles from (fi0, fj0), ntx x nty per map
   int fix_groups;          // workgroups of the fix-up pass: the flag of tile t lives at (t % groups) * kFixTiles + t / groups
@@ -335,7 +340,24 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     float tb = a.w_step * stq[qs];
     asm volatile("" : "+v"(tb));
     const int ky = (j < R) ? (R - j) : ((g.cols - 1 - j < R) ? -(R - (g.cols - 1 - j)) : 0);  // uniform
-    if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
+    if (a.given) {  // (uniform)
+      const size_t og = (size_t)j * g.rows + ic;
+      const float gxf = v_nx[og], gyf = v_ny[og], gzf = v_nz[og];
+      const double gx = (double)gxf, gy = (double)gyf, gz = (double)gzf;
+      const double mz = Sz * inv_np;
+      const double ca = nres * Siz * inv_np;  // cov(x,z), x = -res*di
+      const double cb = nres * Sjz * inv_np;  // cov(y,z)
+      const double cd = fma(Szz, inv_np, -mz * mz);
+      // sum of squared distances to the plane / N = n^T C n with C = [[cxx,0,ca],[0,cxx,cb],[ca,cb,cd]] (RoughnessFilter.cpp:105-117)
+      double q = fma(cxx, fma(gx, gx, gy * gy), fma(2.0 * gz, fma(gx, ca, gy * cb), gz * gz * cd));
+      q = q > 0.0 ? q : 0.0;
+      const float rgh = __builtin_amdgcn_sqrtf((float)(q * nm1));
+      const float rs = rgh < rough_critf ? 1.0f - rgh * inv_rough_critf : 0.0f;
+      const bool have = __builtin_isfinite(gxf);  // :84 (the reference tests surface_normal_x only)
+      const bool clean = (j > dirty_until) && (kx == 0) && (ky == 0);
+      done = clean || !have;  // no normal: the layer stays NaN, nothing to recompute
+      o_rough = (clean && have) ? rs : qnanf();
+    } else if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
       // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
       // the x/y moments of the clipped disc come from the host-built table
       double qrough = 0.0;
@@ -394,10 +416,10 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
     const bool emit = i < sub_i1;
     if (emit) {
       const size_t o = (size_t)j * g.rows + i;
-      v_slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
+      if (!a.given) v_slope[o] = o_slope;  // NaN == "to be recomputed by the fix-up pass if the centre is valid"
       v_rough[o] = o_rough;
       if (a.combine) v_trav[o] = o_trav;
-      if (onx) {
+      if (onx && !a.given) {
         v_nx[o] = nx;
         v_ny[o] = ny;
         v_nz[o] = nz;
@@ -534,6 +556,7 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.w_step = p.w_step;
   a.w_rough = p.w_rough;
   a.combine = combine ? 1 : 0;
+  a.given = 0;
   a.gtab = gtab;
   if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1 || !gtab) return false;  // both borders inside one disc
   // cells whose disc lies inside the map: k_normals3 (3 waves per SIMD); this file keeps the frame
@@ -563,6 +586,67 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
 #define X(q) \
   case q:    \
     launch_r<q, -1>(g, a, L, keep_normals, r, flags, s); \
+    return true;
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#undef X
+    default:
+      return false;
+  }
+}
+
+// RoughnessFilter alone on the roughness disc with the normals of the layers (SlideArgs::given).  False: not taken.
+bool roughness_given_fast(const Geo& g, const ChainParams& p, const Layers& L, const Region& r, int* flags, FastGrid* fg, hipStream_t s) {
+  const Disc& d = p.rough;
+  if (d.n_ties != 0 || d.R < 1 || d.R > 16 || d.npoints < 3 || !flags) return false;
+  if (g.rows < 2 * d.R + 1 || g.cols < 2 * d.R + 1) return false;
+  SlideArgs a;
+  int sii = 0;
+  for (int k = 0; k <= kMaxRadiusCells; ++k) {
+    a.h[k] = k <= d.R ? d.hw[k] : -1;
+    a.hd[k] = (double)a.h[k];
+  }
+  for (int dj = -d.R; dj <= d.R; ++dj) {
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) sii += di * di;
+  }
+  a.np = d.npoints;
+  a.sii = sii;
+  fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
+  fg->nty = (r.j1 - r.j0 + 15) / 16;
+  fg->nbz = r.map >= 0 ? 1 : g.batch;
+  fg->frame = 0;
+  a.fi0 = r.i0;
+  a.fj0 = r.j0;
+  a.ntx = fg->ntx;
+  a.nty = fg->nty;
+  a.fix_groups = fix_groups(fg->ntx * fg->nty * fg->nbz);
+  a.slope_crit = p.slope_crit;
+  a.inv_slope_crit = 1.0 / p.slope_crit;
+  a.rough_crit = p.rough_crit;
+  a.inv_rough_crit = 1.0 / p.rough_crit;
+  a.w_scale = a.w_slope = a.w_step = a.w_rough = 0.0f;
+  a.combine = 0;
+  a.given = 1;
+  a.gtab = nullptr;
+  if (d.Q >= 1) {  // instantiated shape: compile-time run table
+    switch (d.Q) {
+#define X(q)                                                      \
+  case q:                                                         \
+    if constexpr (q >= 1) {                                       \
+      launch_r<Shape<q>::R, q>(g, a, L, true, r, flags, s);       \
+      return true;                                                \
+    }                                                             \
+    break;
+      TE_DISC_SHAPES(X)
+#undef X
+      default:
+        break;
+    }
+  }
+  switch (d.R) {
+#define X(q) \
+  case q:    \
+    launch_r<q, -1>(g, a, L, true, r, flags, s); \
     return true;
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X
