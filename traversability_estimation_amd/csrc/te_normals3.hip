@@ -43,7 +43,16 @@ namespace fast {
 
 namespace {
 
-constexpr int kN3Waves = 3;  // waves per SIMD the kernel is compiled for
+#ifndef TE_N3_WAVES
+#define TE_N3_WAVES 3
+#endif
+#ifndef TE_N3_DYN_LDS
+#define TE_N3_DYN_LDS (TE_N3_WAVES > 3)
+#endif
+#ifndef TE_N3_PRIO
+#define TE_N3_PRIO 0
+#endif
+constexpr int kN3Waves = TE_N3_WAVES;  // waves per SIMD the kernel is compiled for
 // Sparse-hole march: the cells whose disc holds an invalid cell wait in a per-block queue (global scratch, it stays in L2)
 // until 64 of them fill a wavefront for the general tail.  An item is 48 bytes: Sz, Siz, Sjz, Szz, the six x/y moments
 // of the valid cells packed into three words, and (row << 8 | lane).  Up to C rows are appended between two looks at
@@ -926,8 +935,17 @@ constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 by
 template <int Q, bool KEEP, int HM, bool TIES = false>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? kN3TieWaves : kN3Waves, TIES ? kN3TieWaves : kN3Waves))) void k_normals3(N3Args a) {
   constexpr int R = Shape<Q>::R;
+#if TE_N3_DYN_LDS
+  // (a ring whose size the compiler does not see: with the static array it derives 3 waves per SIMD from the LDS size and
+  // allocates registers for that, whatever amdgpu_waves_per_eu asks for)
+  extern __shared__ double ring[];
+#else
   __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+#endif
   __shared__ unsigned long long hmask[2 * R + 2][2];  // invalid cells of the ring rows (HOLES march)
+#if TE_N3_PRIO
+  __builtin_amdgcn_s_setprio(TE_N3_PRIO);
+#endif
   // which block (uniform): [0, nb_fast) interior columns x interior rows; then the edge block columns over all rows;
   // then the top and the bottom frame rows of the interior columns
   int b = (int)blockIdx.x, bx, js, jend;
@@ -1021,12 +1039,13 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int nblocks = a.n_int * a.s_int + ne * a.s_edge + a.n_top + n_bottom;
   if (nblocks <= 0) return true;
   const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
+  constexpr unsigned kDyn = TE_N3_DYN_LDS ? (unsigned)((2 * R + 2) * (kLanes + 2 * R) * 8) : 0u;  // the ring, when the kernel declares it extern
   if (a.n_ties != 0) {  // tie radius: the whole-cell shapes only
     if constexpr (R * R == Q) {
       if (keep)
-        hipLaunchKernelGGL((k_normals3<Q, true, 2, true>), grid, dim3(kLanes), 0, s, a);
+        hipLaunchKernelGGL((k_normals3<Q, true, 2, true>), grid, dim3(kLanes), kDyn, s, a);
       else
-        hipLaunchKernelGGL((k_normals3<Q, false, 2, true>), grid, dim3(kLanes), 0, s, a);
+        hipLaunchKernelGGL((k_normals3<Q, false, 2, true>), grid, dim3(kLanes), kDyn, s, a);
       return true;
     }
     return false;
@@ -1038,11 +1057,11 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   // blocks than queues and takes the dense march, which needs no scratch.
   const bool queues_fit = (long long)nblocks * (long long)(maps > 0 ? maps : 1) <= (long long)(kN3Waves * 4) * (long long)device_cus();
   if (keep)
-    hipLaunchKernelGGL((k_normals3<Q, true, 2>), grid, dim3(kLanes), 0, s, a);
+    hipLaunchKernelGGL((k_normals3<Q, true, 2>), grid, dim3(kLanes), kDyn, s, a);
   else if (a.sparse_holes && queues_fit)
-    hipLaunchKernelGGL((k_normals3<Q, false, 1>), grid, dim3(kLanes), 0, s, a);
+    hipLaunchKernelGGL((k_normals3<Q, false, 1>), grid, dim3(kLanes), kDyn, s, a);
   else
-    hipLaunchKernelGGL((k_normals3<Q, false, 2>), grid, dim3(kLanes), 0, s, a);
+    hipLaunchKernelGGL((k_normals3<Q, false, 2>), grid, dim3(kLanes), kDyn, s, a);
   return true;
 }
 
