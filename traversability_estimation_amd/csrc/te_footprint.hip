@@ -296,35 +296,58 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     s_rough[c] = (a.check_rough || a.combine) ? rough[o] : 1.0f;
   });
   {
-    // all loads of the tile in flight at once (clamped addresses), then the LDS writes
-    constexpr int NT = MX * MBY, NL = (MTW * MTH + NT - 1) / NT;
+    // all loads of the tile in flight at once (clamped addresses), then the LDS writes.  A thread stages its own column
+    // (tile column threadIdx.x + MH) in the tile rows threadIdx.y, + MBY, ... -- one clamped column, row offsets that are
+    // multiples of MBY map rows, LDS addresses that differ by constants -- and the first 2 * MH * MTH threads one cell of
+    // the 2 * MH halo columns each.  (Round 1-4 flattened the tile over the threads: a division by MTW, two clamps and a
+    // 64-bit address per cell and pass, 40 % of the kernel's vector instructions.)
+    constexpr int KM = (MTH + MBY - 1) / MBY;
     const int tid = threadIdx.y * MX + threadIdx.x;
-    float le[NL], ls[NL];
+    const int ac = i0 + (int)threadIdx.x;
+    const bool col_in = ac < g.rows;
+    const float* const pe = elev + mo + (col_in ? ac : g.rows - 1);
+    const float* const ps = step + mo + (col_in ? ac : g.rows - 1);
+    float le[KM], ls[KM];
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      int idx = tid + k * NT;
-      idx = idx < MTW * MTH ? idx : MTW * MTH - 1;
-      const int tj = idx / MTW, ti = idx - tj * MTW;
-      int aa = i0 - MH + ti, bb = j0 - MH + tj;
-      aa = aa < 0 ? 0 : (aa >= g.rows ? g.rows - 1 : aa);
+    for (int k = 0; k < KM; ++k) {
+      int bb = j0 - MH + (int)threadIdx.y + k * MBY;
       bb = bb < 0 ? 0 : (bb >= g.cols ? g.cols - 1 : bb);
+      const size_t o = (size_t)bb * g.rows;
+      le[k] = pe[o];
+      ls[k] = ps[o];
+    }
+    // halo: tile columns 0 .. MH-1 and MX+MH .. MTW-1
+    constexpr int NH = 2 * MH * MTH;
+    static_assert(NH <= MX * MBY, "one halo cell per thread");
+    const int hj = tid / (2 * MH), hc = tid - hj * (2 * MH);
+    const int hti = hc < MH ? hc : MX + hc;  // tile column
+    const int ha = i0 - MH + hti, hb = j0 - MH + hj;
+    float he = 0.0f, hs = 0.0f;
+    if (tid < NH) {
+      const int aa = ha < 0 ? 0 : (ha >= g.rows ? g.rows - 1 : ha), bb = hb < 0 ? 0 : (hb >= g.cols ? g.cols - 1 : hb);
       const size_t o = mo + (size_t)bb * g.rows + aa;
-      le[k] = elev[o];
-      ls[k] = step[o];
+      he = elev[o];
+      hs = step[o];
     }
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int idx = tid + k * NT;
-      const int tj = idx / MTW, ti = idx - tj * MTW;
-      const int aa = i0 - MH + ti, bb = j0 - MH + tj;
-      const bool in = aa >= 0 && aa < g.rows && bb >= 0 && bb < g.cols;
-      if (idx < MTW * MTH) {
+    for (int k = 0; k < KM; ++k) {
+      const int tj = (int)threadIdx.y + k * MBY, bb = j0 - MH + tj;
+      const bool in = col_in && bb >= 0 && bb < g.cols;
+      if (tj < MTH) {
+        const int idx = tj * MTW + (int)threadIdx.x + MH;
         t_elev[idx] = in ? le[k] : qnanf();
         t_key[idx] = (in && ls[k] == 0.0f) ? le[k] : qnanf();
       }
     }
+    if (tid < NH) {
+      const bool in = ha >= 0 && ha < g.rows && hb >= 0 && hb < g.cols;
+      const int idx = hj * MTW + hti;
+      t_elev[idx] = in ? he : qnanf();
+      t_key[idx] = (in && hs == 0.0f) ? he : qnanf();
+    }
   }
   __syncthreads();
+  bool any_kl = false;  // some cell of my share has a lower step neighbour (see below: without one in the whole tile the windows have nothing to find)
   {
     // t_kl for the tile cells the windows can reach (rows 1..MTH-2, columns 1..MTW-2): the 3x3 minimum of
     // t_key slides down a column (row minimum of 3 cells, then the minimum of 3 consecutive rows).
@@ -349,6 +372,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       const int idx = r * MTW + la;
       const bool hit = (double)m < (double)t_elev[idx] - a.crit_step;  // :825 in the reference's double arithmetic
       t_kl[idx] = hit ? t_key[idx] : qnanf();
+      any_kl |= hit;
     });
     const int tid = threadIdx.y * MX + threadIdx.x;
     if (tid < 4 * (MTH - 2)) {
@@ -359,9 +383,14 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
                                   fast::vmin3(k[MTW - 1], k[MTW], k[MTW + 1]));
       const bool hit = (double)m < (double)t_elev[idx] - a.crit_step;
       t_kl[idx] = hit ? t_key[idx] : qnanf();
+      any_kl |= hit;
     }
   }
-  __syncthreads();
+  // (the barrier that publishes t_kl also tells whether the tile holds ANY lower step neighbour: on terrain without
+  // vertical faces -- a drop of more than crit_step between adjacent cells -- no tile does, t_kl is NaN throughout, both
+  // branches of the screen's test are false for every cell (NaN > thr, NaN == NaN) and the window maxima need not be
+  // formed at all: a third of the kernel's instructions on the bench map, where the step score is 0 in 98 % of the cells)
+  const bool tile_has_kl = __syncthreads_or(any_kl ? 1 : 0) != 0;
   const TileView ve = {t_elev, elev + mo, i0, j0, g.rows, MTH}, vs = {nullptr, step + mo, i0, j0, g.rows, MTH},
                  vl = {nullptr, slope + mo, i0, j0, g.rows, MTH}, vr = {nullptr, rough + mo, i0, j0, g.rows, MTH};
   const bool in_map = i < g.rows;  // (a thread beyond the last column takes no cells of its own but helps with the list below)
@@ -381,7 +410,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     h2l[slot] = fast::vmax3(h1l[slot], l[-2], l[2]);
   };
   unsigned screen_mask = 0;  // bit c: the screening pass clears my c-th cell
-  if (q5 && in_map) {
+  if (q5 && in_map && !tile_has_kl) screen_mask = (1u << NC) - 1u;
+  if (q5 && in_map && tile_has_kl) {
     fast::static_for<4>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       reduce_row(r - 2, r);  // rows -2 .. 1
@@ -408,8 +438,10 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     constexpr int c = decltype(cc)::value;
     const int j = j0 + jb + c;
     const float c_slope = s_slope[c], c_step = s_step[c], c_rough = s_rough[c];
-    const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) ||
-                                                ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
+    bool near_bad_edge = false;
+    if (__builtin_expect(a.edge_fail != 0, 0))  // (uniform; a map whose border makes the submap lookup fail is the exception)
+      near_bad_edge = ((a.edge_fail & 1) && i <= 2) || ((a.edge_fail & 2) && i >= g.rows - 3) || ((a.edge_fail & 4) && j <= 2) ||
+                      ((a.edge_fail & 8) && j >= g.cols - 3);
     const bool step_fast = !(c_step == 0.0f) || (q5 && ((screen_mask >> c) & 1u) != 0 && !near_bad_edge);
     const bool slow = (c_slope == 0.0f) || !step_fast || (a.check_rough && c_rough == 0.0f);
     slow_mask |= (slow && j < g.cols && in_map) ? (1u << c) : 0u;

@@ -108,9 +108,14 @@ struct SlideK {
     tm0[q] = bload_f(rs_t, L.o_main0, so);
     tm1[q] = bload_f(rs_t, L.o_main1, so);
     th[q] = bload_f(rs_t, L.o_halo, so);
+#ifdef TE_F5_NO_U  // (measurement only: the mask bytes not loaded -- what the three byte loads of a pass cost on a map without obstacles)
+    um0[q] = um1[q] = uh[q] = 0u;
+    (void)sb;
+#else
     um0[q] = bload_u8(rs_u, ob_main0, sb);
     um1[q] = bload_u8(rs_u, ob_main1, sb);
     uh[q] = bload_u8(rs_u, ob_halo, sb);
+#endif
   }
   template <int n>
   __device__ __forceinline__ void rotate_queue(ic<n>) {

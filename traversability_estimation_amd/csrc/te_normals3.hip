@@ -52,6 +52,9 @@ namespace {
 #ifndef TE_N3_PRIO
 #define TE_N3_PRIO 0
 #endif
+#ifndef TE_N3_WHATIF
+#define TE_N3_WHATIF 0
+#endif
 constexpr int kN3Waves = TE_N3_WAVES;  // waves per SIMD the kernel is compiled for
 // Sparse-hole march: the cells whose disc holds an invalid cell wait in a per-block queue (global scratch, it stays in L2)
 // until 64 of them fill a wavefront for the general tail.  An item is 48 bytes: Sz, Siz, Sjz, Szz, the six x/y moments
@@ -855,10 +858,19 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
             tail_clipped(j, ky);
           } else {
+#if TE_N3_WHATIF == 1  // (measurement only: no tail -- what the slide alone costs; the layers hold garbage)
+            o_slope = (float)(Sz + Siz);
+            o_rough = (float)(Sjz + Szz);
+#else
             tail(j);
+#endif
           }
         }
+#if TE_N3_WHATIF == 2  // (measurement only: no slide -- the tail, the staging and the stores alone)
+        Sz += 1.0;
+#else
         slide(uc);
+#endif
         // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
         stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
         load_row(j + 2 + R + C, pmq[u], phq[u]);
@@ -1024,14 +1036,39 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   static const int pct_env = lab_int("TE_N3_EDGE_PERCENT", 50);  // measurement aid: strip height of the edge columns in percent
   const int pct = pct_env > 0 ? pct_env : 50;
   auto edge_rows = [&](int h) { return (pct * h + 99) / 100; };
+  bool fits = false;
   for (int h = 8; h <= 512; ++h) {  // smallest strip height whose block count fits (small maps: short strips, low latency)
     const int he = edge_rows(h);
     const int blocks = a.n_int * ((Hf + h - 1) / h) + ne * ((H + he - 1) / he) + a.n_top + n_bottom;
     if (blocks <= capacity) {
       rows_int = h;
+      fits = true;
       break;
     }
   }
+  if (!fits && capacity > 0) {
+    // More blocks than resident slots whatever the strip height (a large batch -- 512 maps of 512^2: 22 blocks per map
+    // against 5.5 slots --, a very large map, a small device): the launch runs in waves of blocks and its last blocks run
+    // on a nearly empty device.  Shorter strips make that tail shorter and pay the strip start (staging 2R+2 rows and the
+    // direct sums of the first disc: about R + 6 row steps) more often; the height that minimises
+    //   (row steps of all blocks) / slots  +  half a block
+    // is taken (512 x 512^2 at R = 5: 512 -> 72 rows).
+    const double c0 = (double)(R + 6);
+    double best = 0.0;
+    for (int h = 16; h <= 512; h += 8) {
+      const int he = edge_rows(h);
+      const double si = (double)((Hf + h - 1) / h), se = (double)((H + he - 1) / he);
+      const double work = (double)a.n_int * (si > 0 ? (double)Hf + si * c0 : 0.0) + 1.5 * (double)ne * ((double)H + se * c0) +
+                          (double)(a.n_top + n_bottom) * ((double)R + c0);
+      const double t = work / (double)capacity + 0.5 * ((double)h + c0);
+      if (best == 0.0 || t < best) {
+        best = t;
+        rows_int = h;
+      }
+    }
+  }
+  static const int rows_env = lab_int("TE_N3_STRIP_ROWS", 0);  // measurement aid
+  if (rows_env > 0) rows_int = rows_env;
   a.rows_int = rows_int;
   a.rows_edge = edge_rows(rows_int);
   a.s_int = (a.n_int > 0 && Hf > 0) ? (Hf + a.rows_int - 1) / a.rows_int : 0;
