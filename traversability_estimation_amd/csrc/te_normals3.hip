@@ -88,6 +88,7 @@ struct N3Args {
   double Nd, K1h, Kr2, kinv;  // N; N*res^2*sum(di^2)/2; (N*res)^2; 1/(N(N-1))
   int Ni, SIIi;               // N and sum(di^2) = sum(dj^2) of the full disc as integers (discs with invalid cells)
   int sparse_holes;           // the map holds few invalid cells (host's count at upload): HOLES = 1 instead of 2
+  int no_holes;               // ... none at all: the clean march alone, on its slim ring (k_normals3s)
   char* hole_queue;           // HOLES = 1: kHoleQueueBytes of global scratch per block (cells waiting for the general tail)
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
@@ -102,10 +103,15 @@ struct N3Args {
   double r2, ax, ay;
 };
 
-constexpr int n3_chunk_rows(int NR) {
+constexpr int n3_chunk_rows(int NR, bool slim = false) {
   const int pref[] = {4, 5, 6, 3, 7, 8, 9, 10, 11, 2};
-  for (int c : pref)
+  // (the slim ring's row counts, 2R, rarely divide by 4: chunks of 3 or 2 rows -- with 6 rows in one unrolled body the
+  // scheduler holds the ring reads of several steps at once and spills: 168 registers + 1.9 KB of scratch at R = 9)
+  const int pref_slim[] = {4, 3, 2, 5, 6, 7, 8, 9, 10, 11};
+  for (int k = 0; k < 10; ++k) {
+    const int c = slim ? pref_slim[k] : pref[k];
     if (NR % c == 0) return c;
+  }
   return 1;
 }
 
@@ -129,13 +135,23 @@ typedef float __attribute__((address_space(1))) gfloat;
 //      number of holes).  A clean strip -- the common case by
 // far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
 // clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
-template <int Q, bool KEEP, bool GENERAL, int HOLES, bool TIES = false>
+// SLIM (clean march of a shape whose centre column alone reaches rows j +- R, i.e. hw(1) < R -- the radii just above a
+// whole number of cells, the bench's 9.000009 among them): the ring holds the 2R rows j-R+1 .. j+R only.  The two cells
+// of the slide that lie outside it are the centre column's: the leading one (row j+1+R) is the lane's own cell of the
+// row that is staged in this very step -- taken from its prefetch register --, the trailing one (row j-R) is the
+// lane's own cell of the ring row that was overwritten one step earlier -- read back just before that.  18 rows of 82
+// doubles at R = 9 are 11 808 bytes: 12 single-wave blocks per CU instead of 11 (tools/census.hip: 12 288 bytes admit 12,
+// 13 120 admit 11), i.e. three waves on every SIMD and strips 8 % shorter.
+template <int Q, bool KEEP, bool GENERAL, int HOLES, bool TIES = false, bool SLIM = false>
 __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
                                        const int jend) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
-  constexpr int NR = 2 * R + 2;  // rows j-R .. j+1+R: exactly what one slide reads
-  constexpr int C = n3_chunk_rows(NR);
+  static_assert(!SLIM || (HOLES == 0 && !TIES && R >= 1 && Shape<Q>::hw(1) < R), "the slim ring serves the clean march of a shape whose centre column alone is 2R+1 cells high");
+  constexpr int NR = SLIM ? 2 * R : 2 * R + 2;  // rows j-R .. j+1+R: exactly what one slide reads (SLIM: j-R+1 .. j+R)
+  constexpr int LEAD = SLIM ? 1 : 2;             // the step at row j stages map row j + LEAD + R
+  constexpr int OLD = SLIM ? R - 1 : R;          // the oldest ring row is map row j - OLD
+  constexpr int C = n3_chunk_rows(NR, SLIM);
   constexpr int NC = NR / C;
   constexpr int RB = W * 8;  // bytes per ring row
   char* const ringb = reinterpret_cast<char*>(ring);
@@ -240,19 +256,35 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < C; ++k) pmq[k] = phq[k] = 0.0f;
+  // SLIM: the lane's own cell of map row r as the ring would hold it (dz, +0.0 where absent) and whether it is an invalid
+  // cell of the map -- the centre column's cells that are not in the ring
+  auto own_cell = [&](int r, float pm, bool& invalid) __attribute__((always_inline)) {
+    const bool rin = GENERAL ? (r >= 0 && r < a.cols) : true;
+    const bool okm = __builtin_isfinite(pm) && rin;
+    invalid = !__builtin_isfinite(pm) && rin;
+    return (double)(okm ? pm : zref32) - zref;
+  };
+  double ctr_old = 0.0;  // SLIM: my own cell of map row j - R (the centre column's trailing cell of the next slide)
+  if constexpr (SLIM) {
+    float pm0 = 0.0f, ph0 = 0.0f;
+    load_row(js - R, pm0, ph0);
+    bool inv = false;
+    ctr_old = own_cell(js - R, pm0, inv);
+    dmask |= __any(inv) ? 1u : 0u;
+  }
   static_for<NC>([&](auto cc) __attribute__((always_inline)) {
     constexpr int c = decltype(cc)::value;
 #pragma unroll
-    for (int k = 0; k < C; ++k) load_row(js - R + c * C + k, pmq[k], phq[k]);
+    for (int k = 0; k < C; ++k) load_row(js - OLD + c * C + k, pmq[k], phq[k]);
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      stage_row(js - R + c * C + k, vb[c], k, pmq[k], phq[k]);
+      stage_row(js - OLD + c * C + k, vb[c], k, pmq[k], phq[k]);
       dmask |= row_dirty ? 1u << (c * C + k) : 0u;
     }
   });
 #pragma unroll
-  for (int k = 0; k < C; ++k) load_row(js + R + 2 + k, pmq[k], phq[k]);  // rows j + 2 + R of the first C steps
-  if (!TIES && HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march
+  for (int k = 0; k < C; ++k) load_row(js + R + LEAD + k, pmq[k], phq[k]);  // rows j + LEAD + R of the first C steps
+  if (!TIES && HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march (SLIM: the fix-up pass, see k_normals3s)
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
@@ -261,8 +293,12 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     double cs = 0.0, cj = 0.0;
     static_for<2 * h + 1>([&](auto rc) __attribute__((always_inline)) {
       constexpr int dj = decltype(rc)::value - h;
-      constexpr int p = R + dj;  // ring row of map row js + dj
-      const double z = *reinterpret_cast<const double*>(ringb + vb[p / C] + ((p % C) * RB + (R + e) * 8));
+      constexpr int p = OLD + dj;  // ring row of map row js + dj (SLIM: row js - R is not in the ring, ctr_old has the one cell of it)
+      double z;
+      if constexpr (p < 0)
+        z = ctr_old;
+      else
+        z = *reinterpret_cast<const double*>(ringb + vb[(p < 0 ? 0 : p) / C] + (((p < 0 ? 0 : p) % C) * RB + (R + e) * 8));
       cs += z;
       if (dj != 0) cj = fma((double)dj, z, cj);
       Szz = fma(z, z, Szz);
@@ -690,7 +726,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   };
 
   // ---- slide from row j to row j+1 at unrolled position u (the oldest row j-R is row u of chunk role 0) -------------
-  auto slide = [&](auto uc) __attribute__((always_inline)) {
+  auto slide = [&](auto uc, double lead_c = 0.0) __attribute__((always_inline)) {  // lead_c (SLIM): my own cell of row j + 1 + R
     constexpr int u = decltype(uc)::value;
     double sv[R + 1];  // sum of (lead + trail) over the columns of half-height h
     const double Sz0 = Sz;
@@ -699,15 +735,20 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     static_for<R + 1>([&](auto dc) __attribute__((always_inline)) {
       constexpr int d = decltype(dc)::value;
       constexpr int h = Shape<Q>::hw(d);
-      constexpr int pl = u + R + 1 + h, pt = u + R - h;  // ring positions of the leading row j+1+h and the trailing row j-h
-      constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
-      const char* rl = ringb + vb[al];
-      const char* rt = ringb + vb[at];
-      zl[R + d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R + d) * 8));
-      zt[R + d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R + d) * 8));
-      if (d != 0) {
-        zl[R - d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R - d) * 8));
-        zt[R - d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R - d) * 8));
+      if constexpr (SLIM && d == 0) {  // the centre column: neither cell is in the ring
+        zl[R] = lead_c;
+        zt[R] = ctr_old;
+      } else {
+        constexpr int pl = u + OLD + 1 + h, pt = u + OLD - h;  // ring positions of the leading row j+1+h and the trailing row j-h
+        constexpr int al = (pl / C) % NC, ol = pl % C, at = (pt / C) % NC, ot = pt % C;
+        const char* rl = ringb + vb[al];
+        const char* rt = ringb + vb[at];
+        zl[R + d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R + d) * 8));
+        zt[R + d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R + d) * 8));
+        if (d != 0) {
+          zl[R - d] = *reinterpret_cast<const double*>(rl + (ol * RB + (R - d) * 8));
+          zt[R - d] = *reinterpret_cast<const double*>(rt + (ot * RB + (R - d) * 8));
+        }
       }
     });
     // ... then the moment updates, column by column
@@ -869,11 +910,19 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
 #if TE_N3_WHATIF == 2  // (measurement only: no slide -- the tail, the staging and the stores alone)
         Sz += 1.0;
 #else
-        slide(uc);
+        if constexpr (SLIM) {
+          bool inv = false;
+          const double lead_c = own_cell(j + 1 + R, pmq[u], inv);
+          slide(uc, lead_c);
+          // my own cell of the ring's oldest row, j - R + 1, before row j + 1 + R takes its slot: the next slide's trailing centre cell
+          ctr_old = *reinterpret_cast<const double*>(ringb + vb[0] + (u * RB + R * 8));
+        } else {
+          slide(uc);
+        }
 #endif
-        // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order)
-        stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
-        load_row(j + 2 + R + C, pmq[u], phq[u]);
+        // row j+2+R replaces row j-R (same slot: LDS operations of a wave execute in order); SLIM: row j+1+R replaces row j-R+1
+        stage_row(j + LEAD + R, vb[0], u, pmq[u], phq[u]);
+        load_row(j + LEAD + R + C, pmq[u], phq[u]);
         if (out) store_row();
         ++j;
         if (__builtin_expect(row_dirty && j < jend, 0)) {  // an invalid cell: this strip needs the other march
@@ -1001,6 +1050,88 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? k
   }
 }
 
+// The clean march on the slim ring (march3, SLIM), for launches whose elevation layer holds no invalid cell at all -- the
+// host counted them at upload (N3Args::no_holes) -- and shapes whose centre column alone reaches rows j +- R.  Should an
+// invalid cell turn up all the same (the layer was written behind the library's back), the rest of the strip goes to
+// the fix-up pass, which is correct for any input.
+constexpr int n3_blocks_per_cu(int lds_bytes) {  // single-wave blocks the LDS admits (2 KiB granules, tools/census.hip), at most 3 waves per SIMD
+  const int n = (160 * 1024) / (((lds_bytes + 2047) / 2048) * 2048);
+  return n > kN3Waves * 4 ? kN3Waves * 4 : n;
+}
+// ... and only where the two rows saved buy a resident block: R = 9 (11 -> 12 per CU) and R = 10 (10 -> 11).  At smaller
+// radii both rings admit the 12 blocks the registers allow, and the slim march -- chunks of 2 or 3 rows instead of 4, more
+// chunk rotations -- measured 2 % slower there (8192^2 at R = 5: 1.156 -> 1.18 ms per launch).
+template <int Q>
+constexpr bool slim_shape() {
+  constexpr int R = Shape<Q>::R, W = kLanes + 2 * R;
+  return R >= 2 && Shape<Q>::hw(1) < R && n3_blocks_per_cu(2 * R * W * 8) > n3_blocks_per_cu((2 * R + 2) * W * 8 + (2 * R + 2) * 16);
+}
+template <int Q>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves, kN3Waves))) void k_normals3s(N3Args a) {
+  constexpr int R = Shape<Q>::R;
+  if constexpr (slim_shape<Q>()) {
+    __shared__ double ring[(2 * R) * (kLanes + 2 * R)];
+    // (the block -> strip mapping of k_normals3)
+    int b = (int)blockIdx.x, bx, js, jend;
+    bool general = true;
+    const int nb_fast = a.n_int * a.s_int, ne = a.edge0 + a.edge1;
+    if (b < nb_fast) {
+      general = false;
+      bx = a.edge0 + b % a.n_int;
+      js = a.jf_lo + (b / a.n_int) * a.rows_int;
+      jend = js + a.rows_int < a.jf_hi ? js + a.rows_int : a.jf_hi;
+    } else if ((b -= nb_fast) < ne * a.s_edge) {
+      const int q = b % ne;
+      bx = q < a.edge0 ? q : a.nbx - ne + q;
+      js = a.j_lo + (b / ne) * a.rows_edge;
+      jend = js + a.rows_edge < a.j_hi ? js + a.rows_edge : a.j_hi;
+    } else {
+      b -= ne * a.s_edge;
+      const bool bottom = b >= a.n_top;
+      bx = a.edge0 + (bottom ? b - a.n_top : b);
+      js = bottom ? a.jf_hi : a.j_lo;
+      jend = bottom ? a.j_hi : a.jf_lo;
+    }
+    const int own_lo = a.i_lo + bx * kLanes;
+    const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;
+    if (js >= jend) return;
+    const bool clean = general ? march3<Q, false, true, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend)
+                               : march3<Q, false, false, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend);
+    if (__builtin_expect(!clean, 0)) {
+      // an invalid cell after all: the whole strip goes to the fix-up pass (NaN in my cells, every tile the strip touches
+      // flagged -- the pass takes the valid cells of a flagged tile whose slope is NaN; rows the march had already stored
+      // are simply computed again)
+      const int lane = threadIdx.x;
+      const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
+      if (i0 + lane >= own_lo)
+        for (int jj = js; jj < jend; ++jj) {
+          const size_t o = mo + (size_t)jj * a.rows + (size_t)(i0 + lane);
+          a.slope[o] = a.rough[o] = __builtin_nanf("");
+        }
+      if (lane == 0) {
+        const int tile_base = (a.map >= 0 ? 0 : (int)blockIdx.z) * a.ntx * a.nty;
+        const int tc0 = (i0 - a.fi0) >> 6, tc1 = (i0 + kLanes - 1 - a.fi0) >> 6;  // a shifted block straddles two tiles
+        for (int tr = (js - a.fj0) >> 4; tr <= (jend - 1 - a.fj0) >> 4; ++tr) {
+          const int t0 = tile_base + tr * a.ntx + tc0, t1 = tile_base + tr * a.ntx + tc1;
+          a.tile_flags[(t0 % a.fix_groups) * kFixTiles + t0 / a.fix_groups] = 1;
+          a.tile_flags[(t1 % a.fix_groups) * kFixTiles + t1 / a.fix_groups] = 1;
+        }
+      }
+    }
+  }
+}
+
+template <int Q>
+int resident_blocks_slim() {
+  constexpr int R = Shape<Q>::R;
+  constexpr int lds = (2 * R) * (kLanes + 2 * R) * 8;
+  int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);
+  if (per_cu > kN3Waves * 4) per_cu = kN3Waves * 4;
+  static const int ov = lab_int("TE_N3_BLOCKS_PER_CU", 0);  // measurement aid
+  if (ov > 0) per_cu = ov < kN3Waves * 4 ? ov : kN3Waves * 4;
+  return per_cu * device_cus();
+}
+
 // Resident single-wave blocks per CU and CUs of the current device.  The LDS allocation granularity decides: at R = 9
 // (13 120 B) 11 blocks fit, not 12 (tools/census.hip), and a grid of 12 per CU runs in two rounds -- twice the time.
 template <int Q, bool KEEP>
@@ -1023,7 +1154,11 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const int H = a.j_hi - a.j_lo;
   // As many blocks as fill the resident wave slots in ONE round.  Edge block columns run the general tail on every row
   // (about 1.5x the time of an interior row): their strips are 1.5x shorter so that all blocks finish together.
-  const int capacity = (keep ? resident_blocks<Q, true>(a.n_ties != 0) : resident_blocks<Q, false>(a.n_ties != 0)) / (maps > 0 ? maps : 1);
+  static const bool no_slim = lab_flag("TE_N3_NO_SLIM");  // measurement aid
+  const bool slim = slim_shape<Q>() && a.no_holes && !keep && a.n_ties == 0 && !no_slim;
+  const int resident = slim ? resident_blocks_slim<Q>() : keep ? resident_blocks<Q, true>(a.n_ties != 0) : resident_blocks<Q, false>(a.n_ties != 0);
+  const int capacity = resident / (maps > 0 ? maps : 1);
+  const double capacity_f = (double)resident / (double)(maps > 0 ? maps : 1);  // slots per map
   const int ne = a.edge0 + a.edge1;
   constexpr int R = Shape<Q>::R;
   a.n_int = a.nbx - ne;
@@ -1046,13 +1181,13 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
       break;
     }
   }
-  if (!fits && capacity > 0) {
+  if (!fits) {
     // More blocks than resident slots whatever the strip height (a large batch -- 512 maps of 512^2: 22 blocks per map
     // against 5.5 slots --, a very large map, a small device): the launch runs in waves of blocks and its last blocks run
     // on a nearly empty device.  Shorter strips make that tail shorter and pay the strip start (staging 2R+2 rows and the
     // direct sums of the first disc: about R + 6 row steps) more often; the height that minimises
     //   (row steps of all blocks) / slots  +  half a block
-    // is taken (512 x 512^2 at R = 5: 512 -> 72 rows).
+    // is taken (512 x 512^2 at R = 5: 512 -> 176 rows; normals pass 1.16 -> 0.97 ms).
     const double c0 = (double)(R + 6);
     double best = 0.0;
     for (int h = 16; h <= 512; h += 8) {
@@ -1060,7 +1195,7 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
       const double si = (double)((Hf + h - 1) / h), se = (double)((H + he - 1) / he);
       const double work = (double)a.n_int * (si > 0 ? (double)Hf + si * c0 : 0.0) + 1.5 * (double)ne * ((double)H + se * c0) +
                           (double)(a.n_top + n_bottom) * ((double)R + c0);
-      const double t = work / (double)capacity + 0.5 * ((double)h + c0);
+      const double t = work / capacity_f + 0.5 * ((double)h + c0);
       if (best == 0.0 || t < best) {
         best = t;
         rows_int = h;
@@ -1086,6 +1221,10 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
       return true;
     }
     return false;
+  }
+  if (slim) {
+    hipLaunchKernelGGL((k_normals3s<Q>), grid, dim3(kLanes), 0, s, a);
+    return true;
   }
   // (the kernel that keeps the normals -- the plugin path -- exists with the dense march only)
   // The sparse march indexes its queue scratch by block (blockIdx.x + gridDim.x * blockIdx.z) and the scratch holds one
@@ -1231,6 +1370,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.Nd = N;
   a.Ni = d.npoints;
   a.sparse_holes = L.sparse_holes && L.hole_queue ? 1 : 0;
+  a.no_holes = L.no_holes;
   a.hole_queue = L.hole_queue;
   a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;

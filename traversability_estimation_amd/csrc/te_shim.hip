@@ -524,6 +524,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.fb_walk = c->opt_fb_walk;
   c->L.fb_blocks_per_cu = c->opt_fb_blocks_per_cu;
   c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
+  c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
   c->L.hole_queue = c->hole_queue;
   ensure_tie_scratch(c);  // (likewise)
   c->L.tie_scratch = c->tie_scratch;
@@ -569,7 +570,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     int slot = -1;
     // (the captured launches bake in which k_normals3 variant runs: the hint is part of the key)
     ensure_tie_scratch(c);
-    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u);
+    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u) | (c->invalid_cells == 0 ? 0x40000000u : 0u);
     for (int k = 0; k < te_ctx::kGraphs; ++k)
       if (c->graph_exec[k] && c->graph_flags[k] == key) slot = k;
     if (slot < 0) {
