@@ -401,7 +401,7 @@ def main():
                          "ms_per_launch": ms_chain, "ms_per_launch_stat": f"median of {n_samples} launches, one HIP event pair each "
                                                                           f"(p10 {np.percentile(chain_samples, 10):.4f}, p90 {np.percentile(chain_samples, 90):.4f})",
                          "algorithmic_bytes_per_cell": bytes_per_cell,
-                         "dominant_kernel": {"name": "k_normals3 (+ k_normals_fixup), alone on the GPU (TE_RUN_NORMALS_ONLY; rocprofv3 "
+                         "dominant_kernel": {"name": "the normals pass (k_normals3s or k_normals3, + k_normals_fixup), alone on the GPU (TE_RUN_NORMALS_ONLY; rocprofv3 "
                                                      "lists the two kernels separately, profiles/)",
                                              "ms": ms_normals, "algorithmic_bytes_per_cell": 12,
                                              "achieved": B * n * n * 12 / (ms_normals * 1e-3) / 1e9,

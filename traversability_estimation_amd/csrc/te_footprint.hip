@@ -250,6 +250,12 @@ struct MaskArgs {
   float w_scale, w_slope, w_step, w_rough;
   int ti0, tj0, map;  // first tile of the launch (in tiles of MX x MY cells) and the map (< 0: blockIdx.z): region runs
   unsigned* blocked_count;  // the first mask launch of a pass empties k_fp_slide4's list (nullptr: not this launch)
+  // one byte per 64 x 4 cells (all maps): "holds an untraversable cell".  A block clears the flags of its tile before its
+  // first barrier and a thread that finds a cell untraversable -- behind the barriers -- sets the flag of the cell's rows:
+  // after the kernel a clear flag says that none of the 256 mask bytes is 1.  (k_fp_slide5 reads no mask bytes where
+  // every flag of its strip is clear.)
+  uint8_t* untrav_flags;
+  int flag_ntx, flag_nfy;
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
@@ -275,6 +281,13 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   // (the footprint pass's list of blocked cells starts empty: k_fp_slide4 / k_fp_blocked run after this kernel)
   if (a.blocked_count && threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
     a.blocked_count[0] = a.blocked_count[1] = 0u;
+  // my tile's flags (flag rows j0 / 4 .. of flag column i0 / 64: i0 and j0 are multiples of 64 and of MY)
+  uint8_t* const my_flags = a.untrav_flags + ((size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * a.flag_nfy) * a.flag_ntx + (i0 >> 6);
+  {
+    constexpr int NF = MY / 4;
+    const int t = threadIdx.y * MX + threadIdx.x;
+    if (t < NF && (j0 >> 2) + t < a.flag_nfy) my_flags[(size_t)((j0 >> 2) + t) * a.flag_ntx] = 0;
+  }
   // The three scores of this thread's MY/MBY cells: issued together with the tile loads, so that they
   // are in flight during the staging and the two LDS passes (clamped rows; a thread beyond the last column has nothing to do but must reach the barrier).
   constexpr int NC = MY / MBY;
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
         m_rough = ok ? 1.0f : 0.0f;
       }
       untrav[o] = ok ? 0 : 1;
+      if (!ok) my_flags[(size_t)(j >> 2) * a.flag_ntx] = 1;
       if (a.write_memo) {
         slope_fp[o] = m_slope;
         step_fp[o] = m_step;
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       m_rough = ok ? 1.0f : 0.0f;
     }
     untrav[o] = ok ? 0 : 1;
+    if (!ok) my_flags[(size_t)(j >> 2) * a.flag_ntx] = 1;
     if (a.write_memo) {
       slope_fp[o] = m_slope;
       step_fp[o] = m_step;
@@ -1007,6 +1022,9 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.ti0 = m.tj0 = 0;
   m.map = -1;
   m.blocked_count = L.fp_blocked_count;
+  m.untrav_flags = L.untrav_flags;
+  m.flag_ntx = untrav_flag_ntx(g.rows);
+  m.flag_nfy = untrav_flag_nfy(g.cols);
   // A region run (te_run_chain_region with the footprint flag): isTraversableForFilters of a cell reads scores within
   // 3 cells (circle(3 res), circle(2.5 res) and the 3x3 blocks around its cells), so the mask is recomputed on the
   // region grown by MH; the footprint of a cell reads the mask and the traversability within the footprint's reach.
@@ -1027,7 +1045,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   const long tiles32 = (long)((rm.i1 - rm.i0 + MX - 1) / MX) * ((rm.j1 - rm.j0 + 31) / 32) * (region ? 1 : (g.batch > 0 ? g.batch : 1));
   static const int small_env = lab_int("TE_MASK_SMALL_TILES", -1);
   const bool small = small_env >= 0 ? small_env != 0 : tiles32 < 1024;  // fewer than 4 workgroups per CU
-  const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : 32);  // a very small map: one cell per thread
+  static const int tile_env = lab_int("TE_MASK_TILE", 0);  // measurement aid: 16-row tiles on large maps (8 blocks per CU instead of 5)
+  const int my = (small && tiles32 < 128 && small_env != 8) ? 4 : (small ? 8 : (tile_env == 16 ? 16 : 32));  // a very small map: one cell per thread
   // the mask kernel on the tile rows [t0, t1) (tiles of my cells) of the region
   auto launch_mask = [&](int t0, int t1, hipStream_t st) {
     if (t1 <= t0) return;
@@ -1038,6 +1057,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
       hipLaunchKernelGGL(k_fp_mask<4>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
     else if (my == 8)
       hipLaunchKernelGGL(k_fp_mask<8>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+#ifdef TE_LAB
+    else if (my == 16)
+      hipLaunchKernelGGL(k_fp_mask<16>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
+#endif
     else
       hipLaunchKernelGGL(k_fp_mask<32>, grid, dim3(MX, MBY), 0, st, g, m, L.elev, L.slope, L.step, L.rough, L.untrav, L.slope_fp, L.step_fp, L.rough_fp, L.trav);
   };

@@ -48,6 +48,13 @@ struct F5Args {
   unsigned* blocked_count;  // ... [0] entries reserved, [1] entries that hold a cell (k_fp_mask resets both)
   int chunk;                // entries a block reserves at a time
   size_t list_cap;          // (host side: the launcher refuses a grid whose unfinished chunks might not fit)
+  // one byte per 64 x 4 cells, written by k_fp_mask: "holds an untraversable cell" (Layers::untrav_flags).  A strip whose
+  // flags are all clear -- on terrain without obstacles every strip -- does not fetch its mask bytes: the byte loads stay
+  // in the instruction stream, but their descriptor is given zero records, and a raw buffer load beyond its records
+  // returns 0 without a memory request.  (Built without the loads, for timing only, the footprint pass went from 0.160 to
+  // 0.148-0.154 ms: profiles/r04_experiments.json.)
+  const uint8_t* untrav_flags;
+  int flag_ntx, flag_nfy;
 };
 
 template <int Q>
@@ -88,7 +95,18 @@ struct SlideK {
     r0 = js_ - R;
     row_bytes = (unsigned)a.rows * 4u;
     rs_t = make_rsrc(a.trav + mo + ((long long)(js_ - R) * a.rows + (i0 - R)));
-    rs_u = make_rsrc(a.untrav + mo + ((long long)(js_ - R) * a.rows + (i0 - R)));
+    {
+      // the flags of every 64 x 4 block the strip's window touches: columns i0 - R .. i0 + 63 + R, rows js - R .. jend - 1 + R
+      const int c0 = (i0 - R < 0 ? 0 : i0 - R) >> 6, c1 = (i0 + kLanes - 1 + R > a.rows - 1 ? a.rows - 1 : i0 + kLanes - 1 + R) >> 6;
+      const int f0 = (js_ - R < 0 ? 0 : js_ - R) >> 2, f1 = (jend - 1 + R > a.cols - 1 ? a.cols - 1 : jend - 1 + R) >> 2;
+      const int nc = c1 - c0 + 1, n = nc * (f1 - f0 + 1);
+      const uint8_t* fl = a.untrav_flags + (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.flag_nfy * (size_t)a.flag_ntx;
+      unsigned any = 0;
+      for (int k = lane; k < n; k += kLanes) any |= fl[(size_t)(f0 + k / nc) * a.flag_ntx + (size_t)(c0 + k % nc)];
+      const bool clean = !__any(any != 0u);  // (uniform)
+      const void* ub = a.untrav + mo + ((long long)(js_ - R) * a.rows + (i0 - R));
+      rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ub), /*stride*/ 0, /*num_records*/ clean ? 0 : 0x7fffffff, /*flags*/ 0x00020000);
+    }
     rs_out = make_rsrc(a.footprint + mo + ((long long)(js_ - 2 * R) * a.rows + (i0 - R)));
     icol = i0 + lane;
     own = icol >= own_lo;
@@ -385,6 +403,9 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.blocked_count = L.fp_blocked_count;
   a.chunk = kF4Chunk;
   a.list_cap = L.fp_blocked_cap;
+  a.untrav_flags = L.untrav_flags;
+  a.flag_ntx = untrav_flag_ntx(g.rows);
+  a.flag_nfy = untrav_flag_nfy(g.cols);
   bool launched = f5_launch_part0(shape, &a, g.batch, s);
 #if TE_PARTS > 1
   launched = launched || f5_launch_part1(shape, &a, g.batch, s) || f5_launch_part2(shape, &a, g.batch, s) || f5_launch_part3(shape, &a, g.batch, s) ||

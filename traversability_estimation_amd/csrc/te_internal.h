@@ -104,6 +104,8 @@ struct Layers {
   unsigned* fp_blocked_count;  // ... and its length (k_fp_mask resets it)
   size_t fp_blocked_cap;       // entries the list holds (cells + fast::f4_list_slack)
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
+  uint8_t* untrav_flags;  // one byte per 64 x 4 cells: "holds an untraversable cell" as of the mask kernel's last pass over them (1 until then);
+                          // k_fp_slide5 does not fetch the mask bytes of a strip whose flags are all clear
   int* clip_table;     // x/y moments of the normals disc clipped by the map border (build_clip_table)
   // second stream + fork/join events: step filter || normals kernel on whole-map runs (nullptr: sequential)
   hipStream_t aux_stream;
@@ -221,6 +223,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
                             const int* clip_table, bool write_memo, const ChainParams* combine, double trav_cap, hipStream_t stream,
                             const Region* region = nullptr);
 int chain_max_reach(const ChainParams& p);
+// the flag grid of Layers::untrav_flags: one byte per 64 x 4 cells of every map
+inline int untrav_flag_ntx(int rows) { return (rows + 63) / 64; }
+inline int untrav_flag_nfy(int cols) { return (cols + 3) / 4; }
+inline size_t untrav_flag_bytes(int rows, int cols, int batch) { return (size_t)untrav_flag_ntx(rows) * (size_t)untrav_flag_nfy(cols) * (size_t)batch; }
 // te_paths.hip: checkCircularFootprintPath for a batch of paths on the (complete) footprint layer of one map;
 // robot_slope: the layer checkInclination reads (nullptr: footprint/check_robot_inclination off)
 hipError_t launch_check_circular_paths(const Geo& g, const float* footprint, double fp_default, const float* robot_slope,

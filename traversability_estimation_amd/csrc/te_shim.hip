@@ -839,7 +839,9 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     const size_t qb = (list_cap * sizeof(unsigned) + 255) & ~(size_t)255;
     // (guard: kSlabGuardRows rows of slack before the first and behind the last layer -- te_internal.h)
     const size_t guard = ((size_t)kSlabGuardRows * (size_t)rows * sizeof(float) + 255) & ~(size_t)255;
-    const size_t total = guard + 13 * lb + ub + fb + qb + 256 + guard;
+    // (+ one byte per 64 x 4 cells: "holds an untraversable cell", written by the mask kernel, 1 = unknown until then)
+    const size_t ufb = (untrav_flag_bytes(rows, cols, batch) + 255) & ~(size_t)255;
+    const size_t total = guard + 13 * lb + ub + fb + qb + 256 + ufb + guard;
     hipError_t e = hipMalloc(&slab, total);
     if (e != hipSuccess) return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", total, hipGetErrorString(e));
     c->slab = slab;
@@ -852,10 +854,12 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     c->L.fp_blocked = list_cap < ((size_t)1 << 32) ? (unsigned*)(b + 13 * lb + ub + fb) : nullptr;
     c->L.fp_blocked_count = (unsigned*)(b + 13 * lb + ub + fb + qb);
     c->L.fp_blocked_cap = list_cap;
+    c->L.untrav_flags = (uint8_t*)(b + 13 * lb + ub + fb + qb + 256);
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
     HIP_TRY(hipMemsetAsync(slab, 0xFF, guard + 13 * lb + ub + fb, c->stream));
-    HIP_TRY(hipMemsetAsync(b + 13 * lb + ub + fb + qb + 256, 0xFF, guard, c->stream));
+    HIP_TRY(hipMemsetAsync(b + 13 * lb + ub + fb + qb + 256 + ufb, 0xFF, guard, c->stream));
+    HIP_TRY(hipMemsetAsync(c->L.untrav_flags, 0x01, ufb, c->stream));
     HIP_TRY(hipMemsetAsync(c->L.fp_blocked_count, 0, 256, c->stream));
     // the fix-up flags are zero between launches: k_normals_fixup clears every flag it consumes
     HIP_TRY(hipMemsetAsync(c->L.block_flags, 0, fb, c->stream));
