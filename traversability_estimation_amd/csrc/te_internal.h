@@ -113,6 +113,7 @@ struct Layers {
   int fb_walk, fb_blocks_per_cu;  // te_set_option: k_fp_blocked's walk (0: by the length of the list, 1: per wavefront, 2: per lane) and grid (0: default)
   int sparse_holes;  // 1: at most a few per mille of the elevation cells are invalid (counted at upload): k_normals3 takes its sparse march
   int no_holes;      // 1: none of them is (counted at upload): the clean march alone, on its slim ring (k_normals3s)
+  int skip_clean;    // 1: scattered invalid cells, several per strip on average (sparse march): the clean march is not attempted first
   char* hole_queue;  // its scratch: normals_hole_queue_bytes() (te_normals3.hip), nullptr: the dense march serves
 };
 

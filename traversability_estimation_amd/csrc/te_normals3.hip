@@ -89,6 +89,7 @@ struct N3Args {
   int Ni, SIIi;               // N and sum(di^2) = sum(dj^2) of the full disc as integers (discs with invalid cells)
   int sparse_holes;           // the map holds few invalid cells (host's count at upload): HOLES = 1 instead of 2
   int no_holes;               // ... none at all: the clean march alone, on its slim ring (k_normals3s)
+  int skip_clean;             // sparse holes on nearly every strip: straight to the HOLES = 1 march (Layers::skip_clean)
   char* hole_queue;           // HOLES = 1: kHoleQueueBytes of global scratch per block (cells waiting for the general tail)
   float inv_slope_crit, inv_rough_crit;
   float Krf;                  // N*res (normals only)
@@ -1039,8 +1040,9 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? k
       march3<Q, KEEP, false, 0, true>(a, ring, hmask, i0, own_lo, js, jend);
     return;
   }
-  const bool clean = general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
-                             : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
+  const bool clean = (HM == 1 && a.skip_clean) ? false  // (uniform) nearly every strip holds an invalid cell: no first attempt
+                      : general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
+                                : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
   if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
     __syncthreads();
     if (general)
@@ -1371,6 +1373,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.Ni = d.npoints;
   a.sparse_holes = L.sparse_holes && L.hole_queue ? 1 : 0;
   a.no_holes = L.no_holes;
+  a.skip_clean = L.skip_clean;
   a.hole_queue = L.hole_queue;
   a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;

@@ -217,6 +217,17 @@ bool sparse_holes(const te_ctx* c) {
   return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems;
 }
 
+// Sparse holes, and so many of them that hardly a strip is free of them (a strip's window is some 8 000 cells: from three
+// expected invalid cells per window on): k_normals3's clean first attempt would be given up within its first rows on
+// nearly every strip (0.1 % speckle: 99.99 % of them) -- it is skipped.  (Clustered holes -- unobserved regions -- take the
+// dense march by their count and keep the attempt: most of their strips ARE clean.)
+bool skip_clean_march(const te_ctx* c) {
+#ifdef TE_NO_SKIP_CLEAN  // (A/B builds only)
+  return false;
+#endif
+  return sparse_holes(c) && (double)c->invalid_cells * 8000.0 >= 3.0 * (double)c->layer_elems;
+}
+
 // the sparse march's queues; false (and the dense kernel) if the allocation fails
 bool ensure_hole_queue(te_ctx* c) {
   if (c->hole_queue) return true;
@@ -525,6 +536,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.fb_blocks_per_cu = c->opt_fb_blocks_per_cu;
   c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
   c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
+  c->L.skip_clean = c->L.sparse_holes && skip_clean_march(c) ? 1 : 0;
   c->L.hole_queue = c->hole_queue;
   ensure_tie_scratch(c);  // (likewise)
   c->L.tie_scratch = c->tie_scratch;
@@ -570,7 +582,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     int slot = -1;
     // (the captured launches bake in which k_normals3 variant runs: the hint is part of the key)
     ensure_tie_scratch(c);
-    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u) | (c->invalid_cells == 0 ? 0x40000000u : 0u);
+    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u) | (c->invalid_cells == 0 ? 0x40000000u : 0u) | (skip_clean_march(c) ? 0x20000000u : 0u);
     for (int k = 0; k < te_ctx::kGraphs; ++k)
       if (c->graph_exec[k] && c->graph_flags[k] == key) slot = k;
     if (slot < 0) {
