@@ -992,26 +992,11 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   return true;
 }
 
-constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 bytes of scratch (local copies of the moments, the general
-                                // tail on every row); compiled for 2 waves the compiler takes all 256 and spills 500 bytes on top
-template <int Q, bool KEEP, int HM, bool TIES = false>
-__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? kN3TieWaves : kN3Waves, TIES ? kN3TieWaves : kN3Waves))) void k_normals3(N3Args a) {
-  constexpr int R = Shape<Q>::R;
-#if TE_N3_DYN_LDS
-  // (a ring whose size the compiler does not see: with the static array it derives 3 waves per SIMD from the LDS size and
-  // allocates registers for that, whatever amdgpu_waves_per_eu asks for)
-  extern __shared__ double ring[];
-#else
-  __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
-#endif
-  __shared__ unsigned long long hmask[2 * R + 2][2];  // invalid cells of the ring rows (HOLES march)
-#if TE_N3_PRIO
-  __builtin_amdgcn_s_setprio(TE_N3_PRIO);
-#endif
-  // which block (uniform): [0, nb_fast) interior columns x interior rows; then the edge block columns over all rows;
-  // then the top and the bottom frame rows of the interior columns
-  int b = (int)blockIdx.x, bx, js, jend;
-  bool general = true;
+// Which strip a block works on (uniform): blocks [0, nb_fast) are the interior columns x interior rows, then come the edge
+// block columns over all rows, then the top and the bottom frame rows of the interior columns.  false: nothing to do.
+__device__ __forceinline__ bool n3_block(const N3Args& a, int& i0, int& own_lo, int& js, int& jend, bool& general) {
+  int b = (int)blockIdx.x, bx;
+  general = true;
   const int nb_fast = a.n_int * a.s_int, ne = a.edge0 + a.edge1;
   if (b < nb_fast) {
     general = false;
@@ -1030,9 +1015,30 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? k
     js = bottom ? a.jf_hi : a.j_lo;
     jend = bottom ? a.j_hi : a.jf_lo;
   }
-  const int own_lo = a.i_lo + bx * kLanes;
-  const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
-  if (js >= jend) return;
+  own_lo = a.i_lo + bx * kLanes;
+  i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
+  return js < jend;
+}
+
+constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 bytes of scratch (local copies of the moments, the general
+                                // tail on every row); compiled for 2 waves the compiler takes all 256 and spills 500 bytes on top
+template <int Q, bool KEEP, int HM, bool TIES = false>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? kN3TieWaves : kN3Waves, TIES ? kN3TieWaves : kN3Waves))) void k_normals3(N3Args a) {
+  constexpr int R = Shape<Q>::R;
+#if TE_N3_DYN_LDS
+  // (a ring whose size the compiler does not see: with the static array it derives 3 waves per SIMD from the LDS size and
+  // allocates registers for that, whatever amdgpu_waves_per_eu asks for)
+  extern __shared__ double ring[];
+#else
+  __shared__ double ring[(2 * R + 2) * (kLanes + 2 * R)];
+#endif
+  __shared__ unsigned long long hmask[2 * R + 2][2];  // invalid cells of the ring rows (HOLES march)
+#if TE_N3_PRIO
+  __builtin_amdgcn_s_setprio(TE_N3_PRIO);
+#endif
+  int i0, own_lo, js, jend;
+  bool general;
+  if (!n3_block(a, i0, own_lo, js, jend, general)) return;
   if constexpr (TIES) {  // (a strip with invalid cells flags its tiles for the fix-up pass itself)
     if (general)
       march3<Q, KEEP, true, 0, true>(a, ring, hmask, i0, own_lo, js, jend);
@@ -1073,30 +1079,9 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
   constexpr int R = Shape<Q>::R;
   if constexpr (slim_shape<Q>()) {
     __shared__ double ring[(2 * R) * (kLanes + 2 * R)];
-    // (the block -> strip mapping of k_normals3)
-    int b = (int)blockIdx.x, bx, js, jend;
-    bool general = true;
-    const int nb_fast = a.n_int * a.s_int, ne = a.edge0 + a.edge1;
-    if (b < nb_fast) {
-      general = false;
-      bx = a.edge0 + b % a.n_int;
-      js = a.jf_lo + (b / a.n_int) * a.rows_int;
-      jend = js + a.rows_int < a.jf_hi ? js + a.rows_int : a.jf_hi;
-    } else if ((b -= nb_fast) < ne * a.s_edge) {
-      const int q = b % ne;
-      bx = q < a.edge0 ? q : a.nbx - ne + q;
-      js = a.j_lo + (b / ne) * a.rows_edge;
-      jend = js + a.rows_edge < a.j_hi ? js + a.rows_edge : a.j_hi;
-    } else {
-      b -= ne * a.s_edge;
-      const bool bottom = b >= a.n_top;
-      bx = a.edge0 + (bottom ? b - a.n_top : b);
-      js = bottom ? a.jf_hi : a.j_lo;
-      jend = bottom ? a.j_hi : a.jf_lo;
-    }
-    const int own_lo = a.i_lo + bx * kLanes;
-    const int i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;
-    if (js >= jend) return;
+    int i0, own_lo, js, jend;
+    bool general;
+    if (!n3_block(a, i0, own_lo, js, jend, general)) return;
     const bool clean = general ? march3<Q, false, true, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend)
                                : march3<Q, false, false, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend);
     if (__builtin_expect(!clean, 0)) {

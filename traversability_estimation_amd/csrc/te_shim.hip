@@ -1286,6 +1286,11 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   HIP_TRY(hipSetDevice(c->device));
   ensure_tie_scratch(c);
   c->L.tie_scratch = c->tie_scratch;
+  // (the hints the normals kernel takes from the upload's count, as run_chain_locked sets them: never stale ones)
+  c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;
+  c->L.hole_queue = c->hole_queue;
+  c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
+  c->L.skip_clean = c->L.sparse_holes && skip_clean_march(c) ? 1 : 0;
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
   // A single plugin's filter overwrites score layers from whatever inputs are resident (TE_FILTER_NORMALS also slope
   // and roughness, with the normals radius): the layers no longer form one chain result, so region re-filters, the
