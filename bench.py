@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+VALU_CYCLES_PER_INST, N_SIMDS, CLOCK_HZ = 4.2, 1024, 2.4e9  # measured issue rate of fp64 / 3-operand instructions per SIMD (profiles/r01_valu_rates.txt)
 FP64_LANE_OPS_PEAK = 39.3e12  # 78.6 TFLOP/s vector fp64 = 39.3e12 fused multiply-adds (lane operations) per second
 # double-precision lane operations per cell of one launch: the sliding moments of k_normals3 (6 per disc
 # column and edge + 1 per distinct run length: 118 at R = 9, scaled with 2R+1 for other radii) and its tail (31)
@@ -432,6 +433,35 @@ def main():
                 out["roofline"]["traffic_unit"] = f"bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/{os.path.basename(hit[0])})"
             else:
                 out["roofline"]["traffic_unit"] = f"not reported: profiles/{os.path.basename(tpaths[0])} was taken with other kernel sources"
+        # What this FORMULATION can reach at most: the launch is bound by vector-instruction issue, so
+        # the sum of the kernels' VALU floors -- executed vector instructions (SQ_INSTS_VALU of the committed counter
+        # profile) x 4.2 cycles per wavefront instruction / (1024 SIMDs x 2.4 GHz) -- is a lower bound of its time,
+        # whatever the overlap.  `frac` is to be read against this ceiling, not against 1.
+        spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), reverse=True)
+        if spaths and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0:
+            try:
+                sq = json.load(open(spaths[0]))
+                floors = {}
+                for kname, rec in sq.items():
+                    if kname.startswith("k_combine") or kname.startswith("k_count_invalid") or kname == "kernel_sources_sha16":
+                        continue  # (the sequential profile's separate combine: inside k_fp_mask in the timed launch; upload-time count)
+                    v = rec.get("counters", {}).get("SQ_INSTS_VALU")
+                    if v:
+                        floors[kname] = v * VALU_CYCLES_PER_INST / (N_SIMDS * CLOCK_HZ) * 1e6
+                floor_us = sum(floors.values())
+                if floor_us > 0:
+                    ceiling = B * n * n * bytes_per_cell / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    out["roofline"]["formulation_ceiling"] = ceiling
+                    out["roofline"]["frac_of_ceiling"] = out["roofline"]["frac"] / ceiling
+                    out["roofline"]["formulation_ceiling_what"] = {
+                        "valu_floor_us": {k: round(v, 1) for k, v in sorted(floors.items())}, "valu_floor_us_sum": round(floor_us, 1),
+                        "model": f"SQ_INSTS_VALU x {VALU_CYCLES_PER_INST} cycles / ({N_SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz), every kernel of the launch; "
+                                 "fp64 and 3-operand instructions issue once per 4.2 cycles per SIMD (profiles/r01_valu_rates.txt)",
+                        "source": f"profiles/{os.path.basename(spaths[0])}",
+                        "note": "an fp64 sliding-disc formulation at R = 9 is bound by vector-instruction issue, not by HBM: "
+                                "the 50 % north-star presumes a bandwidth-bound stencil, which this is not (DESIGN.md 4)"}
+            except (OSError, ValueError, KeyError) as e:
+                out["roofline"]["formulation_ceiling_error"] = str(e)
         if host_path is not None:
             out["host_path"] = host_path
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only

@@ -208,7 +208,11 @@ int te_run_chain(te_ctx* ctx, unsigned flags);
  * change (the re-filtered cells grown by 3 cells for isTraversableForFilters and by the footprint's reach); the
  * traversability_footprint layer must have been complete before (te_run_chain with the flag, or te_run_footprint),
  * TE_ERR_NOT_READY otherwise.  The caller of the reference's node re-filters the whole map on every update
- * (TraversabilityMap.cpp:202-237); this is the incremental form of the same call. */
+ * (TraversabilityMap.cpp:202-237); this is the incremental form of the same call.
+ * A footprint shape none of the shape-specialised sum kernels takes (a tie radius that is not a whole number of cells,
+ * a reach of 17..20 cells, a map narrower than 64 cells) is served by the general kernel, which recomputes the footprint
+ * layer of the WHOLE map `map` (no other map of the batch): cost O(map), not O(region); cells outside the region are
+ * recomputed from unchanged inputs and keep their values to within the fixed-point kernels' rounding (< 1e-6). */
 int te_run_chain_region(te_ctx* ctx, unsigned flags, int map, int row0, int col0, int h, int w);
 /* The h x w rectangle at (row0, col0) of a layer of map `map` into a packed column-major h x w host tile (the layout
  * te_upload_tile reads); returns when the tile is in host memory. */

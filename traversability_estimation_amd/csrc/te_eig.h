@@ -7,6 +7,10 @@
 namespace te {
 namespace fast {
 
+// a raw (unclipped) score 1 - x / crit that lies within `band` of the clip at 0: see kExactNaNBits (te_internal.h)
+__device__ __forceinline__ bool near_clip(float raw, float band) { return __builtin_fabsf(raw) < band; }
+__device__ __forceinline__ float exact_nanf() { return __builtin_bit_cast(float, kExactNaNBits); }
+
 __device__ __forceinline__ double rsqrt_nr(double x) {  // x > 0
   double y = __builtin_amdgcn_rsq(x);
   const double hx = 0.5 * x;

@@ -150,7 +150,89 @@ __device__ __forceinline__ bool check_step_screen(const Disc& d, const float* __
   return !hit;
 }
 
-// checkForStep :794-865
+// ---- checkForStep :794-865, in pieces ---------------------------------------------------------------------------------
+// GridMap::getSubmap -> getSubmapInformation (grid_map_core) for a 2.5*res square around a cell centre: the corners lie
+// 1.25 cells from the centre, i.e. 0.25 cells inside the neighbouring cells, or are clamped into the border cell by
+// boundPositionToRange: the submap is exactly the 3x3 block clipped to the map (rounding of 1e-13 cells cannot move a
+// corner across a cell boundary a quarter cell away) -- unless the clamped corner rounds onto the map border and the
+// lookup fails (:818-822), which submap_edge_failures() decides per border side with the reference's own arithmetic.
+struct Submap {
+  int ti, tj, sr, sc;  // first cell and size; GridMapIterator runs over it with the row index fastest: a = lin % sr, b = lin / sr
+};
+__device__ __forceinline__ Submap submap_of(const Geo& g, int ii, int ij) {
+  Submap s;
+  s.ti = ii > 0 ? ii - 1 : 0;
+  s.tj = ij > 0 ? ij - 1 : 0;
+  const int bi = ii < g.rows - 1 ? ii + 1 : g.rows - 1, bj = ij < g.cols - 1 ? ij + 1 : g.cols - 1;
+  s.sr = bi - s.ti + 1;
+  s.sc = bj - s.tj + 1;
+  return s;
+}
+// v = position of submap cell (a, b) - position of the candidate (ii, ij), with the submap's own geometry (length
+// re-derived by setGeometry) as the reference computes it (:826-828)
+__device__ __forceinline__ void pair_vector(const Geo& g, int ii, int ij, const Submap& s, int a, int b, double& vx, double& vy) {
+  const double sx = cell_x(g, ii), sy = cell_y(g, ij);  // subMapPos
+  const double tcornx = cell_x(g, s.ti) + 0.5 * g.res, tcorny = cell_y(g, s.tj) + 0.5 * g.res;
+  const double slx = (double)s.sr * g.res, sly = (double)s.sc * g.res;
+  const double spx = tcornx - 0.5 * slx, spy = tcorny - 0.5 * sly;
+  const double px = (spx + (0.5 * slx - 0.5 * g.res)) + g.res * (double)(-a);
+  const double py = (spy + (0.5 * sly - 0.5 * g.res)) + g.res * (double)(-b);
+  vx = px - sx;
+  vy = py - sy;
+}
+// :833-856 for a pair (candidate (ii, ij) of elevation `height`, direction v) that passed :825 and :829-832: the ray is
+// extended up to max_gap_width, the Bresenham line to its end is walked.  true: checkForStep returns false because of
+// this pair (an obstacle on the line, :840-843, or a gap that does not end, :853-856).  A property of the candidate and
+// the direction alone -- not of the centre cell whose check runs into it.
+__device__ bool pair_blocks(const Geo& g, const TileView& elev, int ii, int ij, double vx, double vy, double height, double crit_step,
+                            double max_gap) {
+  const double sx = cell_x(g, ii), sy = cell_y(g, ij);
+  const double lowest = height - crit_step;
+  double qx = sx + vx, qy = sy + vy;
+  for (int guard = 0; guard < 100000; ++guard) {  // :834
+    const double ex = (qx - sx) + vx, ey = (qy - sy) + vy;
+    if (!(sqrt(ex * ex + ey * ey) < max_gap && pos_inside(g, qx + vx, qy + vy))) break;
+    qx += vx;
+    qy += vy;
+  }
+  int ei, ej;
+  pos_to_index(g, qx, qy, ei, ej);
+  ei = ei < 0 ? 0 : (ei > g.rows - 1 ? g.rows - 1 : ei);
+  ej = ej < 0 ? 0 : (ej > g.cols - 1 ? g.cols - 1 : ej);
+  // LineIterator (Bresenham, grid_map_core) from `index` to `endIndex` :839-852
+  const int dx = ei > ii ? ei - ii : ii - ei, dy = ej > ij ? ej - ij : ij - ej;
+  int inc1i = (ei >= ii) ? 1 : -1, inc2i = inc1i, inc1j = (ej >= ij) ? 1 : -1, inc2j = inc1j;
+  int den, num, numadd, ncells;
+  if (dx >= dy) {
+    inc1i = 0; inc2j = 0; den = dx; num = dx / 2; numadd = dy; ncells = dx + 1;
+  } else {
+    inc2i = 0; inc1j = 0; den = dy; num = dy / 2; numadd = dx; ncells = dy + 1;
+  }
+  int li = ii, lj = ij;
+  bool gap_start = false, gap_end = false;
+  for (int icell = 0; icell < ncells; ++icell) {
+    const float ef = elev.at(li, lj);
+    if ((double)ef > height + crit_step) return true;  // :840-843
+    if ((double)ef < lowest || !__builtin_isfinite(ef)) {
+      gap_start = true;
+    } else if (gap_start) {
+      gap_end = true;
+      break;
+    }
+    num += numadd;
+    if (num >= den) {
+      num -= den;
+      li += inc1i;
+      lj += inc1j;
+    }
+    li += inc2i;
+    lj += inc2j;
+  }
+  return gap_start && !gap_end;  // :853-856
+}
+
+// checkForStep :794-865, straight: every (candidate, submap cell) pair evaluated where the centre cell meets it.  Serves the
+// general disc shapes and the cells next to a border whose submap lookups fail.
 __device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, const TileView& step, int ci, int cj,
                            double crit_step, double max_gap, int edge_fail) {
   const double cx = cell_x(g, ci), cy = cell_y(g, cj);
@@ -164,78 +246,87 @@ __device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, co
   if (ncand == 0) cand[ncand++] = (ci << 16) | cj;  // :811
   for (int c = 0; c < ncand; ++c) {
     const int ii = cand[c] >> 16, ij = cand[c] & 0xffff;
-    const double sl = 2.5 * g.res;                         // subMapLength :813
-    // GridMap::getSubmap -> getSubmapInformation (grid_map_core) for a 2.5*res square around a cell centre:
-    // the corners lie 1.25 cells from the centre, i.e. 0.25 cells inside the neighbouring cells, or are
-    // clamped into the border cell by boundPositionToRange: the submap is exactly the 3x3 block clipped to
-    // the map (rounding of 1e-13 cells cannot move a corner across a cell boundary a quarter cell away) --
-    // unless the clamped corner rounds onto the map border and the lookup fails (:818-822), which
-    // submap_edge_failures() decides per border side with the reference's own arithmetic.
-    (void)sl;
-    if (submap_fails(g, edge_fail, ii, ij)) return false;
-    const int ti = ii > 0 ? ii - 1 : 0, tj = ij > 0 ? ij - 1 : 0;
-    const int bi = ii < g.rows - 1 ? ii + 1 : g.rows - 1, bj = ij < g.cols - 1 ? ij + 1 : g.cols - 1;
-    const int sr = bi - ti + 1, sc = bj - tj + 1;
+    if (submap_fails(g, edge_fail, ii, ij)) return false;  // :817-822
+    const Submap sm = submap_of(g, ii, ij);
     height = (double)elev.at(ii, ij);  // :823
     const double lowest = height - crit_step;
-    for (int lin = 0; lin < sr * sc; ++lin) {  // GridMapIterator over the submap: row index fastest
-      const int a = lin % sr, b = lin / sr;
-      if (!(step.at(ti + a, tj + b) == 0.0f && (double)elev.at(ti + a, tj + b) < lowest)) continue;  // :825
-      // the submap's own geometry (length re-derived by setGeometry), only needed for the rare hits
-      const double sx = cell_x(g, ii), sy = cell_y(g, ij);   // subMapPos
-      const double tcx = cx - sx, tcy = cy - sy;             // toCenter :816
-      const double tcornx = cell_x(g, ti) + 0.5 * g.res, tcorny = cell_y(g, tj) + 0.5 * g.res;
-      const double slx = (double)sr * g.res, sly = (double)sc * g.res;
-      const double spx = tcornx - 0.5 * slx, spy = tcorny - 0.5 * sly;
-      const double px = (spx + (0.5 * slx - 0.5 * g.res)) + g.res * (double)(-a);
-      const double py = (spy + (0.5 * sly - 0.5 * g.res)) + g.res * (double)(-b);
-      const double vx = px - sx, vy = py - sy;
+    const double tcx = cx - cell_x(g, ii), tcy = cy - cell_y(g, ij);  // toCenter :816
+    for (int lin = 0; lin < sm.sr * sm.sc; ++lin) {  // GridMapIterator over the submap: row index fastest
+      const int a = lin % sm.sr, b = lin / sm.sr;
+      if (!(step.at(sm.ti + a, sm.tj + b) == 0.0f && (double)elev.at(sm.ti + a, sm.tj + b) < lowest)) continue;  // :825
+      double vx, vy;
+      pair_vector(g, ii, ij, sm, a, b, vx, vy);
       if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
       if (sqrt(tcx * tcx + tcy * tcy) > 0.025) {      // :830-832
         if (tcx * vx + tcy * vy < 0.0) continue;
       }
-      double qx = sx + vx, qy = sy + vy;
-      for (int guard = 0; guard < 100000; ++guard) {  // :834
-        const double ex = (qx - sx) + vx, ey = (qy - sy) + vy;
-        if (!(sqrt(ex * ex + ey * ey) < max_gap && pos_inside(g, qx + vx, qy + vy))) break;
-        qx += vx;
-        qy += vy;
-      }
-      int ei, ej;
-      pos_to_index(g, qx, qy, ei, ej);
-      ei = ei < 0 ? 0 : (ei > g.rows - 1 ? g.rows - 1 : ei);
-      ej = ej < 0 ? 0 : (ej > g.cols - 1 ? g.cols - 1 : ej);
-      // LineIterator (Bresenham, grid_map_core) from `index` to `endIndex` :839-852
-      const int dx = ei > ii ? ei - ii : ii - ei, dy = ej > ij ? ej - ij : ij - ej;
-      int inc1i = (ei >= ii) ? 1 : -1, inc2i = inc1i, inc1j = (ej >= ij) ? 1 : -1, inc2j = inc1j;
-      int den, num, numadd, ncells;
-      if (dx >= dy) {
-        inc1i = 0; inc2j = 0; den = dx; num = dx / 2; numadd = dy; ncells = dx + 1;
-      } else {
-        inc2i = 0; inc1j = 0; den = dy; num = dy / 2; numadd = dx; ncells = dy + 1;
-      }
-      int li = ii, lj = ij;
-      bool gap_start = false, gap_end = false;
-      for (int icell = 0; icell < ncells; ++icell) {
-        const float ef = elev.at(li, lj);
-        if ((double)ef > height + crit_step) return false;  // :840-843
-        if ((double)ef < lowest || !__builtin_isfinite(ef)) {
-          gap_start = true;
-        } else if (gap_start) {
-          gap_end = true;
-          break;
-        }
-        num += numadd;
-        if (num >= den) {
-          num -= den;
-          li += inc1i;
-          lj += inc1j;
-        }
-        li += inc2i;
-        lj += inc2j;
-      }
-      if (gap_start && !gap_end) return false;  // :853-856
+      if (pair_blocks(g, elev, ii, ij, vx, vy, height, crit_step, max_gap)) return false;
     }
+  }
+  return true;
+}
+
+// ---- the same with the pairs' ray / line tests MEMOISED per candidate (k_fp_mask, tiles that hold a vertical face) ----
+// Whether a pair (candidate n, submap cell m) makes checkForStep return false -- :825 holds for m, m is not n itself, and
+// pair_blocks() -- does not depend on the centre cell; only the direction filter :830-832 does.  Next to a kerb every
+// candidate is met by up to 21 centres (circle(2.5 res)), each of which used to walk the candidate's rays again: one cell
+// beside a tall edge ran 189 pairs, ~1500 instructions each, 70 us in its thread, and the tile waited for it.  Now a tile
+// evaluates the pairs of its candidates ONCE (pair_mask: one bit per submap cell, for every tile cell that can be a
+// candidate and has a lower step neighbour -- the cells of t_kl), all threads sharing the candidates, and a centre's check
+// is a look at 21 masks plus the direction filter for the set bits.
+__device__ unsigned pair_mask(const Geo& g, const TileView& elev, const float* __restrict__ t_elev, const float* __restrict__ t_key, int idx,
+                              int ii, int ij, double crit_step, double max_gap) {
+  const Submap sm = submap_of(g, ii, ij);
+  const double height = (double)t_elev[idx];  // :823
+  const double lowest = height - crit_step;
+  unsigned f = 0;
+  for (int lin = 0; lin < sm.sr * sm.sc; ++lin) {
+    const int a = lin % sm.sr, b = lin / sm.sr;
+    const int m = idx + (sm.tj + b - ij) * MTW + (sm.ti + a - ii);
+    const float km = t_key[m];  // elevation where the step score is 0 (NaN elsewhere): :825
+    if (!((double)km < lowest)) continue;
+    double vx, vy;
+    pair_vector(g, ii, ij, sm, a, b, vx, vy);
+    if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
+    if (pair_blocks(g, elev, ii, ij, vx, vy, height, crit_step, max_gap)) f |= 1u << lin;
+  }
+  return f;
+}
+// circle(2.5 res) is the tie-free shape Q = 5 (rows dj = 0, +-1 span |di| <= 2, rows dj = +-2 span |di| <= 1); cells
+// outside the map are NaN in t_key and fail the candidate test like being skipped.
+__device__ bool check_step_memo(const Geo& g, const float* __restrict__ t_elev, const float* __restrict__ t_key,
+                                const unsigned short* __restrict__ fmask, int ctr, int ci, int cj, double crit_step, int edge_fail) {
+  const double cx = cell_x(g, ci), cy = cell_y(g, cj);
+  const double thr = crit_step + (double)t_elev[ctr];
+  int ncand = 0;
+  for (int dj = -2; dj <= 2; ++dj) {
+    const int hw = (dj == -2 || dj == 2) ? 1 : 2;
+    for (int di = -hw; di <= hw; ++di) {
+      const int idx = ctr + dj * MTW + di;
+      if (!((double)t_key[idx] > thr)) continue;  // :807-809 (t_key: the elevation where the step score is 0)
+      ++ncand;
+      const int ii = ci + di, ij = cj + dj;
+      if (submap_fails(g, edge_fail, ii, ij)) return false;  // :817-822
+      unsigned f = fmask[idx];
+      if (f == 0u) continue;
+      const Submap sm = submap_of(g, ii, ij);
+      const double tcx = cx - cell_x(g, ii), tcy = cy - cell_y(g, ij);  // toCenter :816
+      const bool filter = sqrt(tcx * tcx + tcy * tcy) > 0.025;           // :830
+      while (f) {
+        const int lin = __ffs((int)f) - 1;
+        f &= f - 1u;
+        if (filter) {
+          double vx, vy;
+          pair_vector(g, ii, ij, sm, lin % sm.sr, lin / sm.sr, vx, vy);
+          if (tcx * vx + tcy * vy < 0.0) continue;  // :831
+        }
+        return false;
+      }
+    }
+  }
+  if (ncand == 0) {  // :811 the centre is its own candidate; toCenter = 0: no direction filter
+    if (submap_fails(g, edge_fail, ci, cj)) return false;
+    if (fmask[ctr] != 0) return false;
   }
   return true;
 }
@@ -274,8 +365,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   __shared__ float t_elev[MTW * MTH], t_key[MTW * MTH], t_kl[MTW * MTH];
   // the slow cells' list (below): entries, wavefronts past the screening pass, wavefronts with slow cells, of those the ones
   // whose entries are in the list -- zeroed here, before the first barrier
-  __shared__ int ntodo, arrived, members, compacted;
-  if (threadIdx.x == 0 && threadIdx.y == 0) ntodo = arrived = members = compacted = 0;
+  __shared__ int ntodo, arrived, members, compacted, nkl;
+  if (threadIdx.x == 0 && threadIdx.y == 0) ntodo = arrived = members = compacted = nkl = 0;
   const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * g.rows * g.cols;
   const int i0 = ((int)blockIdx.x + a.ti0) * MX, j0 = ((int)blockIdx.y + a.tj0) * MY;
   // (the footprint pass's list of blocked cells starts empty: k_fp_slide4 / k_fp_blocked run after this kernel)
@@ -520,6 +611,114 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     }
     return;  // (uniform)
   }
+  if (tile_has_kl) {  // (uniform)
+    // The tile holds a vertical face.  Every wavefront stays (real barriers: such a tile has slow cells to share):
+    //   1. the candidates with a lower step neighbour -- the non-NaN cells of t_kl -- are collected from the whole tile
+    //      (own cells and halo), by the threads that computed them;
+    //   2. their pair masks are evaluated, 256 candidates at a time (pair_mask: the reference's ray / line geometry, once
+    //      per candidate instead of once per centre that meets it);
+    //   3. the slow cells are listed and shared as below, their step check being check_step_memo.
+    // t_kl is dead once every thread is through the screening pass: its memory holds the candidate list (later the slow
+    // cells' list) and the pair masks, one unsigned short each per tile cell.
+    constexpr int NCELL = MTW * MTH;
+    static_assert(sizeof(t_kl) >= 2 * NCELL * sizeof(unsigned short), "candidate list + pair masks fit the tile they replace");
+    static_assert(NCELL % 2 == 0, "pair masks are cleared word by word");
+    unsigned short* const klist = reinterpret_cast<unsigned short*>(t_kl);
+    unsigned short* const fmask = klist + NCELL;
+    const int tid = threadIdx.y * MX + threadIdx.x;
+    // (1) my share of t_kl, read before anything overwrites it: the column segment of the 3x3-minimum pass + one edge cell
+    constexpr int SEG = (MTH - 2) / MBY;
+    unsigned klbits = 0;
+    {
+      const int la = threadIdx.x + 2, r0 = 1 + threadIdx.y * SEG;
+#pragma unroll
+      for (int q = 0; q < SEG; ++q) {
+        const float v = t_kl[(r0 + q) * MTW + la];
+        klbits |= (v == v) ? (1u << q) : 0u;
+      }
+      if (tid < 4 * (MTH - 2)) {
+        const int col = (tid & 3) == 0 ? 1 : MTW - 5 + (tid & 3);
+        const float v = t_kl[(1 + (tid >> 2)) * MTW + col];
+        klbits |= (v == v) ? 0x80000000u : 0u;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < NCELL / 2; k += MX * MBY) reinterpret_cast<unsigned*>(fmask)[k] = 0u;
+    if (klbits != 0u) {
+      int at = atomicAdd(&nkl, __popc(klbits));
+      const int la = threadIdx.x + 2, r0 = 1 + threadIdx.y * SEG;
+      unsigned bits = klbits & 0x7fffffffu;
+      while (bits) {
+        const int q = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        klist[at++] = (unsigned short)((r0 + q) * MTW + la);
+      }
+      if (klbits & 0x80000000u) klist[at++] = (unsigned short)((1 + (tid >> 2)) * MTW + ((tid & 3) == 0 ? 1 : MTW - 5 + (tid & 3)));
+    }
+    __syncthreads();
+    // (2)
+    {
+      const int n_kl = nkl;
+#pragma unroll 1
+      for (int k = tid; k < n_kl; k += MX * MBY) {
+        const int idx = klist[k];
+        const int lb = idx / MTW, la2 = idx - lb * MTW;
+        fmask[idx] = (unsigned short)pair_mask(g, ve, t_elev, t_key, idx, i0 - MH + la2, j0 - MH + lb, a.crit_step, a.max_gap);
+      }
+    }
+    __syncthreads();
+    // (3) the slow cells, into the candidate list's memory
+    unsigned short* const todo2 = klist;
+    fast::static_for<NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const bool need = ((slow_mask >> c) & 1u) != 0;
+      const unsigned long long bm = __ballot(need);
+      if (bm != 0ull) {  // uniform
+        int base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(&ntodo, __popcll(bm));
+        base = __shfl(base, 0);
+        if (need)
+          todo2[base + __popcll(bm & ((1ull << threadIdx.x) - 1ull))] =
+              (unsigned short)(((jb + c) << 7) | ((((screen_mask >> c) & 1u) != 0 ? 1 : 0) << 6) | (int)threadIdx.x);
+      }
+    });
+    __syncthreads();
+    const int n_todo2 = ntodo;
+#pragma unroll 1
+    for (int k = tid; k < n_todo2; k += MX * MBY) {
+      const int e = todo2[k];
+      const int li = e & 63, lj = e >> 7;
+      const bool screened = ((e >> 6) & 1) != 0;
+      const int ci = i0 + li, j = j0 + lj;
+      const size_t o = mo + (size_t)j * g.rows + ci;
+      const float c_slope = slope[o], c_step = step[o], c_rough = (a.check_rough || a.combine) ? rough[o] : 1.0f;
+      float m_slope = qnanf(), m_step = qnanf(), m_rough = qnanf();
+      bool ok = true;
+      if (c_slope == 0.0f) {  // checkForSlope
+        ok = count_zero_ok(g, a.slope_disc, vl, ci, j, a.ncrit_slope);
+        m_slope = ok ? 1.0f : 0.0f;
+      }
+      if (ok && c_step == 0.0f) {  // checkForStep
+        const bool near_bad_edge = a.edge_fail && (((a.edge_fail & 1) && ci <= 2) || ((a.edge_fail & 2) && ci >= g.rows - 3) ||
+                                                    ((a.edge_fail & 4) && j <= 2) || ((a.edge_fail & 8) && j >= g.cols - 3));
+        ok = (screened && !near_bad_edge) ||
+             check_step_memo(g, t_elev, t_key, fmask, (lj + MH) * MTW + (li + MH), ci, j, a.crit_step, a.edge_fail);
+        m_step = ok ? 1.0f : 0.0f;
+      }
+      if (ok && a.check_rough && c_rough == 0.0f) {  // checkForRoughness
+        ok = count_zero_ok(g, a.slope_disc, vr, ci, j, a.ncrit_rough);
+        m_rough = ok ? 1.0f : 0.0f;
+      }
+      untrav[o] = ok ? 0 : 1;
+      if (!ok) my_flags[(size_t)(j >> 2) * a.flag_ntx] = 1;
+      if (a.write_memo) {
+        slope_fp[o] = m_slope;
+        step_fp[o] = m_step;
+        rough_fp[o] = m_rough;
+      }
+    }
+    return;  // (uniform)
+  }
   // No barrier: on a map without obstacles no tile has a slow cell, and two barriers per tile cost the mask kernel 5 of
   // its 72 us.  A wavefront (one tile row of threads) without slow cells signs off and leaves; the others wait -- LDS
   // counters, all wavefronts of a workgroup are resident together -- until every wavefront is through the screening pass
@@ -603,6 +802,7 @@ struct SpiralArgs {
   double rmin, rmax, def;
   int out_rows;
   int inner_q;  // see k_fp_slide, step (0)
+  int map0;     // first map of the launch (a region run covers its own map only)
 };
 
 // Ring encoding: one double per cell, T' + kUOff * U with T' = traversability (NaN -> default) and
@@ -628,7 +828,7 @@ __global__ __launch_bounds__(kLanes, kFpWaves) void k_fp_slide(Geo g, SpiralArgs
   constexpr bool kPipe = R <= 10;  // software-pipelined ring reads (needs 8(R+1) more VGPRs)
   __shared__ double ring[NR * W];
   const int lane = threadIdx.x;
-  const size_t mo = (size_t)blockIdx.z * g.rows * g.cols;
+  const size_t mo = (size_t)(a.map0 + (int)blockIdx.z) * g.rows * g.cols;
   const int i0 = blockIdx.x * kLanes;
   const int js = blockIdx.y * a.out_rows;
   const int jend = js + a.out_rows < g.cols ? js + a.out_rows : g.cols;
@@ -1069,7 +1269,17 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // measured in round 3 with k_fp_slide4 (0.418 ms per launch against 0.385) and again in round 4 with k_fp_slide5 and
   // 2 / 3 / 4 / 6 bands on two streams (0.393 / 0.425 / 0.462 / 0.589 against 0.375, profiles/r04_experiments.json): the two
   // kernels slow each other down by more than they overlap, and every band pays the strips' 2R lead-in rows again.)
-  launch_mask(t_lo, t_hi, stream);
+  // What-if (lab library only, tools/lab/r05_exp1.sh; results wrong by construction): the sum kernel on the second stream
+  // BESIDE the mask kernel instead of behind it -- the two kernels' instruction streams sharing the machine, which is the
+  // most a fusion of the two could overlap.
+  static const bool whatif_concurrent = lab_flag("TE_FP_WHATIF_CONCURRENT");
+  hipStream_t sum_stream = stream;
+  if (whatif_concurrent && L.aux_stream && !region) {
+    (void)hipEventRecord(L.ev_fork, stream);
+    (void)hipStreamWaitEvent(L.aux_stream, L.ev_fork, 0);
+    sum_stream = L.aux_stream;
+  }
+  if (!fast::footprint_slide5_replaces_mask()) launch_mask(t_lo, t_hi, stream);
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;
   const Disc& d = p.fp_disc;
@@ -1090,8 +1300,12 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // tie-free disc of an instantiated shape on a map at least one block wide: the scatter-form sum on fixed point, ...
   {
     bool needs_blocked = false;
-    if (fast::footprint_slide5(g, p, L, clip_table, trav_cap, stream, rfp, &needs_blocked)) {
-      if (needs_blocked) fast::footprint_blocked4(g, p, L, spiral_table, stream);
+    if (fast::footprint_slide5(g, p, L, clip_table, trav_cap, sum_stream, rfp, &needs_blocked)) {
+      if (needs_blocked) fast::footprint_blocked4(g, p, L, spiral_table, sum_stream);
+      if (sum_stream != stream) {
+        (void)hipEventRecord(L.ev_join, sum_stream);
+        (void)hipStreamWaitEvent(stream, L.ev_join, 0);
+      }
       return hipGetLastError();
     }
   }
@@ -1099,15 +1313,16 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   if (fast::footprint_slide4(g, p, L, spiral_table, clip_table, trav_cap, stream, rfp) ||
       fast::footprint_slide3(g, p, L, spiral_table, clip_table, stream, rfp))
     return hipGetLastError();
-  // (the kernel below always covers every cell of every map: a region run falls back to it -- the cells outside the
-  // region get the values they had, recomputed from unchanged inputs: correct, and slower)
+  // (the kernel below always covers every cell of a map: a region run falls back to it for the region's map -- the cells
+  // outside the region are recomputed from unchanged inputs.  Where an earlier whole-map pass wrote them with the
+  // fixed-point kernels they move by that kernel's rounding, below 1e-6; include/travgpu.h says so at te_run_chain_region)
   {  // one round of resident waves (kFpWaves per SIMD): as many strips as fit
     const int nbx = (g.rows + kLanes - 1) / kLanes;
     const int Rk = p.reach;
     const long ring_bytes = (long)(2 * Rk + 3) * (kLanes + 2 * Rk) * 8;
     long per_cu = 160 * 1024 / ring_bytes;  // blocks (= waves) per CU the LDS allows
     if (per_cu > kFpWaves * 4) per_cu = kFpWaves * 4;
-    int strips = (int)((per_cu * 256) / (nbx * (g.batch > 0 ? g.batch : 1)));
+    int strips = (int)((per_cu * 256) / (nbx * (region ? 1 : (g.batch > 0 ? g.batch : 1))));
     strips = strips < 1 ? 1 : strips;
     int rows_per = (g.cols + strips - 1) / strips;
     // (a small map cannot fill the wave slots anyway: every block is resident at once and the launch takes one warm-up
@@ -1116,8 +1331,9 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
     a.out_rows = rows_per < min_rows ? min_rows : (rows_per > 512 ? 512 : rows_per);
     a.out_rows = a.out_rows < 1 ? 1 : a.out_rows;
   }
+  a.map0 = region ? region->map : 0;
   const dim3 grid((unsigned)((g.rows + kLanes - 1) / kLanes), (unsigned)((g.cols + a.out_rows - 1) / a.out_rows),
-                  (unsigned)g.batch);
+                  (unsigned)(region ? 1 : g.batch));
   // (the compile-time run tables of this kernel, Q >= 0, are no longer instantiated: tie-free discs of the instantiated
   // shapes go to k_fp_slide3 above unless the map is narrower than a wavefront, where speed is not a concern)
   switch (p.reach) {

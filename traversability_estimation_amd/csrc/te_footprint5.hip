@@ -55,6 +55,16 @@ struct F5Args {
   // 0.148-0.154 ms: profiles/r04_experiments.json.)
   const uint8_t* untrav_flags;
   int flag_ntx, flag_nfy;
+#ifdef TE_F5_WHATIF_FUSED
+  // WHAT-IF BUILD (timing only, results wrong by construction; tools/lab/r05_exp1.sh): "one footprint kernel" -- the march
+  // stages elevation and the three scores itself (12 loads per pass instead of 6), combines them (MathExpressionFilter),
+  // stores the combined layer and a mask byte for its own rows, and sums; isTraversableForFilters is stubbed (every cell
+  // passes) and k_fp_mask is not launched.  What the fusion could gain at most, before any of its difficulties.
+  const float *w_elev, *w_slope, *w_step, *w_rough;
+  float* w_trav;
+  uint8_t* w_untrav;
+  float ws, wa, wb, wc;
+#endif
 };
 
 template <int Q>
@@ -70,6 +80,10 @@ struct SlideK {
   int js, nout, r0;               // r0 = js - R: the strip's first input row (the descriptors' row 0)
   float tm0[C], tm1[C], th[C];
   unsigned um0[C], um1[C], uh[C];
+#ifdef TE_F5_WHATIF_FUSED
+  brsrc rs_e, rs_s, rs_p, rs_r, rs_tw, rs_uw;
+  float e0[C], e1[C], eh[C], s0[C], s1[C], sh[C], p0[C], p1[C], ph[C], q0[C], q1[C], qh[C];
+#endif
   unsigned* lds;   // [2][W]
   unsigned c0, c1;
   unsigned ubits;  // my own cells' U, newest row in bit 0
@@ -108,6 +122,17 @@ struct SlideK {
       rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ub), /*stride*/ 0, /*num_records*/ clean ? 0 : 0x7fffffff, /*flags*/ 0x00020000);
     }
     rs_out = make_rsrc(a.footprint + mo + ((long long)(js_ - 2 * R) * a.rows + (i0 - R)));
+#ifdef TE_F5_WHATIF_FUSED
+    {
+      const long long o = (long long)mo + ((long long)(js_ - R) * a.rows + (i0 - R));
+      rs_e = make_rsrc(a.w_elev + o);
+      rs_s = make_rsrc(a.w_slope + o);
+      rs_p = make_rsrc(a.w_step + o);
+      rs_r = make_rsrc(a.w_rough + o);
+      rs_tw = make_rsrc(a.w_trav + o);
+      rs_uw = make_rsrc(a.w_untrav + o);
+    }
+#endif
     icol = i0 + lane;
     own = icol >= own_lo;
     rmin_zero = a.rmin == 0.0;
@@ -123,6 +148,15 @@ struct SlideK {
   template <int q>
   __device__ __forceinline__ void load_pair(int r, ic<q>) {
     const unsigned sb = (unsigned)(r - r0) * (unsigned)a.rows, so = sb * 4u;  // (uniform; the mask is one byte per cell)
+#ifdef TE_F5_WHATIF_FUSED
+    e0[q] = bload_f(rs_e, L.o_main0, so); e1[q] = bload_f(rs_e, L.o_main1, so); eh[q] = bload_f(rs_e, L.o_halo, so);
+    s0[q] = bload_f(rs_s, L.o_main0, so); s1[q] = bload_f(rs_s, L.o_main1, so); sh[q] = bload_f(rs_s, L.o_halo, so);
+    p0[q] = bload_f(rs_p, L.o_main0, so); p1[q] = bload_f(rs_p, L.o_main1, so); ph[q] = bload_f(rs_p, L.o_halo, so);
+    q0[q] = bload_f(rs_r, L.o_main0, so); q1[q] = bload_f(rs_r, L.o_main1, so); qh[q] = bload_f(rs_r, L.o_halo, so);
+    um0[q] = um1[q] = uh[q] = 0u;
+    tm0[q] = tm1[q] = th[q] = 0.0f;
+    return;
+#endif
     tm0[q] = bload_f(rs_t, L.o_main0, so);
     tm1[q] = bload_f(rs_t, L.o_main1, so);
     th[q] = bload_f(rs_t, L.o_halo, so);
@@ -139,6 +173,10 @@ struct SlideK {
   __device__ __forceinline__ void rotate_queue(ic<n>) {
     if constexpr (n % C != 0) {
       static_assert(C == 2, "a queue of two passes");
+#ifdef TE_F5_WHATIF_FUSED
+      auto sw = [](float (&x)[C]) { const float t = x[0]; x[0] = x[1]; x[1] = t; };
+      sw(e0); sw(e1); sw(eh); sw(s0); sw(s1); sw(sh); sw(p0); sw(p1); sw(ph); sw(q0); sw(q1); sw(qh);
+#endif
       const float f0 = tm0[0], f1 = tm1[0], fh = th[0];
       const unsigned u0 = um0[0], u1 = um1[0], u2 = uh[0];
       tm0[0] = tm0[1];
@@ -162,6 +200,27 @@ struct SlideK {
   }
   template <int q>
   __device__ __forceinline__ void stage_pair(int r, ic<q>) {
+#ifdef TE_F5_WHATIF_FUSED
+    {
+      auto comb = [&](float sl, float st, float ro) { return a.ws * ((a.wa * sl + a.wb * st) + a.wc * ro); };
+      auto stub = [&](float el, float st) { return (st == 0.0f && el > 1e30f) ? 1u : 0u; };  // (never 1: keeps the elevation loads alive)
+      tm0[q] = comb(s0[q], p0[q], q0[q]);
+      tm1[q] = comb(s1[q], p1[q], q1[q]);
+      th[q] = comb(sh[q], ph[q], qh[q]);
+      um0[q] = stub(e0[q], p0[q]);
+      um1[q] = stub(e1[q], p1[q]);
+      uh[q] = stub(eh[q], ph[q]);
+      const unsigned so = (unsigned)(r - r0) * row_bytes, sb = (unsigned)(r - r0) * (unsigned)a.rows;
+      if ((unsigned)(r - js) < (unsigned)nout) {  // (uniform) my own rows: the combined layer and the mask byte
+        bstore_f(rs_tw, L.o_main0, so, tm0[q]);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)um0[q], rs_uw, ob_main0, sb, 0);
+      }
+      if ((unsigned)(r + 1 - js) < (unsigned)nout) {
+        bstore_f(rs_tw, L.o_main1, so, tm1[q]);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)um1[q], rs_uw, ob_main1, sb, 0);
+      }
+    }
+#endif
     c0 = pack(tm0[q], um0[q]);
     c1 = pack(tm1[q], um1[q]);
     unsigned vh = L.halo_in ? pack(th[q], uh[q]) : 0u;  // cells outside the map: nothing
@@ -357,6 +416,15 @@ bool f5_launch_part3(int Q, const void* args, int batch, hipStream_t s);
 bool f5_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
+// What-if build only (TE_F5_WHATIF_FUSED): the sum kernel also stands in for the mask kernel, which is then not launched.
+bool footprint_slide5_replaces_mask() {
+#ifdef TE_F5_WHATIF_FUSED
+  return true;
+#else
+  return false;
+#endif
+}
+
 // The scatter-form sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken
 // (the caller tries k_fp_slide4, then the double kernel).  tcap: upper bound of the finite values of the traversability
 // layer, as the host can prove it (the layer was written by the chain: w_scale * (w_slope + w_step + w_rough) with
@@ -374,6 +442,9 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   // the fixed-point scale: the T-sum of a whole disc (npoints cells of at most cap * 2^k + 1/2 each) must stay below
   // 2^27 -- the untraversable flag's bit -- and the default value that replaces NaN has to fit as well
   if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
+  // (the march loads rows beyond the layers it is given, te_internal.h; the mask bytes are a quarter of a float layer's
+  // rows in bytes, so the float test of the mask's own rows is the stricter one)
+  if (!layer_has_guard_rows(L.trav, g, sizeof(float)) || !layer_has_guard_rows(L.untrav, g, sizeof(uint8_t))) return false;
   const double cap = (tcap > p.def ? tcap : p.def) * (1.0 + 1e-6) + 1e-12;
   int k = 23;
   while (k >= 0 && (double)d.npoints * (cap * ldexp(1.0, k) + 1.0) >= (double)(1u << kF5UBit)) --k;
@@ -406,6 +477,15 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.untrav_flags = L.untrav_flags;
   a.flag_ntx = untrav_flag_ntx(g.rows);
   a.flag_nfy = untrav_flag_nfy(g.cols);
+#ifdef TE_F5_WHATIF_FUSED
+  a.w_elev = L.elev;
+  a.w_slope = L.slope;
+  a.w_step = L.step;
+  a.w_rough = L.rough;
+  a.w_trav = L.trav;
+  a.w_untrav = L.untrav;
+  a.ws = a.wa = a.wb = a.wc = 1.0f / 3.0f;  // (timing only)
+#endif
   bool launched = f5_launch_part0(shape, &a, g.batch, s);
 #if TE_PARTS > 1
   launched = launched || f5_launch_part1(shape, &a, g.batch, s) || f5_launch_part2(shape, &a, g.batch, s) || f5_launch_part3(shape, &a, g.batch, s) ||

@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -66,6 +67,25 @@ struct ChainParams {
   int step_ncrit;
   float w_scale, w_slope, w_step, w_rough;
 };
+
+// THE CLIP OF A SCORE.  SlopeFilter / RoughnessFilter clip their scores at 0 (SlopeFilter.cpp:77-81, RoughnessFilter.cpp:119-124)
+// and the footprint checks treat "score == 0" as a category of its own: checkForSlope / checkForRoughness run -- and
+// memoise -- only where the score IS 0 (TraversabilityMap.cpp:869, :897).  A fast tail whose score lands within its own
+// error of the clip therefore does not decide the cell: it writes the kExactNaN payload into the slope layer and flags the
+// tile, and the fix-up pass settles the cell with the generic arithmetic (gather in the generic order, cyclic Jacobi,
+// double acos: bit-identical to the generic kernels and the oracle).  The bands are the fast tails' error bounds in score
+// units with a margin of 3, from the parameters (host side):
+//   slope:  (float32 acos polynomial + float rounding: 4e-7 rad  +  one float32 ulp of nz: 1.2e-7 / sin(crit) rad) / crit
+//   roughness: float32 square root, product and 1/crit: 3 * 2^-23, relative to a score distance of 1 at the clip
+constexpr unsigned kExactNaNBits = 0x7fc00001u;  // slope (given normals: roughness) of a cell the fix-up pass must settle exactly
+inline float clip_band_slope(double crit) {
+  if (!(crit > 0.0)) return 0.0f;
+  double s = sin(crit);
+  s = s > 1e-3 ? s : 1e-3;
+  const double e = 3.0 * (4e-7 + 1.2e-7 / s) / crit;
+  return (float)(e < 2e-6 ? 2e-6 : (e > 1e-2 ? 1e-2 : e));
+}
+inline float clip_band_rough(double crit) { return crit > 0.0 ? 2e-6f : 0.0f; }
 
 constexpr unsigned kDeferCombine = 0x8000u;  // internal launch_chain flag: the footprint mask kernel will write `traversability`
 
@@ -195,6 +215,44 @@ struct HostStager {
   hipError_t download(void* host, const void* dev, size_t bytes, hipStream_t compute);
 };
 
+// The marching kernels of te_march5.h read kSlabGuardRows rows above and below the layers they are given (unconditional
+// raw buffer loads, no bounds check: DESIGN.md).  Layers of a context's slab have that slack by construction; any other
+// pointer -- a caller's own allocation handed in through a future entry point -- is checked here against the allocation
+// that holds it, and the launchers fall back to the bounds-checked generic kernels when the slack is not there.
+// (One driver query per distinct (pointer, shape); the verdicts are dropped whenever a context frees its layers.)
+inline std::atomic<unsigned>& guard_cache_generation() {
+  static std::atomic<unsigned> g{0};
+  return g;
+}
+inline bool layer_has_guard_rows(const void* p, const Geo& g, size_t elem_bytes) {
+  struct Entry {
+    const void* p;
+    int rows, cols, batch;
+    unsigned gen;
+    bool ok;
+  };
+  static thread_local Entry cache[8] = {};
+  static thread_local int next = 0;
+  const unsigned gen = guard_cache_generation().load(std::memory_order_acquire);
+  for (const Entry& e : cache)
+    if (e.p == p && e.rows == g.rows && e.cols == g.cols && e.batch == g.batch && e.gen == gen && p) return e.ok;
+  bool ok = false;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (p && hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess) {
+    const size_t guard = (size_t)kSlabGuardRows * (size_t)g.rows * elem_bytes;
+    const size_t layer = (size_t)g.rows * (size_t)g.cols * (size_t)(g.batch > 0 ? g.batch : 1) * elem_bytes;
+    const char* lo = (const char*)base;
+    const char* hi = lo + size;
+    ok = (size_t)((const char*)p - lo) >= guard && (const char*)p + layer <= hi && (size_t)(hi - ((const char*)p + layer)) >= guard;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[next] = Entry{p, g.rows, g.cols, g.batch, gen, ok};
+  next = (next + 1) & 7;
+  return ok;
+}
+
 // Compute units of the CURRENT device (hipGetDevice), cached per device; the launchers size their grids from it.
 // (A function-local static of the first device's count would be a data race with one context per thread and the
 // wrong capacity on a node with different devices.)
@@ -275,6 +333,7 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
 // footprint_blocked4 for the listed cells (after every launch of the pass)
 bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, const int* clip_table, double tcap, hipStream_t s,
                       const Region* region, bool* needs_blocked);
+bool footprint_slide5_replaces_mask();  // false in every shipped build (te_footprint5.hip, TE_F5_WHATIF_FUSED: a timing experiment)
 constexpr int kClipInts = 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1);  // one clip table of the normals disc; for a tie radius the
                                                                                       // table of the disc with its circle follows, then the packed offsets
 constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint disc (reach <= 20); a second one follows it for a tie

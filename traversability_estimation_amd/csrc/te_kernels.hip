@@ -218,6 +218,7 @@ struct NormalsArgs {
   float w_scale, w_slope, w_step, w_rough;
   int combine;  // also write the traversability layer (reads the step layer)
   int given_normals;  // RoughnessFilter alone: surface_normal_{x,y,z} are INPUT layers (RoughnessFilter.cpp:108-110)
+  float band_slope, band_rough;  // k_normals_fixup: a fast-tail score within this of its clip takes the generic arithmetic (te_internal.h)
 };
 
 // One cell from the LDS tile: normals -> slope -> roughness (-> combine), all outputs written.
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
     for (int c = 0; c < CPT; ++c) {
       const int lj = threadIdx.y + c * BY;
       const int i = i0 + threadIdx.x, j = j0 + lj;
-      bool need = false;
+      bool need = false, exact = false;
       if (i < rg.i1 && j < jb1) {
         const float z0 = tile[(lj + K) * tw + (threadIdx.x + K)];
         const size_t oc = mo + (size_t)j * g.rows + i;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
         const bool have = a.given_normals ? __builtin_isfinite(onx[oc]) : (z0 == z0);
         const bool in_frame = fg.frame > 0 && (i < fg.frame || j < fg.frame || i >= g.rows - fg.frame || j >= g.cols - fg.frame);
         need = have && (!(s == s) || in_frame);
+        exact = __builtin_bit_cast(unsigned, s) == kExactNaNBits;  // a fast tail's score sat at its clip: the generic arithmetic decides
         if (!a.given_normals && in_frame && !(z0 == z0)) {  // nobody else writes the frame: an invalid centre has no normal, slope or roughness
           const size_t o = mo + (size_t)j * g.rows + i;
           const float qn = __builtin_nanf("");
@@ -395,12 +397,13 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       int base = 0;
       if (threadIdx.x == 0 && mask) base = atomicAdd(&ntodo, __popcll(mask));
       base = __shfl(base, 0);
-      if (need) todo[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)(lj * TX + threadIdx.x);
+      if (need) todo[base + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (unsigned short)((exact ? 0x8000 : 0) | (lj * TX + threadIdx.x));
     }
     __syncthreads();
     const int n = ntodo;
     for (int k = tid; k < n; k += TX * BY) {
-      const int c = todo[k];
+      const int c = todo[k] & 0x7fff;
+      const bool exact = (todo[k] & 0x8000) != 0;
       const int lj = c / TX, li = c - lj * TX;
       const int i = i0 + li, j = j0 + lj;
       const float* ctr = tile + (lj + K) * tw + (li + K);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
       // (moments -> one Jacobi rotation + secular equation), the cyclic Jacobi of normals_cell only for the
       // configurations it does not resolve
       bool fast_done = false;
-      if (a.same_disc && a.axis == 2 && !a.given_normals) {
+      if (a.same_disc && a.axis == 2 && !a.given_normals && !exact) {
         Mom m;
         mom_zero(m);
         accumulate_disc(m, g, a.dn, ctr, tw, i, j, (double)*ctr);
@@ -418,21 +421,27 @@ __global__ __launch_bounds__(TX* BY) void k_normals_fixup(Geo g, NormalsArgs a, 
         fast_done = fast::border_tail(g.res, m.n, m.si, m.sj, m.sii, m.sij, m.sjj, m.sz, m.siz, m.sjz, m.szz, nx, ny, nz, q);
         if (fast_done) {
           const double sl = fast::acos_poly((double)nz);
-          const float o_slope = sl < a.slope_crit ? (float)(1.0 - sl / a.slope_crit) : 0.0f;
+          const float rs = (float)(1.0 - sl / a.slope_crit);
+          const float o_slope = sl < a.slope_crit ? rs : 0.0f;
           const double rgh = m.n > 1 ? fast::sqrt_nr(q * ((double)m.n / (double)(m.n - 1))) : 1e300;
-          const float o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh / a.rough_crit) : 0.0f;
-          slope[o] = o_slope;
-          rough[o] = o_rough;
-          if (a.combine) {
-            const float ta = a.w_slope * o_slope, tb = a.w_step * step[o], tc = a.w_rough * o_rough;
-            const float tab = ta + tb;
-            const float tabc = tab + tc;
-            trav[o] = a.w_scale * tabc;
-          }
-          if (onx) {
-            onx[o] = nx;
-            ony[o] = ny;
-            onz[o] = nz;
+          const float rr = (float)(1.0 - rgh / a.rough_crit);
+          const float o_rough = rgh < a.rough_crit ? rr : 0.0f;
+          // this tail's normal can differ from the generic one by a float32 ulp: a score at its clip goes the generic way too
+          fast_done = !(fast::near_clip(rs, a.band_slope) || (m.n > 1 && fast::near_clip(rr, a.band_rough)));
+          if (fast_done) {
+            slope[o] = o_slope;
+            rough[o] = o_rough;
+            if (a.combine) {
+              const float ta = a.w_slope * o_slope, tb = a.w_step * step[o], tc = a.w_rough * o_rough;
+              const float tab = ta + tb;
+              const float tabc = tab + tc;
+              trav[o] = a.w_scale * tabc;
+            }
+            if (onx) {
+              onx[o] = nx;
+              ony[o] = ny;
+              onz[o] = nz;
+            }
           }
         }
       }
@@ -527,6 +536,8 @@ hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, in
     na.w_scale = na.w_slope = na.w_step = na.w_rough = 0.0f;
     na.combine = 0;
     na.given_normals = 1;
+    na.band_slope = clip_band_slope(p.slope_crit);
+    na.band_rough = clip_band_rough(p.rough_crit);
     // tie-free discs: the sliding kernel with the layers' normals (interior, hole-free discs in closed form from the
     // moments), the fix-up pass for the frame and the holes; otherwise the generic kernel on every cell
     FastGrid fg;
@@ -599,6 +610,8 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   na.w_step = p.w_step;
   na.w_rough = p.w_rough;
   na.given_normals = 0;
+  na.band_slope = clip_band_slope(p.slope_crit);
+  na.band_rough = clip_band_rough(p.rough_crit);
   // the combine is fused into the normals kernel only when the step layer is complete before it starts;
   // region runs: the step reach may exceed the normals reach, combine separately
   na.combine = (whole && !overlap && !normals_only && !(flags & kDeferCombine)) ? 1 : 0;

@@ -152,6 +152,9 @@ template <int Q, class K>
 __device__ __forceinline__ void march5(K& k, const int js, const int jend) {
   using S = Shape<Q>;
   constexpr int R = S::R, P = S::P, C = K::C;
+  // rows the unconditional loads reach beyond a layer: R above its first row, R + the prefetch distance (2C rows, two per
+  // pass) + the pass's second row below its last -- the slack every layer a policy loads from must have (layer_has_guard_rows)
+  static_assert(R + 2 * C + 2 <= kSlabGuardRows, "the march's loads must stay inside the guard rows around a layer");
   typename K::Acc acc[P];
   static_for<P>([&](auto c) __attribute__((always_inline)) { k.reset(acc[decltype(c)::value]); });
   int r = js - R;               // map row of the current pass's first row

@@ -92,6 +92,7 @@ struct N3Args {
   int skip_clean;             // sparse holes on nearly every strip: straight to the HOLES = 1 march (Layers::skip_clean)
   char* hole_queue;           // HOLES = 1: kHoleQueueBytes of global scratch per block (cells waiting for the general tail)
   float inv_slope_crit, inv_rough_crit;
+  float band_slope, band_rough;  // a raw score within this of the clip at 0 is left to the fix-up pass (kExactNaNBits, te_internal.h)
   float Krf;                  // N*res (normals only)
   int fi0, fj0, ntx, nty, fix_groups;  // fix-up flag grid (64x16 tiles from (fi0, fj0))
   // TIE RADII (radius a whole number R of cells): the cells exactly on the circle belong to a disc or not as
@@ -341,7 +342,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   float o_slope, o_rough, fx = 0.0f, fy = 0.0f, fz = 0.0f;
   bool deferred = false;  // HOLES = 1: this lane's cell of the current row waits in the queue (its closed form is meaningless)
   auto tail = [&](int j) __attribute__((always_inline)) {
-    bool bad;
+    bool bad, near;
     {
       const double D = fma(a.Nd, Szz, -(Sz * Sz));        // N^2 var(z)
       const double dl = fma(-0.5, D, a.K1h);              // delta = (N^2 cxx - D) / 2
@@ -377,7 +378,9 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       float rq = (float)(lam * a.kinv);
       rq = rq > 0.0f ? rq : 0.0f;
       const float rgh = __builtin_amdgcn_sqrtf(rq);
-      o_rough = fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f);
+      const float rr = fmaf(-rgh, a.inv_rough_crit, 1.0f);
+      o_rough = fmaxf(rr, 0.0f);
+      near = near_clip(rr, a.band_rough);
       if (KEEP) {
         // normal ~ (N res Siz, N res Sjz, t) / sqrt(2 s t)
         const float inv = __builtin_amdgcn_rsqf((float)(2.0 * X));
@@ -387,9 +390,12 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     }
     // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
     const float sl = acosf_poly01(fz);
-    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    const float rs = fmaf(-sl, a.inv_slope_crit, 1.0f);
+    o_slope = fmaxf(rs, 0.0f);
+    near = near || near_clip(rs, a.band_slope);
+    bad = bad || near;  // (a score at its clip: the fix-up pass decides zero / not zero, TraversabilityMap.cpp:869, :897)
     if (__builtin_expect(__any(bad && own && !deferred), 0)) {
-      const float qn = __builtin_nanf("");
+      const float qn = near ? exact_nanf() : __builtin_nanf("");
       o_slope = bad ? qn : o_slope;
       o_rough = bad ? qn : o_rough;
       fx = bad ? qn : fx;
@@ -398,6 +404,18 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       flag_tiles(j);
     }
   };
+  // slope and roughness scores behind a general tail (normal fz, q = n^2 n^T C n, n cells); true: a score at its clip
+  auto scores_general = [&](float nzf, double qs, int n, bool poly01) __attribute__((always_inline)) {
+    const float sl = poly01 ? acosf_poly01(nzf) : acosf_poly(nzf);
+    const float rs = fmaf(-sl, a.inv_slope_crit, 1.0f);
+    o_slope = fmaxf(rs, 0.0f);
+    float rq = (float)(qs * rcp_fast((double)n * (double)(n - 1)));
+    rq = rq > 0.0f ? rq : 0.0f;
+    const float rgh = __builtin_amdgcn_sqrtf(rq);
+    const float rr = fmaf(-rgh, a.inv_rough_crit, 1.0f);
+    o_rough = n > 1 ? fmaxf(rr, 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+    return near_clip(rs, a.band_slope) || (n > 1 && near_clip(rr, a.band_rough));
+  };
   // rows of the top / bottom frame and block columns with lanes in the left / right frame: x/y moments of the clipped
   // disc from the host-built table, general tail (te_eig3.h); the z-moments are already right (cells outside count 0)
   auto tail_clipped = [&](int j, int ky) __attribute__((always_inline)) {
@@ -405,15 +423,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     const int n = gt[0];
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, n, gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
-    const float sl = acosf_poly(fz);
-    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    float rq = (float)(qs * rcp_fast((double)n * (double)(n - 1)));
-    rq = rq > 0.0f ? rq : 0.0f;
-    const float rgh = __builtin_amdgcn_sqrtf(rq);
-    o_rough = n > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
-    if (__builtin_expect(__any(unresolved != 0 && own), 0)) {
-      const float qn = __builtin_nanf("");
-      const bool bad = unresolved != 0;
+    const bool near = scores_general(fz, qs, n, false);
+    if (__builtin_expect(__any((unresolved != 0 || near) && own), 0)) {
+      const float qn = near ? exact_nanf() : __builtin_nanf("");
+      const bool bad = unresolved != 0 || near;
       o_slope = bad ? qn : o_slope;
       o_rough = bad ? qn : o_rough;
       fx = bad ? qn : fx;
@@ -480,15 +493,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     }
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, n, si, sj, sii, sij, sjj, lSz, lSiz, lSjz, lSzz, fx, fy, fz, qs);
-    const float sl = acosf_poly(fz);
-    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    float rq = (float)(qs * rcp_fast((double)n * (double)(n - 1)));
-    rq = rq > 0.0f ? rq : 0.0f;
-    const float rgh = __builtin_amdgcn_sqrtf(rq);
-    o_rough = n > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;
-    if (__builtin_expect(__any(unresolved != 0 && own), 0)) {
-      const float qn = __builtin_nanf("");
-      const bool bad = unresolved != 0;
+    const bool near = scores_general(fz, qs, n, false);
+    if (__builtin_expect(__any((unresolved != 0 || near) && own), 0)) {
+      const float qn = near ? exact_nanf() : __builtin_nanf("");
+      const bool bad = unresolved != 0 || near;
       o_slope = bad ? qn : o_slope;
       o_rough = bad ? qn : o_rough;
       fx = bad ? qn : fx;
@@ -550,13 +558,16 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, qn_, qsi, qsj, qsii, qsij, qsjj, m0.x, m0.y, m1.x, m1.y, gx, gy, gz, qs);
     const float sl = acosf_poly01(gz);
-    float s_out = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
+    const float rs_ = fmaf(-sl, a.inv_slope_crit, 1.0f);
+    float s_out = fmaxf(rs_, 0.0f);
     float rq = (float)(qs * rcp_fast((double)qn_ * (double)(qn_ - 1)));
     rq = rq > 0.0f ? rq : 0.0f;
     const float rgh = __builtin_amdgcn_sqrtf(rq);
-    float r_out = qn_ > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
-    const bool bad = act && unresolved != 0;
-    if (bad) s_out = r_out = __builtin_nanf("");
+    const float rr_ = fmaf(-rgh, a.inv_rough_crit, 1.0f);
+    float r_out = qn_ > 1 ? fmaxf(rr_, 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+    const bool near = near_clip(rs_, a.band_slope) || (qn_ > 1 && near_clip(rr_, a.band_rough));  // a score at its clip: the fix-up pass decides
+    const bool bad = act && (unresolved != 0 || near);
+    if (bad) s_out = r_out = near ? exact_nanf() : __builtin_nanf("");
     unsigned long long bm = __ballot(bad);
     while (__builtin_expect(bm != 0ull, 0)) {  // unresolved cells go to the fix-up pass (rare)
       const int l = __builtin_ctzll(bm);
@@ -635,14 +646,9 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     const int Mn = n0 - hn;
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, Mn, si0 - hi_, sj0 - hj, sii0 - hii, sij0 - hij, sjj0 - hjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
-    const float sl = acosf_poly01(fz);
-    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    float rq = (float)(qs * rcp_fast((double)Mn * (double)(Mn - 1)));
-    rq = rq > 0.0f ? rq : 0.0f;
-    const float rgh = __builtin_amdgcn_sqrtf(rq);
-    o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
-    const float qn = __builtin_nanf("");
-    const bool bad = unresolved != 0 && !nocentre;  // (no normal, slope or roughness where the input layer is invalid)
+    const bool near = scores_general(fz, qs, Mn, true);
+    const bool bad = (unresolved != 0 || near) && !nocentre;  // (no normal, slope or roughness where the input layer is invalid)
+    const float qn = (near && !nocentre) ? exact_nanf() : __builtin_nanf("");
     if (nocentre || bad) {
       o_slope = qn;
       o_rough = qn;
@@ -689,15 +695,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     const double ctr = *reinterpret_cast<const double*>(ringb + vb[(pc / C) % NC] + ((pc % C) * RB + R * 8));
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, Mn, Mi, Mj, Mii, Mij, Mjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
-    const float sl = acosf_poly01(fz);
-    o_slope = fmaxf(fmaf(-sl, a.inv_slope_crit, 1.0f), 0.0f);
-    float rq = (float)(qs * rcp_fast((double)Mn * (double)(Mn - 1)));
-    rq = rq > 0.0f ? rq : 0.0f;
-    const float rgh = __builtin_amdgcn_sqrtf(rq);
-    o_rough = Mn > 1 ? fmaxf(fmaf(-rgh, a.inv_rough_crit, 1.0f), 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
-    const float qn = __builtin_nanf("");
+    const bool near = scores_general(fz, qs, Mn, true);
     const bool nocentre = absent(ctr);  // no normal, slope or roughness where the input layer is invalid
-    const bool bad = unresolved != 0 && !nocentre;
+    const bool bad = (unresolved != 0 || near) && !nocentre;
+    const float qn = (near && !nocentre) ? exact_nanf() : __builtin_nanf("");
     if (nocentre || bad) {
       o_slope = qn;
       o_rough = qn;
@@ -1366,6 +1367,8 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.kinv = 1.0 / (N * (N - 1.0));
   a.inv_slope_crit = (float)(1.0 / p.slope_crit);
   a.inv_rough_crit = (float)(1.0 / p.rough_crit);
+  a.band_slope = clip_band_slope(p.slope_crit);
+  a.band_rough = clip_band_rough(p.rough_crit);
   a.Krf = (float)(N * g.res);
   a.fi0 = r.i0;
   a.fj0 = r.j0;

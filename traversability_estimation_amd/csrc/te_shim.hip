@@ -454,6 +454,7 @@ void free_layers(te_ctx* c) {
   drop_graph(c);
   if (c->slab) (void)hipFree(c->slab);
   c->slab = nullptr;
+  guard_cache_generation().fetch_add(1, std::memory_order_acq_rel);  // (layer_has_guard_rows: verdicts about freed memory)
   if (c->poly_x) (void)hipFree(c->poly_x);
   c->poly_x = c->poly_rot = nullptr;
   if (c->poly_stream) (void)hipFree(c->poly_stream);
@@ -572,6 +573,8 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   static const bool no_graph = lab_flag("TE_NO_GRAPH");
   const bool large = (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23);
+  // (only the defined TE_RUN_* bits: the graph key below puts its own hints into the upper bits of the same word)
+  flags &= TE_RUN_KEEP_NORMALS | TE_RUN_FOOTPRINT | TE_RUN_GENERIC_KERNELS | TE_RUN_FOOTPRINT_MEMO | TE_RUN_SEQUENTIAL | TE_RUN_NORMALS_ONLY;
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
   if (!no_graph && large && !(flags & TE_RUN_NORMALS_ONLY) && c->graph_ok && c->have_params && c->have_geo && c->have_elev) {
     if (!c->tables_ready) {
@@ -872,6 +875,9 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     HIP_TRY(hipMemsetAsync(slab, 0xFF, guard + 13 * lb + ub + fb, c->stream));
     HIP_TRY(hipMemsetAsync(b + 13 * lb + ub + fb + qb + 256 + ufb, 0xFF, guard, c->stream));
     HIP_TRY(hipMemsetAsync(c->L.untrav_flags, 0x01, ufb, c->stream));
+    // the mask layer holds 0 / 1 only (k_fp_slide5 packs the byte as it is): "untraversable" until the mask kernel has
+    // looked at the cell, as a byte of 0xFF would also say -- but 1 stays inside the packed word's flag bit
+    HIP_TRY(hipMemsetAsync(c->L.untrav, 0x01, ub, c->stream));
     HIP_TRY(hipMemsetAsync(c->L.fp_blocked_count, 0, 256, c->stream));
     // the fix-up flags are zero between launches: k_normals_fixup clears every flag it consumes
     HIP_TRY(hipMemsetAsync(c->L.block_flags, 0, fb, c->stream));

@@ -46,6 +46,7 @@ struct SlideArgs {
   int np;                      // cells in the disc
   int sii;                     // sum of di^2 over the disc
   double slope_crit, inv_slope_crit, rough_crit, inv_rough_crit;
+  float band_slope, band_rough;  // a raw score within this of the clip at 0 is left to the fix-up pass (kExactNaNBits, te_internal.h)
   float w_scale, w_slope, w_step, w_rough;
   int combine;
   // RoughnessFilter as a stand-alone plugin (RoughnessFilter.cpp:84-119): surface_normal_{x,y,z} are INPUT layers and the
@@ -352,11 +353,13 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
       double q = fma(cxx, fma(gx, gx, gy * gy), fma(2.0 * gz, fma(gx, ca, gy * cb), gz * gz * cd));
       q = q > 0.0 ? q : 0.0;
       const float rgh = __builtin_amdgcn_sqrtf((float)(q * nm1));
-      const float rs = rgh < rough_critf ? 1.0f - rgh * inv_rough_critf : 0.0f;
+      const float rr = 1.0f - rgh * inv_rough_critf;
+      const float rs = rgh < rough_critf ? rr : 0.0f;
       const bool have = __builtin_isfinite(gxf);  // :84 (the reference tests surface_normal_x only)
-      const bool clean = (j > dirty_until) && (kx == 0) && (ky == 0);
+      const bool near = near_clip(rr, a.band_rough);  // a score at its clip: the fix-up pass decides zero / not zero
+      const bool clean = (j > dirty_until) && (kx == 0) && (ky == 0) && !near;
       done = clean || !have;  // no normal: the layer stays NaN, nothing to recompute
-      o_rough = (clean && have) ? rs : qnanf();
+      o_rough = (clean && have) ? rs : (near ? exact_nanf() : qnanf());
     } else if (BORDER && j > dirty_until && (kx != 0 || ky != 0)) {
       // disc clipped by the map border: the z-sums are already right (cells outside contribute 0),
       // the x/y moments of the clipped disc come from the host-built table
@@ -365,10 +368,17 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
       done = border_tail(g.res, gt[0], gt[1], gt[2], gt[3], gt[4], gt[5], Sz, Siz, Sjz, Szz, nx, ny, nz, qrough);
       if (done) {
         const double sl = acos_poly((double)nz);
-        o_slope = sl < a.slope_crit ? (float)(1.0 - sl * a.inv_slope_crit) : 0.0f;
+        const float rs = (float)(1.0 - sl * a.inv_slope_crit);
+        o_slope = sl < a.slope_crit ? rs : 0.0f;
         const int n = gt[0];
         const double rgh = n > 1 ? sqrt_nr(qrough * ((double)n / (double)(n - 1))) : 1e300;
-        o_rough = rgh < a.rough_crit ? (float)(1.0 - rgh * a.inv_rough_crit) : 0.0f;
+        const float rr = (float)(1.0 - rgh * a.inv_rough_crit);
+        o_rough = rgh < a.rough_crit ? rr : 0.0f;
+        if (near_clip(rs, a.band_slope) || (n > 1 && near_clip(rr, a.band_rough))) {  // a score at its clip: the fix-up pass decides
+          done = false;
+          nx = ny = nz = o_rough = qnanf();
+          o_slope = exact_nanf();
+        }
       }
     } else {
       // straight-line closed-form tail; cells it cannot finish (dirty rows, degenerate t) are masked to NaN
@@ -391,17 +401,21 @@ __device__ __forceinline__ void march(double* __restrict__ ring, const Geo& g, c
       const float fy = eig_ok ? (float)(-cb * inv) : 0.0f;
       // slope = acos(float32 nz) (SlopeFilter.cpp:74); float32 evaluation, |error| < 3e-7 rad
       const float sl = acosf_poly(fz);
-      const float ss = sl < slope_critf ? 1.0f - sl * inv_slope_critf : 0.0f;
+      const float rsl = 1.0f - sl * inv_slope_critf;
+      const float ss = sl < slope_critf ? rsl : 0.0f;
       // roughness^2 * (N-1)/N = n^T C n = smallest eigenvalue (RoughnessFilter.cpp:105-117); with the
       // float32-rounded normal the quadratic form differs from lambda0 by O(c * 1e-15)
       double q = eig_ok ? 0.5 * (cxx + cd) - s : cd;
       q = q > 0.0 ? q : 0.0;
       const float rgh = __builtin_amdgcn_sqrtf((float)(q * nm1));
-      const float rs = rgh < rough_critf ? 1.0f - rgh * inv_rough_critf : 0.0f;
+      const float rrg = 1.0f - rgh * inv_rough_critf;
+      const float rs = rgh < rough_critf ? rrg : 0.0f;
+      const bool near = near_clip(rsl, a.band_slope) || near_clip(rrg, a.band_rough);  // a score at its clip: the fix-up pass decides
+      done = done && !near;
       nx = done ? fx : qnanf();
       ny = done ? fy : qnanf();
       nz = done ? fz : qnanf();
-      o_slope = done ? ss : qnanf();
+      o_slope = done ? ss : (near ? exact_nanf() : qnanf());
       o_rough = done ? rs : qnanf();
     }
     const float ta = a.w_slope * o_slope, tc = a.w_rough * o_rough;
@@ -551,6 +565,8 @@ bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep
   a.inv_slope_crit = 1.0 / p.slope_crit;
   a.rough_crit = p.rough_crit;
   a.inv_rough_crit = 1.0 / p.rough_crit;
+  a.band_slope = clip_band_slope(p.slope_crit);
+  a.band_rough = clip_band_rough(p.rough_crit);
   a.w_scale = p.w_scale;
   a.w_slope = p.w_slope;
   a.w_step = p.w_step;
@@ -624,6 +640,8 @@ bool roughness_given_fast(const Geo& g, const ChainParams& p, const Layers& L, c
   a.inv_slope_crit = 1.0 / p.slope_crit;
   a.rough_crit = p.rough_crit;
   a.inv_rough_crit = 1.0 / p.rough_crit;
+  a.band_slope = clip_band_slope(p.slope_crit);
+  a.band_rough = clip_band_rough(p.rough_crit);
   a.w_scale = a.w_slope = a.w_step = a.w_rough = 0.0f;
   a.combine = 0;
   a.given = 1;

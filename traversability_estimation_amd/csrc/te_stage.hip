@@ -8,6 +8,8 @@
 // of page-locked slots per context and a small pool of copy threads per process: chunk k is copied host -> slot by the
 // pool while chunk k - 1 crosses PCIe from its slot (uploads), or the DMA of chunk k + kSlots - 1 runs while the pool
 // copies chunk k slot -> host (downloads).  Buffers the caller has page-locked (te_pin_host) skip all of this.
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 
 #include <atomic>
@@ -34,19 +36,22 @@ class CopyPool {
     static CopyPool* p = new CopyPool;  // (never destroyed: its threads sleep on its condition variable until the process ends)
     return *p;
   }
+  // fork(): the child has the pool's state but none of its threads -- it copies on the calling thread from then on
+  // (registered once, by the constructor; the locks are not taken around the fork: a child only ever reads `forked_`)
+  static void after_fork_in_child() { forked_.store(true, std::memory_order_relaxed); }
   void copy(void* dst, const void* src, size_t bytes) {
-    if (bytes < (1u << 20) || workers_.empty()) {
+    if (bytes < (1u << 20) || n_workers_ == 0 || forked_.load(std::memory_order_relaxed)) {
       memcpy(dst, src, bytes);
       return;
     }
     std::lock_guard<std::mutex> job(job_mu_);
-    const size_t parts = workers_.size() + 1;
+    const size_t parts = (size_t)n_workers_ + 1;
     const size_t piece = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
     dst_ = (char*)dst;
     src_ = (const char*)src;
     bytes_ = bytes;
     piece_ = piece;
-    pending_.store((int)workers_.size());
+    pending_.store(n_workers_);
     generation_.fetch_add(1);  // (sequentially consistent, like the sleepers' counter: one side always sees the other)
     if (sleepers_.load() != 0) {
       std::lock_guard<std::mutex> lk(mu_);  // (a worker between its last look at the counter and its wait holds mu_)
@@ -58,13 +63,41 @@ class CopyPool {
 
  private:
   CopyPool() {
+    // the CPUs this process may run on (a cpuset / taskset narrower than the machine), not the machine's
     unsigned hw = std::thread::hardware_concurrency();
+    {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0 && (unsigned)c < hw) hw = (unsigned)c;
+      }
+    }
     // (a copy thread moves 20-25 GB/s from cache-cold memory on these hosts; PCIe takes 50: a few of them keep the DMA
     // engine fed.  More threads than the container may really use do harm -- the GPU boxes of this pool show 256 cores
     // and run OpenMP fastest on 32 -- hence the modest numbers)
-    int n = hw >= 32 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0));
-    for (int k = 0; k < n; ++k) workers_.emplace_back([this, k] { run(k); });
-    for (auto& t : workers_) t.detach();  // (process-lifetime pool: the library may be unloaded at exit while they sleep)
+    const int n = hw >= 32 ? 7 : (hw >= 8 ? 3 : (hw >= 4 ? 1 : 0));
+    // A thread that cannot be created (EAGAIN: the process' thread limit) must not take the process down through the
+    // extern "C" boundary: the pool keeps the workers it got -- none at all means a plain memcpy on the caller's thread.
+    for (int k = 0; k < n; ++k) {
+      try {
+        std::thread t([this, k] { run(k); });
+        t.detach();  // (process-lifetime pool: the library may be unloaded at exit while they sleep)
+        ++n_workers_;
+      } catch (...) {
+        break;
+      }
+    }
+    (void)pthread_atfork(nullptr, nullptr, &CopyPool::after_fork_in_child);
+  }
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#else
+    std::this_thread::yield();
+#endif
   }
   void part(size_t k) {
     const size_t off = k * piece_;
@@ -82,7 +115,7 @@ class CopyPool {
           break;
         }
         if (spin < 4096)
-          __builtin_ia32_pause();
+          cpu_relax();
         else
           std::this_thread::yield();  // (a host with fewer free cores than workers: let the copying threads run)
         if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) break;
@@ -98,7 +131,8 @@ class CopyPool {
       pending_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
-  std::vector<std::thread> workers_;
+  int n_workers_ = 0;  // workers k = 0 .. n_workers_ - 1 were created (in order: a failed creation ends the loop)
+  static std::atomic<bool> forked_;
   std::mutex job_mu_, mu_;
   std::condition_variable cv_;
   char* dst_ = nullptr;
@@ -108,7 +142,9 @@ class CopyPool {
   std::atomic<unsigned long long> generation_{0};
 };
 
-bool host_is_pinned(const void* p) {
+std::atomic<bool> CopyPool::forked_{false};
+
+bool byte_is_pinned(const void* p) {
   hipPointerAttribute_t at;
   const hipError_t e = hipPointerGetAttributes(&at, p);
   if (e != hipSuccess) {
@@ -116,6 +152,11 @@ bool host_is_pinned(const void* p) {
     return false;
   }
   return at.type == hipMemoryTypeHost;
+}
+// the WHOLE buffer lies in page-locked memory (first and last byte: a buffer that only starts inside a registered range
+// takes the staged path)
+bool host_is_pinned(const void* p, size_t bytes) {
+  return byte_is_pinned(p) && (bytes == 0 || byte_is_pinned((const char*)p + bytes - 1));
 }
 
 }  // namespace
@@ -152,7 +193,7 @@ hipError_t HostStager::ensure() {
 
 // host -> device, ordered after everything queued on `compute` so far; `compute` waits for the last chunk
 hipError_t HostStager::upload(void* dev, const void* host, size_t bytes, hipStream_t compute) {
-  if (bytes < kMinBytes || host_is_pinned(host) || ensure() != hipSuccess) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, compute);
+  if (bytes < kMinBytes || host_is_pinned(host, bytes) || ensure() != hipSuccess) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, compute);
   hipError_t e = hipEventRecord(ev_order, compute);  // (kernels queued earlier may still read the layer)
   if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_order, 0);
   const size_t nchunks = (bytes + kChunk - 1) / kChunk;
@@ -165,17 +206,26 @@ hipError_t HostStager::upload(void* dev, const void* host, size_t bytes, hipStre
     e = hipMemcpyAsync((char*)dev + off, slot[s], n, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipEventRecord(ev[s], stream);
   }
-  if (e == hipSuccess) e = hipEventRecord(ev_order, stream);
-  if (e == hipSuccess) e = hipStreamWaitEvent(compute, ev_order, 0);
+  // `compute` waits for whatever has been queued on the copy stream -- also after an error: kernels queued later must not
+  // overtake chunks that are still in flight
+  {
+    hipError_t e2 = hipEventRecord(ev_order, stream);
+    if (e2 == hipSuccess) e2 = hipStreamWaitEvent(compute, ev_order, 0);
+    if (e == hipSuccess) e = e2;
+  }
   // the slots are reused by the next transfer, and the caller may reuse `host` as soon as we return: both are safe --
-  // every chunk has been copied out of `host`, and a slot is only rewritten after its event
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  // every chunk has been copied out of `host`, and a slot is only rewritten after its event.  (On an error the drain
+  // matters even more: the next transfer starts from idle slots and events.)
+  {
+    const hipError_t e2 = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = e2;
+  }
   return e;
 }
 
 // device -> host, ordered after everything queued on `compute` so far; returns when `host` holds the data
 hipError_t HostStager::download(void* host, const void* dev, size_t bytes, hipStream_t compute) {
-  if (bytes < kMinBytes || host_is_pinned(host) || ensure() != hipSuccess) {
+  if (bytes < kMinBytes || host_is_pinned(host, bytes) || ensure() != hipSuccess) {
     hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, compute);
     return e == hipSuccess ? hipStreamSynchronize(compute) : e;
   }
@@ -197,6 +247,7 @@ hipError_t HostStager::download(void* host, const void* dev, size_t bytes, hipSt
     CopyPool::get().copy((char*)host + off, slot[s], n);
     if (k + kSlots < nchunks) e = issue(k + kSlots);
   }
+  if (e != hipSuccess) (void)hipStreamSynchronize(stream);  // chunks still in flight into the slots: drain before the next transfer reuses them
   return e;
 }
 

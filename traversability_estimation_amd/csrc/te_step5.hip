@@ -378,6 +378,7 @@ bool dispatch_step5(int Q, bool score, const Geo& g, const Step5Args& a, const R
 
 // sh_min != nullptr: RAW (the running maximum goes to sh, the minimum to sh_min); false: shape / region not taken
 bool step_height5(int Q, const Geo& g, const float* elev, float* sh, float* sh_min, const Region& r, hipStream_t s) {
+  if (!layer_has_guard_rows(elev, g, sizeof(float))) return false;  // (the march loads rows beyond the layer: te_internal.h)
   Step5Args a = {};
   a.in = elev;
   a.out = sh;
@@ -388,6 +389,7 @@ bool step_height5(int Q, const Geo& g, const float* elev, float* sh, float* sh_m
 // out_count != nullptr: RAW (maximum to out, count to out_count)
 bool step_score5(int Q, const Geo& g, double crit, int ncrit, const float* sh, float* out, float* out_count, const Region& r,
                  hipStream_t s) {
+  if (!layer_has_guard_rows(sh, g, sizeof(float))) return false;
   Step5Args a = {};
   a.in = sh;
   a.out = out;
