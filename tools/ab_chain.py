@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--exact-cells", action="store_true", help="footprint radius and offset exactly 6 and 3 cells (a tie radius: cells on the circle decided per centre)")
     ap.add_argument("--exact-chain", action="store_true", help="normals / roughness / step radii exactly --radius-cells cells (tie radii: the generic kernels)")
     ap.add_argument("--loops", type=str, default="", help="comma-separated K: host-timed loops of K launches + sync")
+    ap.add_argument("--fb-walk", type=int, default=0, help="te_set_option(TE_OPT_FP_BLOCKED_WALK): 1 one disc per wavefront, 2 one disc per lane (0: by the length of the list)")
     ap.add_argument("--tag", type=str, default="")
     ap.add_argument("--check", action="store_true", help="after the timing, compare what the launches left on the device with the "
                     "oracle (bench.py's parity_check: a corner crop and a full-width band; exit code 1 on a mismatch) -- no number "
@@ -81,6 +82,8 @@ def main():
            "env": {k: v for k, v in os.environ.items() if k.startswith("TE_")}}
     with capi.Context(0) as ctx:
         ctx.set_params(p)
+        if a.fb_walk:
+            ctx.set_option(capi.OPT_FP_BLOCKED_WALK, a.fb_walk)
         ctx.set_geometry(n, n, B, a.res)
         ctx.upload_elevation(np.stack(elevs))
         if a.footprint_only:

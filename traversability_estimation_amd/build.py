@@ -2,7 +2,8 @@
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels with
 the gpurun snapshot, so the GPU box uses the prebuilt file.  Every source is compiled to its own object
-(in parallel, cached under _build/ by modification time) and the objects are linked into the library.
+(in parallel, cached under _build/ by modification time; build_lib(force=True) compiles every object again) and the
+objects are linked into the library.
 
 `python -m traversability_estimation_amd.build --lab` builds libtravgpu_lab.so (-DTE_LAB, objects under _build_lab/): the
 same sources with their measurement switches (environment variables such as TE_NO_F4, TE_N3_BLOCKS_PER_CU) compiled in.
@@ -29,7 +30,7 @@ _SINGLE_DS_READS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", 
 EXTRA_CFLAGS = {"csrc/te_normals3.hip": _SINGLE_DS_READS, "csrc/te_footprint3.hip": _SINGLE_DS_READS}
 # sources compiled in several parts (-DTE_PARTS=n -DTE_PART=k, one object each): their shape-specialised kernels take
 # minutes in one translation unit, and the parts compile side by side
-PARTS = {"csrc/te_normals3.hip": 6, "csrc/te_footprint3.hip": 5, "csrc/te_footprint4.hip": 5, "csrc/te_footprint5.hip": 5}
+PARTS = {"csrc/te_normals3.hip": 6, "csrc/te_footprint3.hip": 5, "csrc/te_footprint5.hip": 5}
 
 
 def hipcc():
@@ -83,8 +84,10 @@ def build_lib(force=False, verbose=False, lab=False):
         return lib
     os.makedirs(LAB_OBJDIR if lab else OBJDIR, exist_ok=True)
     newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
+    # force: every object is compiled again (the driver's "does it build" check must not be answered from a cache);
+    # otherwise only what is older than its source or than any header
     todo = [u for u in _units()
-            if not os.path.exists(_obj(*u, lab=lab)) or os.path.getmtime(_obj(*u, lab=lab)) < max(_mtime(u[0]), newest_header)]
+            if force or not os.path.exists(_obj(*u, lab=lab)) or os.path.getmtime(_obj(*u, lab=lab)) < max(_mtime(u[0]), newest_header)]
     todo.sort(key=lambda u: u[0] not in PARTS)  # the long ones first
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
         list(pool.map(lambda u: _compile(u, verbose, lab), todo))

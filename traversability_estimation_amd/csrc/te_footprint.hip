@@ -643,6 +643,9 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       }
     }
     __syncthreads();
+    // (Staging the zero-score flags of the slope / roughness layers here as well, so that checkForSlope's window count reads
+    // LDS instead of 29 + 4 cells from L2 per slow cell, was built and measured in round 5 like in round 3: no gain --
+    // 3 boxes 106 -> 112 us, 300 boxes 142 -> 150 us for this kernel, profiles/r05_experiments.json.)
     for (int k = tid; k < NCELL / 2; k += MX * MBY) reinterpret_cast<unsigned*>(fmask)[k] = 0u;
     if (klbits != 0u) {
       int at = atomicAdd(&nkl, __popc(klbits));
@@ -1269,17 +1272,10 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // measured in round 3 with k_fp_slide4 (0.418 ms per launch against 0.385) and again in round 4 with k_fp_slide5 and
   // 2 / 3 / 4 / 6 bands on two streams (0.393 / 0.425 / 0.462 / 0.589 against 0.375, profiles/r04_experiments.json): the two
   // kernels slow each other down by more than they overlap, and every band pays the strips' 2R lead-in rows again.)
-  // What-if (lab library only, tools/lab/r05_exp1.sh; results wrong by construction): the sum kernel on the second stream
-  // BESIDE the mask kernel instead of behind it -- the two kernels' instruction streams sharing the machine, which is the
-  // most a fusion of the two could overlap.
-  static const bool whatif_concurrent = lab_flag("TE_FP_WHATIF_CONCURRENT");
-  hipStream_t sum_stream = stream;
-  if (whatif_concurrent && L.aux_stream && !region) {
-    (void)hipEventRecord(L.ev_fork, stream);
-    (void)hipStreamWaitEvent(L.aux_stream, L.ev_fork, 0);
-    sum_stream = L.aux_stream;
-  }
-  if (!fast::footprint_slide5_replaces_mask()) launch_mask(t_lo, t_hi, stream);
+  // (Round 5 what-ifs, recorded in profiles/r05_experiments.json and kept as tools/lab/attic/r05_whatif_footprint.patch:
+  // the sum kernel on the second stream BESIDE the mask kernel -- 2-3 % slower than behind it -- and ONE kernel that stages
+  // elevation and the three scores itself: 264 us alone against 67 + 51.)
+  launch_mask(t_lo, t_hi, stream);
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;
   const Disc& d = p.fp_disc;
@@ -1300,12 +1296,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // tie-free disc of an instantiated shape on a map at least one block wide: the scatter-form sum on fixed point, ...
   {
     bool needs_blocked = false;
-    if (fast::footprint_slide5(g, p, L, clip_table, trav_cap, sum_stream, rfp, &needs_blocked)) {
-      if (needs_blocked) fast::footprint_blocked4(g, p, L, spiral_table, sum_stream);
-      if (sum_stream != stream) {
-        (void)hipEventRecord(L.ev_join, sum_stream);
-        (void)hipStreamWaitEvent(stream, L.ev_join, 0);
-      }
+    if (fast::footprint_slide5(g, p, L, clip_table, trav_cap, stream, rfp, &needs_blocked)) {
+      if (needs_blocked) fast::footprint_blocked4(g, p, L, spiral_table, stream);
       return hipGetLastError();
     }
   }

@@ -1,4 +1,7 @@
-// te_footprint4.hip -- the sliding-sum kernel of the circular footprint pass on 32-bit fixed point.
+// te_footprint4.hip -- the sliding-sum kernel of the circular footprint pass on 32-bit fixed point FOR TIE RADII (radius a
+// whole number of cells: the reference's own 0.45 m at 0.03 m), and k_fp_blocked, the second half of every fixed-point pass.
+// (Tie-free radii take the scatter-form sum of te_footprint5.hip since round 4; this kernel's tie-free instantiations were
+// retired in round 5.)
 //
 //   TraversabilityMap::traversabilityFootprint(radius, offset)   traversability_estimation/src/TraversabilityMap.cpp:307-318
 //     -> isTraversable(center, radiusMax, traversability, radiusMin)              :654-746
@@ -62,7 +65,9 @@ struct F4Args {
   double r2, ax, ay, res;
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
   unsigned* blocked_count;  // ... [0] how many entries are reserved, [1] how many hold a cell (k_fp_mask resets both: it runs
-                            // before this kernel in every footprint pass)
+                            // before this kernel in every footprint pass), [2] the page size (= chunk) of this pass
+  unsigned* page_count;     // entries of page p that k_fp_blocked looks at (k_fp_slide5 fills pages partly; here every page counts
+                            // in full and unused entries hold kF4NoCell)
   int chunk;                // entries a block reserves at a time: kF4Chunk, less for strips shorter than four rows
   size_t list_cap;          // entries the list holds (host side: launch_f4 refuses a grid whose unfinished chunks might not fit)
 };
@@ -96,6 +101,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   if (js >= a.j_hi) return;
   const int jend = js + a.strip_rows < a.j_hi ? js + a.strip_rows : a.j_hi;
   const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
+  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
+    a.blocked_count[2] = (unsigned)a.chunk;  // the page size of this pass, for k_fp_blocked
+    a.blocked_count[3] = 0u;                 // ... and the first spiral entry that can be untraversable: any (k_fp_slide5: beyond its inner disc)
+  }
 
   unsigned vb[NC];
 #pragma unroll
@@ -274,7 +283,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
           if (n > chunk_left) {
             const int old_left = chunk_left;
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
+            if (lane == 0) {
+              base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
+              a.page_count[base / (unsigned)a.chunk] = (unsigned)a.chunk;
+            }
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (rank >= old_left) at = base + (unsigned)(rank - old_left);
             chunk_at = base - (unsigned)old_left;  // (+ n below: the entries of this row that went into the new chunk)
@@ -361,8 +373,8 @@ template <int Q>
 bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   F4Args a = a0;
   constexpr int R = Shape<Q>::R;
-  constexpr bool kWholeCell = R * R == Q;  // the shapes a tie radius can have (its circle passes through (R, 0))
-  if (a.n_ties != 0 && !kWholeCell) return false;
+  static_assert(R * R == Q, "instantiated for the shapes a tie radius can have: its circle passes through (R, 0)");
+  if (a.n_ties == 0) return false;  // (tie-free discs: k_fp_slide5, or the double kernel -- footprint_slide4 does not ask)
   constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 4;
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
   if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;
@@ -388,43 +400,23 @@ bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   // than one round of resident ones).  false: the double kernel serves.
   if ((double)a.nbx_l * (double)nstrips * (double)nz * (double)a.chunk + (double)a.map_cells * (double)nz > (double)a.list_cap) return false;
   const dim3 grid((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz);
-  if constexpr (kWholeCell) {
-    if (a.n_ties != 0) {
-      hipLaunchKernelGGL((k_fp_slide4<Q, true>), grid, dim3(kLanes), 0, s, a);
-      return true;
-    }
-  }
-  hipLaunchKernelGGL((k_fp_slide4<Q, false>), grid, dim3(kLanes), 0, s, a);
+  hipLaunchKernelGGL((k_fp_slide4<Q, true>), grid, dim3(kLanes), 0, s, a);
   return true;
 }
 
 }  // namespace
 
-// Shapes: every disc shape up to radius 10 (te_march.h) except the single cell, and for radii 11 .. 16 (the default
-// footprint, 0.45 m, is 15 cells at 0.03 m) every sum of two squares up to 256.  Compiled in TE_PARTS parts like
-// te_normals3.hip (build.py): part k instantiates its list and exports one launcher, part 0 also holds footprint_slide4.
-#define TE_F4_P0(X) X(4) X(16) X(26) X(37) X(50) X(65) X(73) X(85) X(100) X(121) X(136) X(148) X(162) X(178) X(193) X(202) X(212) X(229) X(256)
-#define TE_F4_P1(X) X(10) X(13) X(25) X(36) X(49) X(64) X(82) X(98) X(109) X(117) X(130) X(146) X(160) X(173) X(185) X(200) X(226) X(241) X(250)
-#define TE_F4_P2(X) X(9) X(20) X(34) X(45) X(58) X(61) X(81) X(97) X(106) X(116) X(128) X(145) X(157) X(170) X(181) X(197) X(225) X(234) X(245)
-#define TE_F4_P3(X) X(2) X(8) X(18) X(32) X(41) X(53) X(72) X(80) X(90) X(104) X(113) X(125) X(144) X(153) X(169) X(196) X(208) X(221) X(233) X(244)
-#define TE_F4_P4(X) X(1) X(5) X(17) X(29) X(40) X(52) X(68) X(74) X(89) X(101) X(122) X(137) X(149) X(164) X(180) X(194) X(205) X(218) X(232) X(242)
-#if !defined(TE_PARTS) || defined(TE_F4_SHAPES)
+// Shapes: the whole-cell radii 1 .. 16 (Q = R^2), TIES march only.  Until round 5 the kernel was also instantiated for
+// every tie-free shape up to radius 16 (97 shapes x 2, five translation units): k_fp_slide5 has served those since round 4
+// (bit-identical results, 51 against 61 us on the bench map), and the one tie-free radius it does not take -- 16 cells --
+// goes to the double kernel like every unbounded layer.
+#define TE_F4_SHAPES_ALL(X) X(1) X(4) X(9) X(16) X(25) X(36) X(49) X(64) X(81) X(100) X(121) X(144) X(169) X(196) X(225) X(256)
 #undef TE_PARTS
 #undef TE_PART
 #define TE_PARTS 1
 #define TE_PART 0
-#endif
-#if TE_PARTS != 1 && TE_PARTS != 5
-#error "te_footprint3.hip is cut into 1 or 5 parts"
-#endif
 #ifndef TE_F4_SHAPES
-#if TE_PARTS == 1
-#define TE_F4_SHAPES(X) TE_F4_P0(X) TE_F4_P1(X) TE_F4_P2(X) TE_F4_P3(X) TE_F4_P4(X)
-#else
-#define TE_F4_CAT2(a, b) a##b
-#define TE_F4_CAT(a, b) TE_F4_CAT2(a, b)
-#define TE_F4_SHAPES(X) TE_F4_CAT(TE_F4_P, TE_PART)(X)
-#endif
+#define TE_F4_SHAPES(X) TE_F4_SHAPES_ALL(X)
 #endif
 #define TE_F4_NAME2(k) f4_launch_part##k
 #define TE_F4_NAME(k) TE_F4_NAME2(k)
@@ -444,18 +436,17 @@ bool TE_F4_NAME(TE_PART)(int Q, const void* args, int batch, hipStream_t s) {
 }
 
 #if TE_PART == 0
-#if TE_PARTS > 1
-bool f4_launch_part1(int Q, const void* args, int batch, hipStream_t s);
-bool f4_launch_part2(int Q, const void* args, int batch, hipStream_t s);
-bool f4_launch_part3(int Q, const void* args, int batch, hipStream_t s);
-bool f4_launch_part4(int Q, const void* args, int batch, hipStream_t s);
-#endif
 
 namespace {
 
 constexpr int kFBTab = 4;    // chunks of 64 spiral entries a lane keeps in registers (256 entries: radii up to 8 cells)
-constexpr int kFBTrip = 8;   // entries per trip of the per-lane walks, their loads issued together
-constexpr int kFBDense = 8;  // cells per wavefront of the launch from which every lane walks a disc of its own
+#ifndef TE_FB_TRIP
+#define TE_FB_TRIP 8
+#endif
+constexpr int kFBTrip = TE_FB_TRIP;   // entries per trip of the per-lane walks, their loads issued together
+constexpr int kFBDense = 32;  // cells per wavefront of the launch from which every lane walks a disc of its own (round 5: 8 -> 32.  The
+                              // lists are now made of discs walked to their rim, a few per row: neighbouring lanes' loads no longer
+                              // coalesce, and the per-wavefront walk wins up to some 500 boxes on the bench map)
 static_assert(kMaxSpiral % kFBTrip == 0, "k_fp_blocked reads whole trips of the table");
 
 struct FBArgs {
@@ -464,6 +455,7 @@ struct FBArgs {
   float* footprint;
   const unsigned* list;
   const unsigned* count;
+  const unsigned* page_count;
   const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16 | tie << 24 (kMaxSpiral words)
   int n_spiral, rows, cols, reach;
   unsigned map_cells;
@@ -492,12 +484,16 @@ __device__ __forceinline__ bool fb_on_circle_inside(const FBArgs& a, int i, int 
 //     inner radius, for the sum of the cells before it in the iterator's order.  About 25 instructions per disc; the
 //     wave-wide walk needs 250, and 3 million discs (3000 boxes) took it 1.5 ms.
 __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
-  const unsigned n = a.count[0], n_cells = a.count[1];  // entries reserved (some hold kF4NoCell) / cells
+  const unsigned n = a.count[0], n_cells = a.count[1];  // entries reserved (most of a reservation can be unused) / cells
   if (n == 0) return;
   const int lane = threadIdx.x;
   const unsigned nwaves = gridDim.x;
+  // the list comes in pages of count[2] entries (a power of two: 64, 128 or 256), of which the first page_count[p] count
+  const unsigned page_shift = (unsigned)(31 - __builtin_clz(a.count[2] | 1u));
+  // (sized by the cells, not by the entries reserved: the cells sit at the front of their reservations, and a group that
+  // spans a whole run of them would hand one wavefront 64 discs to walk while its neighbours find empty pages)
   unsigned group = 1;
-  while (group < (unsigned)kLanes && group * nwaves < n) group *= 2;
+  while (group < (unsigned)kLanes && group * nwaves < n_cells) group *= 2;
   const bool per_lane = a.path ? a.path == 2 : n_cells >= (unsigned)kFBDense * nwaves;
   // my entries of the table, and their offsets from the top left corner of the disc's bounding square
   unsigned tw[kFBTab];
@@ -511,10 +507,10 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
   }
   const int ctr = a.reach * a.rows + a.reach;
   const int nch = (a.n_spiral + kLanes - 1) / kLanes;
-  for (unsigned c0 = blockIdx.x * group; c0 < n; c0 += nwaves * group) {
-    const unsigned mycell = (unsigned)lane < group && c0 + lane < n ? a.list[c0 + lane] : kF4NoCell;
+  // one group of up to 64 list entries (kF4NoCell: none in this lane)
+  auto take = [&](const unsigned mycell) __attribute__((always_inline)) {
     const unsigned long long actm = __ballot(mycell != kF4NoCell);
-    if (actm == 0ull) continue;
+    if (actm == 0ull) return;
     // (cell -> map, column j, row i) once per lane; a lane without a cell takes the first one's: a valid address, and a
     // neighbour's.  (__shfl, not readlane: with readlane the compiler dropped the select and the empty lanes read
     // untrav[0xffffffff] -- a memory fault on the first obstacle map.)
@@ -530,111 +526,115 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
       const bool all_in = __all(i >= a.reach && i < a.rows - a.reach && j >= a.reach && j < a.cols - a.reach);
       const uint8_t* up = a.untrav + cellv;
       const float* tp = a.trav + cellv;
-      // Both walks come in two versions: every disc of the group inside the map (the offset of an entry is the same
-      // scalar for all lanes: no bounds, no selects -- 9 and 12 instructions per entry against 31), or not.
+      // The walk comes in two versions: every disc of the group inside the map (the offset of an entry is the same scalar
+      // for all lanes: no bounds, no selects), or not.  ONE pass (round 5; rounds 3-4 walked twice, first for the index of
+      // the first untraversable cell, then for the sum before it -- but the lists k_fp_slide5 leaves hold only discs that need
+      // the sum, see its inner disc): every lane adds up the cells it passes until it meets its first untraversable one.
+      // The finite cells add up in double, the others are counted and enter as n * default (the reference adds them in
+      // the iterator's order; at most a few hundred terms in [0, 1]: the order shows in the 16th digit).
       const int N = a.n_spiral;
-      // (1) the index of the first untraversable cell in the iterator's order :690
-      int kmin = N;  // none
-      auto first_hit = [&](auto fast) __attribute__((always_inline)) {
+      const int kstart = (int)a.count[3];  // entries before it cannot be untraversable (the producer saw to that): their mask bytes are not fetched
+      int kmin = N;  // index of the first untraversable cell in the iterator's order :690 (N: none yet)
+      double sum = 0.0;
+      int cnt = 0, ndef = 0;
+      auto walk = [&](auto fast) __attribute__((always_inline)) {
         constexpr bool kFast = decltype(fast)::value;
         for (int k0 = 0; k0 < N; k0 += kFBTrip) {
           if (__all(kmin < N)) break;
           uint8_t u[kFBTrip];
+          float t[kFBTrip];
           bool in[kFBTrip];
 #pragma unroll
           for (int q = 0; q < kFBTrip; ++q) {
-            const bool valid = k0 + q < N;                // uniform
+            const bool valid = k0 + q < N;                   // uniform
             const unsigned w = valid ? a.ptab[k0 + q] : 0u;  // uniform: a scalar load (past the end: the centre)
             const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
             in[q] = valid;
             if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
             if ((w >> 24) != 0u) in[q] = in[q] && fb_on_circle_inside(a, i, j, di, dj);  // (uniform branch)
-            u[q] = kFast ? up[dj * a.rows + di] : up[in[q] ? dj * a.rows + di : 0];
+            const int off = kFast ? dj * a.rows + di : (in[q] ? dj * a.rows + di : 0);
+            u[q] = k0 + q >= kstart ? up[off] : (uint8_t)0;  // (uniform)
+            t[q] = tp[off];
           }
 #pragma unroll
           for (int q = 0; q < kFBTrip; ++q) {
-            const int kq = (in[q] && u[q] != 0) ? k0 + q : N;
-            kmin = kq < kmin ? kq : kmin;
+            const bool before = kmin == N;
+            const bool hit = before && in[q] && u[q] != 0;
+            kmin = hit ? k0 + q : kmin;
+            const bool add = before && !hit && in[q];
+            const bool fin = __builtin_isfinite(t[q]);  // :719-724
+            sum += (double)((add && fin) ? t[q] : 0.0f);
+            cnt += add ? 1 : 0;
+            ndef += (add && !fin) ? 1 : 0;
           }
         }
       };
       if (all_in)
-        first_hit(std::true_type{});
+        walk(std::true_type{});
       else
-        first_hit(std::false_type{});
-      // (2) its ring decides :694-711: within the inner radius 0, beyond it the weighted mean of the cells before it
+        walk(std::false_type{});
+      // its ring decides :694-711: within the inner radius 0, beyond it the weighted mean of the cells before it
       const bool found = kmin < N;
       const int ring_no = found ? (int)((a.ptab[kmin] >> 16) & 0xffu) : 0;
       const double ru = (double)ring_no * a.res;  // getCurrentRadius()
-      const bool need = act && (!found || !(a.rmin == 0.0 || ru <= a.rmin));  // (not found: cannot happen for a listed cell; the mean then)
-      if (__any(need)) {
-        // the finite cells add up in double, the others are counted and enter as n * default (the reference adds them
-        // in the iterator's order; at most a few hundred terms in [0, 1]: the order shows in the 16th digit)
-        double sum = 0.0;
-        int cnt = 0, ndef = 0;
-        const int kend = need ? kmin : 0;
-        auto sum_before = [&](auto fast) __attribute__((always_inline)) {
-          constexpr bool kFast = decltype(fast)::value;
-          for (int k0 = 0; __any(k0 < kend); k0 += kFBTrip) {
-            float t[kFBTrip];
-            bool in[kFBTrip];
-#pragma unroll
-            for (int q = 0; q < kFBTrip; ++q) {
-              const bool valid = k0 + q < N;
-              const unsigned w = valid ? a.ptab[k0 + q] : 0u;
-              const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-              in[q] = k0 + q < kend;
-              if (!kFast) in[q] = in[q] && i + di >= 0 && i + di < a.rows && j + dj >= 0 && j + dj < a.cols;
-              if ((w >> 24) != 0u) in[q] = in[q] && fb_on_circle_inside(a, i, j, di, dj);
-              t[q] = kFast ? tp[dj * a.rows + di] : tp[in[q] ? dj * a.rows + di : 0];
-            }
-#pragma unroll
-            for (int q = 0; q < kFBTrip; ++q) {
-              const bool fin = __builtin_isfinite(t[q]);  // :719-724
-              sum += (double)((in[q] && fin) ? t[q] : 0.0f);
-              cnt += in[q] ? 1 : 0;
-              ndef += (in[q] && !fin) ? 1 : 0;
-            }
-          }
-        };
-        if (all_in)
-          sum_before(std::true_type{});
-        else
-          sum_before(std::false_type{});
-        if (need) {
-          sum += (double)ndef * a.def;
-          const double factor = found ? ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0 : 1.0;  // :705-711 (:732-735)
-          myout = (float)(sum * (factor / cnt));
-        }
+      if (act && !(found && (a.rmin == 0.0 || ru <= a.rmin))) {  // (not found: cannot happen for a listed cell; the mean then, :732-735)
+        sum += (double)ndef * a.def;
+        const double factor = found ? ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0 : 1.0;  // :705-711
+        myout = (float)(sum * (factor / cnt));
       }
       if (act) a.footprint[mycell] = myout;
-      continue;
+      return;
     }
-    // ---- one disc per wavefront at a time
-    unsigned long long rest = actm;
-    while (rest != 0ull) {
-      const int l = __builtin_ctzll(rest);
-      rest &= rest - 1ull;
-      const unsigned cell = (unsigned)__builtin_amdgcn_readlane((int)cellv, l);
-      const int i = __builtin_amdgcn_readlane((int)iv, l), j = __builtin_amdgcn_readlane((int)jv, l);
-      const bool inside = i >= a.reach && i < a.rows - a.reach && j >= a.reach && j < a.cols - a.reach;  // the whole bounding square lies in the map
+    // ---- one disc per wavefront at a time, the next disc's loads in flight while this one is evaluated
+    // (a disc that is on the list at all is walked far -- k_fp_slide5 lists only discs without an untraversable cell inside
+    // the inner radius -- so the loads of all register-resident chunks, discs of up to 8 cells radius: all of them, are
+    // issued together; chunk by chunk every step waited for its own two loads: 10 us per disc)
+    struct Disc1 {
+      unsigned cell;
+      int i, j;
+      bool inside;  // the whole bounding square lies in the map
+      bool qin[kFBTab];
+      uint8_t qu[kFBTab];
+      float qt[kFBTab];
+    };
+    // which of my entries' cells exist (inside the map, on the accepted side of the circle)
+    auto entry_in = [&](const Disc1& d, unsigned w, int k0) __attribute__((always_inline)) {
+      bool in = k0 + lane < a.n_spiral;
+      if (!d.inside) {
+        const int ii = d.i + (int)(signed char)(w & 0xffu), jj = d.j + (int)(signed char)((w >> 8) & 0xffu);
+        in = in && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
+      }
+      if (in && (w >> 24) != 0u) in = fb_on_circle_inside(a, d.i, d.j, (int)(signed char)(w & 0xffu), (int)(signed char)((w >> 8) & 0xffu));
+      return in;
+    };
+    auto issue = [&](int l, Disc1& d) __attribute__((always_inline)) {
+      d.cell = (unsigned)__builtin_amdgcn_readlane((int)cellv, l);
+      d.i = __builtin_amdgcn_readlane((int)iv, l);
+      d.j = __builtin_amdgcn_readlane((int)jv, l);
+      d.inside = d.i >= a.reach && d.i < a.rows - a.reach && d.j >= a.reach && d.j < a.cols - a.reach;
       // (a pointer before the layer for a cell near the border: never dereferenced, those lanes read the centre)
-      const float* tb = a.trav + ((long long)cell - ctr);
-      const uint8_t* ub = a.untrav + ((long long)cell - ctr);
+      const float* tb = a.trav + ((long long)d.cell - ctr);
+      const uint8_t* ub = a.untrav + ((long long)d.cell - ctr);
+      static_for<kFBTab>([&](auto chc) __attribute__((always_inline)) {
+        constexpr int ch = decltype(chc)::value;
+        d.qin[ch] = false;
+        d.qu[ch] = 0;
+        d.qt[ch] = 0.0f;
+        if (ch >= nch) return;  // uniform
+        d.qin[ch] = entry_in(d, tw[ch], ch * kLanes);
+        const int o = d.qin[ch] ? toff[ch] : ctr;
+        d.qu[ch] = ub[o];
+        d.qt[ch] = tb[o];
+      });
+    };
+    auto finish = [&](int l, const Disc1& d) __attribute__((always_inline)) {
+      const float* tb = a.trav + ((long long)d.cell - ctr);
+      const uint8_t* ub = a.untrav + ((long long)d.cell - ctr);
       double acc = 0.0;
       int cnt = 0;
       float oc = 0.0f;
       bool done = false;
-      auto chunk = [&](unsigned w, int off, int k0) __attribute__((always_inline)) {
-        bool in = k0 + lane < a.n_spiral;
-        if (!inside) {
-          const int ii = i + (int)(signed char)(w & 0xffu), jj = j + (int)(signed char)((w >> 8) & 0xffu);
-          in = in && ii >= 0 && ii < a.rows && jj >= 0 && jj < a.cols;
-        }
-        if (in && (w >> 24) != 0u) in = fb_on_circle_inside(a, i, j, (int)(signed char)(w & 0xffu), (int)(signed char)((w >> 8) & 0xffu));
-        const int o = in ? off : ctr;
-        const uint8_t u = ub[o];
-        const float t = tb[o];
+      auto chunk = [&](unsigned w, bool in, uint8_t u, float t) __attribute__((always_inline)) {
         const unsigned long long bm = __ballot(in && u != 0);
         const double v = __builtin_isfinite(t) ? (double)t : a.def;  // :719-724
         if (bm != 0ull) {  // the first untraversable cell :690-717
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
           acc += before ? v : 0.0;
           cnt += __popcll(__ballot(before));
 #pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+          for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd);
           const double factor = ((ru - a.rmin) / (a.rmax - a.rmin) + 1.0) / 2.0;  // :705-711
           oc = (float)(acc * (factor / cnt));
           return;
@@ -658,22 +658,74 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
       static_for<kFBTab>([&](auto chc) __attribute__((always_inline)) {
         constexpr int ch = decltype(chc)::value;
         if (done || ch >= nch) return;  // uniform
-        chunk(tw[ch], toff[ch], ch * kLanes);
+        chunk(tw[ch], d.qin[ch], d.qu[ch], d.qt[ch]);
       });
       for (int ch = kFBTab; ch < nch && !done; ++ch) {
         const int k = ch * kLanes + lane;
         const unsigned w = k < a.n_spiral ? a.ptab[k] : 0u;
         const int di = (int)(signed char)(w & 0xffu), dj = (int)(signed char)((w >> 8) & 0xffu);
-        chunk(w, (dj + a.reach) * a.rows + (di + a.reach), ch * kLanes);
+        const bool in = entry_in(d, w, ch * kLanes);
+        const int o = in ? (dj + a.reach) * a.rows + (di + a.reach) : ctr;
+        chunk(w, in, ub[o], tb[o]);
       }
       if (!done) {  // (no untraversable cell after all: the mean :732-735)
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd);
         oc = (float)(acc / cnt);
       }
       if (lane == l) myout = oc;
+    };
+    unsigned long long rest = actm;
+    Disc1 cur, nxt;
+    int lc = __builtin_ctzll(rest);
+    rest &= rest - 1ull;
+    issue(lc, cur);
+    while (true) {
+      const bool more = rest != 0ull;  // (uniform)
+      int ln = 0;
+      if (more) {
+        ln = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        issue(ln, nxt);
+      }
+      finish(lc, cur);
+      if (!more) break;
+      cur = nxt;
+      lc = ln;
     }
     if (mycell != kF4NoCell) a.footprint[mycell] = myout;
+  };
+  if (per_lane) {
+    // Long list: the pages are dealt out round-robin (page p to wavefront p mod nwaves: the cells sit at the front of
+    // their blocks' reservations, neighbouring pages hold similar amounts of work) and a wavefront fetches the counts of
+    // its next 64 pages with ONE load -- most of a reservation is empty, and an entry-by-entry loop paid a dependent load
+    // per 64 entries to find that out (300 boxes: 170 -> 290 us with k_fp_slide5's one reservation per block).
+    const unsigned npages = (n + (1u << page_shift) - 1u) >> page_shift;
+    for (unsigned pb = blockIdx.x; pb < npages; pb += nwaves * (unsigned)kLanes) {
+      const unsigned my_page = pb + (unsigned)lane * nwaves;
+      const unsigned cnt = my_page < npages ? a.page_count[my_page] : 0u;
+      unsigned long long pm = __ballot(cnt != 0u);
+      while (pm != 0ull) {
+        const int l = __builtin_ctzll(pm);
+        pm &= pm - 1ull;
+        const unsigned page = (unsigned)__builtin_amdgcn_readlane((int)my_page, l), c = (unsigned)__builtin_amdgcn_readlane((int)cnt, l);
+        for (unsigned g0 = 0; g0 < c; g0 += (unsigned)kLanes)
+          take(g0 + (unsigned)lane < c ? a.list[(page << page_shift) + g0 + (unsigned)lane] : kF4NoCell);
+      }
+    }
+    return;
+  }
+  // Short list: `group` consecutive entries per trip, as few as keep every wavefront busy
+  for (unsigned c0 = blockIdx.x * group; c0 < n; c0 += nwaves * group) {
+    unsigned mycell = kF4NoCell;
+    {
+      const unsigned e = c0 + (unsigned)lane;
+      if ((unsigned)lane < group && e < n) {
+        const unsigned pg = e >> page_shift;
+        if (e - (pg << page_shift) < a.page_count[pg]) mycell = a.list[e];
+      }
+    }
+    take(mycell);
   }
 }
 
@@ -698,6 +750,7 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
   a.footprint = L.footprint;
   a.list = L.fp_blocked;
   a.count = L.fp_blocked_count;
+  a.page_count = L.fp_page_count;
   a.ptab = reinterpret_cast<const unsigned*>(spiral_table + 4 * kMaxSpiral);
   a.n_spiral = p.n_spiral;
   a.rows = g.rows;
@@ -726,14 +779,11 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   static const bool no_ties = lab_flag("TE_F4_NO_TIES");  // measurement aid: tie radii to the general kernel as before
   // The shape the kernel slides: the disc itself, or for a tie radius the disc with its circle (whole-cell radii only:
   // every cell on the circle has the norm reach^2, and the runs plus the circle are the shape reach^2).
-  int shape = d.Q, R = d.R;
-  if (d.n_ties != 0) {
-    R = p.reach;
-    shape = R * R;
-    if (no_ties) return false;
-    for (int t = 0; t < d.n_ties; ++t)
-      if ((int)d.tie_di[t] * d.tie_di[t] + (int)d.tie_dj[t] * d.tie_dj[t] != shape) return false;
-  }
+  if (d.n_ties == 0) return false;  // tie-free discs: k_fp_slide5 (te_footprint5.hip), else the double kernel
+  const int R = p.reach, shape = R * R;
+  if (no_ties) return false;
+  for (int t = 0; t < d.n_ties; ++t)
+    if ((int)d.tie_di[t] * d.tie_di[t] + (int)d.tie_dj[t] * d.tie_dj[t] != shape) return false;
   if (off || shape < 1 || R < 1 || p.reach != R || g.rows < kLanes || g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
   // 32-bit list entries, and room for every block's unfinished chunk
@@ -775,12 +825,9 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.inv_scale = ldexp(1.0, -k);
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
+  a.page_count = L.fp_page_count;
   a.list_cap = L.fp_blocked_cap;
-  bool launched = f4_launch_part0(shape, &a, g.batch, s);
-#if TE_PARTS > 1
-  launched = launched || f4_launch_part1(shape, &a, g.batch, s) || f4_launch_part2(shape, &a, g.batch, s) || f4_launch_part3(shape, &a, g.batch, s) ||
-             f4_launch_part4(shape, &a, g.batch, s);
-#endif
+  const bool launched = f4_launch_part0(shape, &a, g.batch, s);
   if (launched && finish) footprint_blocked4(g, p, L, spiral_table, s);
   return launched;
 }

@@ -45,8 +45,9 @@ struct F5Args {
   float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 27, scale = 2^k
   double inv_scale;    // 2^-k
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
-  unsigned* blocked_count;  // ... [0] entries reserved, [1] entries that hold a cell (k_fp_mask resets both)
-  int chunk;                // entries a block reserves at a time
+  unsigned* blocked_count;  // ... [0] entries reserved, [1] entries that hold a cell (k_fp_mask resets both), [2] the page size (= chunk)
+  unsigned* page_count;     // entries of page p (chunk entries each) that hold a cell: k_fp_blocked looks at no others
+  int chunk;                // the page size: a block reserves whole pages
   size_t list_cap;          // (host side: the launcher refuses a grid whose unfinished chunks might not fit)
   // one byte per 64 x 4 cells, written by k_fp_mask: "holds an untraversable cell" (Layers::untrav_flags).  A strip whose
   // flags are all clear -- on terrain without obstacles every strip -- does not fetch its mask bytes: the byte loads stay
@@ -55,16 +56,17 @@ struct F5Args {
   // 0.148-0.154 ms: profiles/r04_experiments.json.)
   const uint8_t* untrav_flags;
   int flag_ntx, flag_nfy;
-#ifdef TE_F5_WHATIF_FUSED
-  // WHAT-IF BUILD (timing only, results wrong by construction; tools/lab/r05_exp1.sh): "one footprint kernel" -- the march
-  // stages elevation and the three scores itself (12 loads per pass instead of 6), combines them (MathExpressionFilter),
-  // stores the combined layer and a mask byte for its own rows, and sums; isTraversableForFilters is stubbed (every cell
-  // passes) and k_fp_mask is not launched.  What the fusion could gain at most, before any of its difficulties.
-  const float *w_elev, *w_slope, *w_step, *w_rough;
-  float* w_trav;
-  uint8_t* w_untrav;
-  float ws, wa, wb, wc;
-#endif
+  // THE INNER DISC.  A disc that holds an untraversable cell is 0 when the FIRST such cell of the spiral lies within the
+  // inner radius (:694-704: getCurrentRadius() = ring * res <= radiusMin), and rings are walked in ascending order: so
+  // it is 0 iff some untraversable cell of the disc has an integer norm floor(|offset|) <= r_in, r_in the last ring with
+  // r_in * res <= radiusMin -- a question about a smaller disc, which the march answers on the way (strips that hold an
+  // untraversable cell at all: inner_row below).  Only the discs whose untraversable cells ALL lie between the two radii go
+  // onto the list for k_fp_blocked: a third of what rounds 3-4 listed next to a kerb (radii 6 and 9 cells), and exactly
+  // the ones that need the weighted mean of :705-711.
+  int r_in;                  // -1: no inner radius (radiusMin = 0 is handled by rmin_zero)
+  int k_start;               // spiral entries 0 .. k_start-1 are the inner disc's: none of them is untraversable in a listed disc
+  unsigned inner_tab[17];    // [g], g = distance along the row to the nearest untraversable cell (r_in + 1: none within r_in):
+                             // bit b set <=> a cell at that distance in a row |r_in - b| rows away lies within the inner disc
 };
 
 template <int Q>
@@ -80,20 +82,24 @@ struct SlideK {
   int js, nout, r0;               // r0 = js - R: the strip's first input row (the descriptors' row 0)
   float tm0[C], tm1[C], th[C];
   unsigned um0[C], um1[C], uh[C];
-#ifdef TE_F5_WHATIF_FUSED
-  brsrc rs_e, rs_s, rs_p, rs_r, rs_tw, rs_uw;
-  float e0[C], e1[C], eh[C], s0[C], s1[C], sh[C], p0[C], p1[C], ph[C], q0[C], q1[C], qh[C];
-#endif
   unsigned* lds;   // [2][W]
   unsigned c0, c1;
-  unsigned ubits;  // my own cells' U, newest row in bit 0
+  // inner disc (strips that hold an untraversable cell): hb bit b = "output row (current input row) - r_in + b has an
+  // untraversable cell within the inner disc among the rows staged so far"; hist: the finished answers, newest row in bit 0
+  unsigned hb, hist;
+  bool dirty;  // (uniform) some flag of the strip's window is set: the mask bytes are loaded and the inner disc is tracked
+  int ri;
+  unsigned in_word, in_sh;  // which 32-bit word of a row's window bits my run starts in, and at which bit
   size_t mo;
   int icol, kx, nt_mid;
   bool own, rmin_zero;
   float rnt;
-  // the list
-  unsigned chunk_at;
-  int chunk_left, listed_total;
+  // the list: ONE reservation per block, made when the block first lists a cell -- room for every cell the rest of its
+  // strip could list, in whole pages.  (Rounds 3-4 reserved a chunk of 256 entries at a time: a strip that runs along a
+  // kerb paid an atomic round trip every four to six rows, 20 us of a 50 us kernel with three boxes on the map; larger
+  // chunks were no way out while k_fp_blocked had to step over their unused entries.  It now reads the page counts.)
+  unsigned res_base;
+  int res_len, listed_total;
 
   __device__ __forceinline__ SlideK(const F5Args& a_) : a(a_) {}
 
@@ -118,45 +124,30 @@ struct SlideK {
       unsigned any = 0;
       for (int k = lane; k < n; k += kLanes) any |= fl[(size_t)(f0 + k / nc) * a.flag_ntx + (size_t)(c0 + k % nc)];
       const bool clean = !__any(any != 0u);  // (uniform)
+      dirty = !clean && a.r_in >= 0;
       const void* ub = a.untrav + mo + ((long long)(js_ - R) * a.rows + (i0 - R));
       rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ub), /*stride*/ 0, /*num_records*/ clean ? 0 : 0x7fffffff, /*flags*/ 0x00020000);
     }
     rs_out = make_rsrc(a.footprint + mo + ((long long)(js_ - 2 * R) * a.rows + (i0 - R)));
-#ifdef TE_F5_WHATIF_FUSED
-    {
-      const long long o = (long long)mo + ((long long)(js_ - R) * a.rows + (i0 - R));
-      rs_e = make_rsrc(a.w_elev + o);
-      rs_s = make_rsrc(a.w_slope + o);
-      rs_p = make_rsrc(a.w_step + o);
-      rs_r = make_rsrc(a.w_rough + o);
-      rs_tw = make_rsrc(a.w_trav + o);
-      rs_uw = make_rsrc(a.w_untrav + o);
-    }
-#endif
     icol = i0 + lane;
     own = icol >= own_lo;
     rmin_zero = a.rmin == 0.0;
     kx = icol < R ? R - icol : (a.rows - 1 - icol < R ? -(R - (a.rows - 1 - icol)) : 0);
     nt_mid = a.gtab[((0 + R) * (2 * R + 1) + (kx + R)) * 6];  // cells of my disc on a row away from the top / bottom
     rnt = (float)(a.inv_scale / (double)nt_mid);
-    ubits = 0;
-    chunk_at = 0;
-    chunk_left = 0;
+    hb = hist = 0u;
+    ri = a.r_in >= 0 ? a.r_in : 0;
+    in_word = (unsigned)(lane + R - ri) >> 5;
+    in_sh = (unsigned)(lane + R - ri) & 31u;
+    if (lane < 17) lds[2 * W + lane] = a.inner_tab[lane];  // (LDS operations of a wave execute in order: visible to the reads below)
+    res_base = 0;
+    res_len = 0;
     listed_total = 0;
   }
   // (unconditional: see Step5Base::load_pair in te_step5.hip and kSlabGuardRows)
   template <int q>
   __device__ __forceinline__ void load_pair(int r, ic<q>) {
     const unsigned sb = (unsigned)(r - r0) * (unsigned)a.rows, so = sb * 4u;  // (uniform; the mask is one byte per cell)
-#ifdef TE_F5_WHATIF_FUSED
-    e0[q] = bload_f(rs_e, L.o_main0, so); e1[q] = bload_f(rs_e, L.o_main1, so); eh[q] = bload_f(rs_e, L.o_halo, so);
-    s0[q] = bload_f(rs_s, L.o_main0, so); s1[q] = bload_f(rs_s, L.o_main1, so); sh[q] = bload_f(rs_s, L.o_halo, so);
-    p0[q] = bload_f(rs_p, L.o_main0, so); p1[q] = bload_f(rs_p, L.o_main1, so); ph[q] = bload_f(rs_p, L.o_halo, so);
-    q0[q] = bload_f(rs_r, L.o_main0, so); q1[q] = bload_f(rs_r, L.o_main1, so); qh[q] = bload_f(rs_r, L.o_halo, so);
-    um0[q] = um1[q] = uh[q] = 0u;
-    tm0[q] = tm1[q] = th[q] = 0.0f;
-    return;
-#endif
     tm0[q] = bload_f(rs_t, L.o_main0, so);
     tm1[q] = bload_f(rs_t, L.o_main1, so);
     th[q] = bload_f(rs_t, L.o_halo, so);
@@ -173,10 +164,6 @@ struct SlideK {
   __device__ __forceinline__ void rotate_queue(ic<n>) {
     if constexpr (n % C != 0) {
       static_assert(C == 2, "a queue of two passes");
-#ifdef TE_F5_WHATIF_FUSED
-      auto sw = [](float (&x)[C]) { const float t = x[0]; x[0] = x[1]; x[1] = t; };
-      sw(e0); sw(e1); sw(eh); sw(s0); sw(s1); sw(sh); sw(p0); sw(p1); sw(ph); sw(q0); sw(q1); sw(qh);
-#endif
       const float f0 = tm0[0], f1 = tm1[0], fh = th[0];
       const unsigned u0 = um0[0], u1 = um1[0], u2 = uh[0];
       tm0[0] = tm0[1];
@@ -198,29 +185,29 @@ struct SlideK {
     // round(T' * 2^k): the product is exact, + 0.5 is exact below 2^23, the conversion truncates (and clamps at 0)
     return (unsigned)__builtin_fmaf(tt, a.scale, 0.5f) | (u << kF5UBit);
   }
+  // One staged row for the inner disc.  mm: my 64 main cells' untraversable bits; hb2: the row's 2R halo cells (bits 0..R-1
+  // the columns left of the block, R..2R-1 the columns right of it), cells outside the map already 0.  The row's window is
+  // a bit string of W <= 94 bits in three uniform words; a lane needs the 2 r_in + 1 bits around its own column, which start
+  // at bit in_sh = lane + R - r_in: a funnel shift (v_alignbit) of the two words that hold them -- which two is a property
+  // of the lane (in_word: 0, 1 or 2), not of the row.
+  __device__ __forceinline__ void inner_row(unsigned long long mm, unsigned long long hb2) {
+    constexpr unsigned long long RM = (1ull << R) - 1ull;
+    const unsigned long long lo = (hb2 & RM) | (mm << R);                 // window columns 0 .. 63
+    const unsigned long long hi = (mm >> (64 - R)) | ((hb2 >> R) << R);   // window columns 64 .. W-1
+    const unsigned w0 = (unsigned)lo, w1 = (unsigned)(lo >> 32), w2 = (unsigned)hi, w3 = (unsigned)(hi >> 32);  // (uniform)
+    const unsigned wl = in_word == 0 ? w0 : (in_word == 1 ? w1 : w2);
+    const unsigned wh = in_word == 0 ? w1 : (in_word == 1 ? w2 : w3);
+    const unsigned x = __builtin_amdgcn_alignbit(wh, wl, in_sh) & ((2u << (2 * ri)) - 1u);  // bit ri: my own cell
+    const unsigned left = x & ((2u << ri) - 1u);                              // bits 0 .. ri: my cell and the ones before it
+    const unsigned dleft = (unsigned)__clz((int)left) - (unsigned)(31 - ri);  // (no such cell: __clz(0) = 32 -> ri + 1)
+    const unsigned dright = (unsigned)(__ffs((int)(x >> ri)) - 1);            // (no such cell: __ffs(0) = 0 -> 0xffffffff)
+    const unsigned g = dleft < dright ? dleft : dright;                       // 0 .. ri + 1
+    hb |= lds[2 * W + g];
+    hist = (hist << 1) | (hb & 1u);
+    hb >>= 1;
+  }
   template <int q>
   __device__ __forceinline__ void stage_pair(int r, ic<q>) {
-#ifdef TE_F5_WHATIF_FUSED
-    {
-      auto comb = [&](float sl, float st, float ro) { return a.ws * ((a.wa * sl + a.wb * st) + a.wc * ro); };
-      auto stub = [&](float el, float st) { return (st == 0.0f && el > 1e30f) ? 1u : 0u; };  // (never 1: keeps the elevation loads alive)
-      tm0[q] = comb(s0[q], p0[q], q0[q]);
-      tm1[q] = comb(s1[q], p1[q], q1[q]);
-      th[q] = comb(sh[q], ph[q], qh[q]);
-      um0[q] = stub(e0[q], p0[q]);
-      um1[q] = stub(e1[q], p1[q]);
-      uh[q] = stub(eh[q], ph[q]);
-      const unsigned so = (unsigned)(r - r0) * row_bytes, sb = (unsigned)(r - r0) * (unsigned)a.rows;
-      if ((unsigned)(r - js) < (unsigned)nout) {  // (uniform) my own rows: the combined layer and the mask byte
-        bstore_f(rs_tw, L.o_main0, so, tm0[q]);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)um0[q], rs_uw, ob_main0, sb, 0);
-      }
-      if ((unsigned)(r + 1 - js) < (unsigned)nout) {
-        bstore_f(rs_tw, L.o_main1, so, tm1[q]);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)um1[q], rs_uw, ob_main1, sb, 0);
-      }
-    }
-#endif
     c0 = pack(tm0[q], um0[q]);
     c1 = pack(tm1[q], um1[q]);
     unsigned vh = L.halo_in ? pack(th[q], uh[q]) : 0u;  // cells outside the map: nothing
@@ -236,7 +223,18 @@ struct SlideK {
     lds[R + L.lane] = c0;
     lds[W + R + L.lane] = c1;
     lds[L.hlds] = vh;
-    ubits = (ubits << 2) | (u0 << 1) | u1;
+    if (__builtin_expect(dirty, 0)) {  // (uniform)
+      constexpr unsigned long long HM = (1ull << (2 * R)) - 1ull;
+      const unsigned long long m0 = __ballot(u0 != 0u), m1 = __ballot(u1 != 0u);
+      const unsigned long long mh = __ballot((vh >> kF5UBit) != 0u);  // lanes 0 .. 2R-1: row r, 2R .. 4R-1: row r + 1 (the others repeat lane 4R-1)
+      if ((m0 | m1 | mh) == 0ull) {  // (uniform) no untraversable cell in either row's window: nothing to add, two answers move on
+        hist = (hist << 2) | ((hb & 1u) << 1) | ((hb >> 1) & 1u);
+        hb >>= 2;
+      } else {
+        inner_row(m0, mh & HM);
+        inner_row(m1, (mh >> (2 * R)) & HM);
+      }
+    }
   }
   template <int slot>
   __device__ __forceinline__ void build(ic<slot>, Run (&s)[R + 1]) {
@@ -260,9 +258,6 @@ struct SlideK {
   __device__ __forceinline__ void fold2(Acc& x, const Run& s1, const Run& s2) {
     x = __builtin_elementwise_add_sat(__builtin_elementwise_add_sat(x, s1), s2);
   }
-  __device__ __forceinline__ void fill_chunk() {
-    for (int q = L.lane; q < chunk_left; q += kLanes) a.blocked_list[chunk_at + (unsigned)q] = kF4NoCell;
-  }
   template <int second>
   __device__ __forceinline__ void emit(ic<second>, int j, const Acc& x) {
     if (!((unsigned)(j - js) < (unsigned)nout)) return;  // (uniform)
@@ -279,35 +274,29 @@ struct SlideK {
       if (rmin_zero) {
         out = blocked ? 0.0f : out;  // :694-704 radiusMin = 0: the first untraversable cell, wherever it lies, gives 0
       } else {
-        // An untraversable centre cell is the spiral's first cell: 0 (ring 0 lies within any inner radius > 0, :694-704).
-        // My own cell of row j: the rows of this pass are bits 1 and 0 of ubits, row j is R rows above the one that
-        // completed it.  The other discs with an untraversable cell go onto the list: k_fp_blocked walks their spirals
-        // and stores their values after this kernel; nothing is stored for them here -- not by the block that lists them
-        // and not by a shifted last block that shares the column (on a region run its neighbour need not be part of
-        // the launch, and the cell then keeps the value it has).
-        const bool self = ((ubits >> (second ? R : R + 1)) & 1u) != 0u;
-        out = (blocked && self) ? 0.0f : out;
-        const bool walk = blocked && !self;
+        // An untraversable cell within the inner radius -- the centre itself is ring 0 -- makes the disc 0 (:694-704); the
+        // answer for row j was finished when row j + r_in was staged, R - r_in rows before the row that completed the sum
+        // (this pass's rows are bits 1 and 0 of hist).  The other discs with an untraversable cell go onto the list:
+        // k_fp_blocked walks their spirals and stores their values after this kernel; nothing is stored for them here --
+        // not by the block that lists them and not by a shifted last block that shares the column (on a region run its
+        // neighbour need not be part of the launch, and the cell then keeps the value it has).
+        const bool inner = ((hist >> (unsigned)((second ? R : R + 1) - ri)) & 1u) != 0u;
+        out = (blocked && inner) ? 0.0f : out;
+        const bool walk = blocked && !inner;
         const bool listed = walk && own;
         const unsigned long long bm = __ballot(listed);
         if (bm != 0ull) {
           const int n = __popcll(bm);
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-          // a row that does not fit the rest of the chunk fills it to the last entry and continues in a new one: every
-          // closed chunk is full, so a launch reserves at most (listed cells + one chunk per block) entries
-          unsigned at = chunk_at + (unsigned)rank;
-          if (n > chunk_left) {
-            const int old_left = chunk_left;
+          if (res_len == 0) {  // (uniform) rows are emitted in ascending order: this row and the ones below it can list 64 cells each
+            const int rows_left = nout - (j - js);
+            const unsigned want = ((unsigned)(rows_left * kLanes) + (unsigned)a.chunk - 1u) / (unsigned)a.chunk * (unsigned)a.chunk;
             unsigned base = 0;
-            if (L.lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (rank >= old_left) at = base + (unsigned)(rank - old_left);
-            chunk_at = base - (unsigned)old_left;
-            chunk_left = a.chunk + old_left;
+            if (L.lane == 0) base = atomicAdd(a.blocked_count, want);
+            res_base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            res_len = (int)want;
           }
-          if (listed) a.blocked_list[at] = (unsigned)(mo + (size_t)j * a.rows + icol);
-          chunk_at += (unsigned)n;
-          chunk_left -= n;
+          if (listed) a.blocked_list[res_base + (unsigned)(listed_total + rank)] = (unsigned)(mo + (size_t)j * a.rows + icol);
           listed_total += n;
         }
         if (!walk) bstore_f(rs_out, L.o_main0, so, out);
@@ -318,15 +307,22 @@ struct SlideK {
     bstore_f(rs_out, L.o_main0, so, out);
   }
   __device__ __forceinline__ void finish() {
-    fill_chunk();
-    if (listed_total != 0 && L.lane == 0) atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
+    if (res_len == 0) return;  // (uniform)
+    // the page counts of my reservation: full pages, one partly filled, empty ones behind it
+    const int pages = res_len / a.chunk;
+    const unsigned p0 = res_base / (unsigned)a.chunk;  // (every reservation is a whole number of pages: so is every base)
+    for (int p = L.lane; p < pages; p += kLanes) {
+      const int c = listed_total - p * a.chunk;
+      a.page_count[p0 + (unsigned)p] = (unsigned)(c < 0 ? 0 : (c > a.chunk ? a.chunk : c));
+    }
+    if (L.lane == 0) atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
   }
 };
 
 template <int Q>
 __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF5Waves, kF5Waves))) void k_fp_slide5(F5Args a) {
   constexpr int R = Shape<Q>::R, W = kLanes + 2 * R;
-  __shared__ unsigned lds[2 * W];
+  __shared__ unsigned lds[2 * W + 17];  // the two staged rows, the inner disc's table
   const int lane = threadIdx.x;
   const int bx = a.bx0 + (int)blockIdx.x % a.nbx_l, strip = (int)blockIdx.x / a.nbx_l;
   int i0 = bx * kLanes;
@@ -338,6 +334,10 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF5Waves
   SlideK<Q> k(a);
   // the last block of a row of blocks is shifted left: the columns it shares with its neighbour are the neighbour's
   // (one list entry per cell; both store the same value)
+  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
+    a.blocked_count[2] = (unsigned)a.chunk;    // the page size of this pass, for k_fp_blocked
+    a.blocked_count[3] = (unsigned)a.k_start;  // ... and the first spiral entry that can be the first untraversable cell of a listed disc
+  }
   k.init(lane, i0, bx * kLanes, js, jend, mo, lds);
   march5<Q>(k, js, jend);
   k.finish();
@@ -357,8 +357,9 @@ bool launch_f5(const F5Args& a0, int batch, hipStream_t s) {
   const int sr = a.strip_rows;
   a.chunk = sr >= 4 ? kF4Chunk : (sr * kLanes >= kF4Chunk / 2 ? kF4Chunk / 2 : kLanes);  // (a strip of one row lists at most 64 cells)
   const int nstrips = (H + sr - 1) / sr;
-  // every listed cell takes one entry and every block may leave one chunk unfinished (closed chunks are full)
-  if ((double)a.nbx_l * (double)nstrips * (double)nz * (double)a.chunk + (double)a.map_cells * (double)nz > (double)a.list_cap) return false;
+  // a block reserves at most its own cells rounded up to whole pages
+  // (64 entries per row of every block -- a shifted last block reserves for the columns it shares with its neighbour too)
+  if ((double)a.nbx_l * (double)nz * ((double)H * (double)kLanes + (double)nstrips * (double)a.chunk) > (double)a.list_cap) return false;
   const dim3 grid((unsigned)(a.nbx_l * nstrips), 1, (unsigned)nz);
   hipLaunchKernelGGL((k_fp_slide5<Q>), grid, dim3(kLanes), 0, s, a);
   return true;
@@ -416,15 +417,6 @@ bool f5_launch_part3(int Q, const void* args, int batch, hipStream_t s);
 bool f5_launch_part4(int Q, const void* args, int batch, hipStream_t s);
 #endif
 
-// What-if build only (TE_F5_WHATIF_FUSED): the sum kernel also stands in for the mask kernel, which is then not launched.
-bool footprint_slide5_replaces_mask() {
-#ifdef TE_F5_WHATIF_FUSED
-  return true;
-#else
-  return false;
-#endif
-}
-
 // The scatter-form sum kernel of the footprint pass for a tie-free disc of an instantiated shape; false: not taken
 // (the caller tries k_fp_slide4, then the double kernel).  tcap: upper bound of the finite values of the traversability
 // layer, as the host can prove it (the layer was written by the chain: w_scale * (w_slope + w_step + w_rough) with
@@ -470,22 +462,39 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.def = (float)p.def;
   a.scale = (float)ldexp(1.0, k);
   a.inv_scale = ldexp(1.0, -k);
+  {
+    // the last ring within the inner radius, with the comparison k_fp_blocked and the reference make (:700: getCurrentRadius() <= radiusMin)
+    int r_in = -1;
+    while (r_in + 1 <= R && (double)(r_in + 1) * g.res <= p.rmin) ++r_in;
+    a.r_in = p.rmin > 0.0 ? r_in : -1;
+    // the spiral visits the cells of ring <= r_in first (rings in ascending order; the disc's two outer rings only where they lie in the disc)
+    a.k_start = 0;
+    if (a.r_in >= 0)
+      for (int dj = -d.R; dj <= d.R; ++dj)
+        for (int di = -d.hw[dj < 0 ? -dj : dj]; di <= d.hw[dj < 0 ? -dj : dj]; ++di) a.k_start += di * di + dj * dj < (a.r_in + 1) * (a.r_in + 1) ? 1 : 0;
+    for (int gg = 0; gg < 17; ++gg) a.inner_tab[gg] = 0u;
+    if (a.r_in >= 0) {
+      const int ri = a.r_in;
+      for (int gg = 0; gg <= ri; ++gg)  // (gg = ri + 1: no untraversable cell of the row within ri columns: no bit)
+        for (int b = 0; b <= 2 * ri; ++b) {
+          const int dj = ri - b < 0 ? b - ri : ri - b;
+          // cells (di, dj) of ring <= ri: di^2 + dj^2 < (ri + 1)^2; the two outer rings of the spiral keep only cells of the disc
+          int w = -1;
+          while ((w + 1) * (w + 1) + dj * dj < (ri + 1) * (ri + 1)) ++w;
+          if (dj <= d.R && d.hw[dj] < w) w = d.hw[dj];
+          if (dj > d.R) w = -1;
+          if (gg <= w) a.inner_tab[gg] |= 1u << b;
+        }
+    }
+  }
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
+  a.page_count = L.fp_page_count;
   a.chunk = kF4Chunk;
   a.list_cap = L.fp_blocked_cap;
   a.untrav_flags = L.untrav_flags;
   a.flag_ntx = untrav_flag_ntx(g.rows);
   a.flag_nfy = untrav_flag_nfy(g.cols);
-#ifdef TE_F5_WHATIF_FUSED
-  a.w_elev = L.elev;
-  a.w_slope = L.slope;
-  a.w_step = L.step;
-  a.w_rough = L.rough;
-  a.w_trav = L.trav;
-  a.w_untrav = L.untrav;
-  a.ws = a.wa = a.wb = a.wc = 1.0f / 3.0f;  // (timing only)
-#endif
   bool launched = f5_launch_part0(shape, &a, g.batch, s);
 #if TE_PARTS > 1
   launched = launched || f5_launch_part1(shape, &a, g.batch, s) || f5_launch_part2(shape, &a, g.batch, s) || f5_launch_part3(shape, &a, g.batch, s) ||

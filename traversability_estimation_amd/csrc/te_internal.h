@@ -121,7 +121,8 @@ struct Layers {
   uint8_t* untrav;     // !isTraversableForFilters per cell
   float* tie_scratch;          // one float per cell: the step filter at a tie radius (te_fast_step.hip); nullptr: not allocated
   unsigned* fp_blocked;        // k_fp_slide4's list of cells whose disc holds an untraversable cell (one entry per cell at most) ...
-  unsigned* fp_blocked_count;  // ... and its length (k_fp_mask resets it)
+  unsigned* fp_blocked_count;  // ... [0] entries reserved, [1] cells listed (k_fp_mask resets both), [2] entries per page (the sum kernel's chunk)
+  unsigned* fp_page_count;     // the list in pages of [2] entries: how many entries of page p hold a cell (the rest of a reservation is unused)
   size_t fp_blocked_cap;       // entries the list holds (cells + fast::f4_list_slack)
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
   uint8_t* untrav_flags;  // one byte per 64 x 4 cells: "holds an untraversable cell" as of the mask kernel's last pass over them (1 until then);
@@ -333,7 +334,6 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
 // footprint_blocked4 for the listed cells (after every launch of the pass)
 bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, const int* clip_table, double tcap, hipStream_t s,
                       const Region* region, bool* needs_blocked);
-bool footprint_slide5_replaces_mask();  // false in every shipped build (te_footprint5.hip, TE_F5_WHATIF_FUSED: a timing experiment)
 constexpr int kClipInts = 6 * (2 * kMaxRadiusCells + 1) * (2 * kMaxRadiusCells + 1);  // one clip table of the normals disc; for a tie radius the
                                                                                       // table of the disc with its circle follows, then the packed offsets
 constexpr int kFpClipInts = 6 * 41 * 41;  // one clip table of the footprint disc (reach <= 20); a second one follows it for a tie
