@@ -371,7 +371,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
   const int i0 = ((int)blockIdx.x + a.ti0) * MX, j0 = ((int)blockIdx.y + a.tj0) * MY;
   // (the footprint pass's list of blocked cells starts empty: k_fp_slide4 / k_fp_blocked run after this kernel)
   if (a.blocked_count && threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-    a.blocked_count[0] = a.blocked_count[1] = 0u;
+    a.blocked_count[0] = a.blocked_count[1] = a.blocked_count[4] = 0u;
   // my tile's flags (flag rows j0 / 4 .. of flag column i0 / 64: i0 and j0 are multiples of 64 and of MY)
   uint8_t* const my_flags = a.untrav_flags + ((size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * a.flag_nfy) * a.flag_ntx + (i0 >> 6);
   {

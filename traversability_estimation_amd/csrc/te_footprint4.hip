@@ -65,9 +65,7 @@ struct F4Args {
   double r2, ax, ay, res;
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
   unsigned* blocked_count;  // ... [0] how many entries are reserved, [1] how many hold a cell (k_fp_mask resets both: it runs
-                            // before this kernel in every footprint pass), [2] the page size (= chunk) of this pass
-  unsigned* page_count;     // entries of page p that k_fp_blocked looks at (k_fp_slide5 fills pages partly; here every page counts
-                            // in full and unused entries hold kF4NoCell)
+                            // before this kernel in every footprint pass), [3] see k_fp_blocked
   int chunk;                // entries a block reserves at a time: kF4Chunk, less for strips shorter than four rows
   size_t list_cap;          // entries the list holds (host side: launch_f4 refuses a grid whose unfinished chunks might not fit)
 };
@@ -101,10 +99,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
   if (js >= a.j_hi) return;
   const int jend = js + a.strip_rows < a.j_hi ? js + a.strip_rows : a.j_hi;
   const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
-  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
-    a.blocked_count[2] = (unsigned)a.chunk;  // the page size of this pass, for k_fp_blocked
-    a.blocked_count[3] = 0u;                 // ... and the first spiral entry that can be untraversable: any (k_fp_slide5: beyond its inner disc)
-  }
+  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.blocked_count[3] = 0u;  // for k_fp_blocked: any spiral entry can be untraversable (k_fp_slide5: beyond its inner disc)
 
   unsigned vb[NC];
 #pragma unroll
@@ -283,10 +278,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
           if (n > chunk_left) {
             const int old_left = chunk_left;
             unsigned base = 0;
-            if (lane == 0) {
-              base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
-              a.page_count[base / (unsigned)a.chunk] = (unsigned)a.chunk;
-            }
+            if (lane == 0) base = atomicAdd(a.blocked_count, (unsigned)a.chunk);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (rank >= old_left) at = base + (unsigned)(rank - old_left);
             chunk_at = base - (unsigned)old_left;  // (+ n below: the entries of this row that went into the new chunk)
@@ -444,9 +436,9 @@ constexpr int kFBTab = 4;    // chunks of 64 spiral entries a lane keeps in regi
 #define TE_FB_TRIP 8
 #endif
 constexpr int kFBTrip = TE_FB_TRIP;   // entries per trip of the per-lane walks, their loads issued together
-constexpr int kFBDense = 32;  // cells per wavefront of the launch from which every lane walks a disc of its own (round 5: 8 -> 32.  The
-                              // lists are now made of discs walked to their rim, a few per row: neighbouring lanes' loads no longer
-                              // coalesce, and the per-wavefront walk wins up to some 500 boxes on the bench map)
+constexpr int kFBDense = 16;  // cells per wavefront of the launch from which every lane walks a disc of its own (round 4: 8; the lists are
+                              // now made of discs walked to their rim -- bench map, 30 / 300 / 1000 / 3000 boxes: per wavefront 0.462 / 0.588 /
+                              // 0.843 / 1.449 ms per launch, per lane -- / 0.577 / 0.748 / 1.147, profiles/r05_experiments.json)
 static_assert(kMaxSpiral % kFBTrip == 0, "k_fp_blocked reads whole trips of the table");
 
 struct FBArgs {
@@ -455,7 +447,6 @@ struct FBArgs {
   float* footprint;
   const unsigned* list;
   const unsigned* count;
-  const unsigned* page_count;
   const unsigned* ptab;  // packed spiral entries: di | dj << 8 | ring << 16 | tie << 24 (kMaxSpiral words)
   int n_spiral, rows, cols, reach;
   unsigned map_cells;
@@ -484,16 +475,12 @@ __device__ __forceinline__ bool fb_on_circle_inside(const FBArgs& a, int i, int 
 //     inner radius, for the sum of the cells before it in the iterator's order.  About 25 instructions per disc; the
 //     wave-wide walk needs 250, and 3 million discs (3000 boxes) took it 1.5 ms.
 __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
-  const unsigned n = a.count[0], n_cells = a.count[1];  // entries reserved (most of a reservation can be unused) / cells
+  const unsigned n = a.count[0], n_cells = a.count[1];  // entries (some hold kF4NoCell: the unused tail of a block's last chunk) / cells
   if (n == 0) return;
   const int lane = threadIdx.x;
   const unsigned nwaves = gridDim.x;
-  // the list comes in pages of count[2] entries (a power of two: 64, 128 or 256), of which the first page_count[p] count
-  const unsigned page_shift = (unsigned)(31 - __builtin_clz(a.count[2] | 1u));
-  // (sized by the cells, not by the entries reserved: the cells sit at the front of their reservations, and a group that
-  // spans a whole run of them would hand one wavefront 64 discs to walk while its neighbours find empty pages)
   unsigned group = 1;
-  while (group < (unsigned)kLanes && group * nwaves < n_cells) group *= 2;
+  while (group < (unsigned)kLanes && group * nwaves < n) group *= 2;
   const bool per_lane = a.path ? a.path == 2 : n_cells >= (unsigned)kFBDense * nwaves;
   // my entries of the table, and their offsets from the top left corner of the disc's bounding square
   unsigned tw[kFBTab];
@@ -695,38 +682,10 @@ __global__ __launch_bounds__(kLanes) void k_fp_blocked(FBArgs a) {
     }
     if (mycell != kF4NoCell) a.footprint[mycell] = myout;
   };
-  if (per_lane) {
-    // Long list: the pages are dealt out round-robin (page p to wavefront p mod nwaves: the cells sit at the front of
-    // their blocks' reservations, neighbouring pages hold similar amounts of work) and a wavefront fetches the counts of
-    // its next 64 pages with ONE load -- most of a reservation is empty, and an entry-by-entry loop paid a dependent load
-    // per 64 entries to find that out (300 boxes: 170 -> 290 us with k_fp_slide5's one reservation per block).
-    const unsigned npages = (n + (1u << page_shift) - 1u) >> page_shift;
-    for (unsigned pb = blockIdx.x; pb < npages; pb += nwaves * (unsigned)kLanes) {
-      const unsigned my_page = pb + (unsigned)lane * nwaves;
-      const unsigned cnt = my_page < npages ? a.page_count[my_page] : 0u;
-      unsigned long long pm = __ballot(cnt != 0u);
-      while (pm != 0ull) {
-        const int l = __builtin_ctzll(pm);
-        pm &= pm - 1ull;
-        const unsigned page = (unsigned)__builtin_amdgcn_readlane((int)my_page, l), c = (unsigned)__builtin_amdgcn_readlane((int)cnt, l);
-        for (unsigned g0 = 0; g0 < c; g0 += (unsigned)kLanes)
-          take(g0 + (unsigned)lane < c ? a.list[(page << page_shift) + g0 + (unsigned)lane] : kF4NoCell);
-      }
-    }
-    return;
-  }
-  // Short list: `group` consecutive entries per trip, as few as keep every wavefront busy
-  for (unsigned c0 = blockIdx.x * group; c0 < n; c0 += nwaves * group) {
-    unsigned mycell = kF4NoCell;
-    {
-      const unsigned e = c0 + (unsigned)lane;
-      if ((unsigned)lane < group && e < n) {
-        const unsigned pg = e >> page_shift;
-        if (e - (pg << page_shift) < a.page_count[pg]) mycell = a.list[e];
-      }
-    }
-    take(mycell);
-  }
+  // `group` consecutive entries per trip, as few as keep every wavefront busy (the list is dense: k_fp_slide5 copies a
+  // block's cells into it when its strip is done, k_fp_slide4 fills it chunk by chunk)
+  for (unsigned c0 = blockIdx.x * group; c0 < n; c0 += nwaves * group)
+    take((unsigned)lane < group && c0 + (unsigned)lane < n ? a.list[c0 + (unsigned)lane] : kF4NoCell);
 }
 
 }  // namespace
@@ -750,7 +709,6 @@ void footprint_blocked4(const Geo& g, const FootprintParams& p, const Layers& L,
   a.footprint = L.footprint;
   a.list = L.fp_blocked;
   a.count = L.fp_blocked_count;
-  a.page_count = L.fp_page_count;
   a.ptab = reinterpret_cast<const unsigned*>(spiral_table + 4 * kMaxSpiral);
   a.n_spiral = p.n_spiral;
   a.rows = g.rows;
@@ -825,7 +783,6 @@ bool footprint_slide4(const Geo& g, const FootprintParams& p, const Layers& L, c
   a.inv_scale = ldexp(1.0, -k);
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
-  a.page_count = L.fp_page_count;
   a.list_cap = L.fp_blocked_cap;
   const bool launched = f4_launch_part0(shape, &a, g.batch, s);
   if (launched && finish) footprint_blocked4(g, p, L, spiral_table, s);

@@ -45,9 +45,9 @@ struct F5Args {
   float def, scale;    // cell = (unsigned)(T' * scale + 0.5) | U << 27, scale = 2^k
   double inv_scale;    // 2^-k
   unsigned* blocked_list;   // cells (index into the layer, all maps) whose disc holds an untraversable cell ...
-  unsigned* blocked_count;  // ... [0] entries reserved, [1] entries that hold a cell (k_fp_mask resets both), [2] the page size (= chunk)
-  unsigned* page_count;     // entries of page p (chunk entries each) that hold a cell: k_fp_blocked looks at no others
-  int chunk;                // the page size: a block reserves whole pages
+  unsigned* blocked_count;  // ... [0] entries of the list, [1] entries that hold a cell, [4] entries of the scratch reserved (k_fp_mask resets them)
+  unsigned* scratch;        // where a block collects its cells until its strip is done (Layers::fp_scratch)
+  int chunk;                // granule of the scratch reservations
   size_t list_cap;          // (host side: the launcher refuses a grid whose unfinished chunks might not fit)
   // one byte per 64 x 4 cells, written by k_fp_mask: "holds an untraversable cell" (Layers::untrav_flags).  A strip whose
   // flags are all clear -- on terrain without obstacles every strip -- does not fetch its mask bytes: the byte loads stay
@@ -94,10 +94,13 @@ struct SlideK {
   int icol, kx, nt_mid;
   bool own, rmin_zero;
   float rnt;
-  // the list: ONE reservation per block, made when the block first lists a cell -- room for every cell the rest of its
-  // strip could list, in whole pages.  (Rounds 3-4 reserved a chunk of 256 entries at a time: a strip that runs along a
+  // the list: a block collects its cells in a SCRATCH reservation made when it first lists one -- room for every cell the
+  // rest of its strip could list -- and copies them into the list proper when the strip is done, where it then reserves
+  // exactly what it needs (rounded up to a wavefront's 64 entries, the rest kF4NoCell): two atomics per listing block, and
+  // a dense list for k_fp_blocked.  (Rounds 3-4 reserved list chunks of 256 entries as they went: a strip that runs along a
   // kerb paid an atomic round trip every four to six rows, 20 us of a 50 us kernel with three boxes on the map; larger
-  // chunks were no way out while k_fp_blocked had to step over their unused entries.  It now reads the page counts.)
+  // chunks left k_fp_blocked more unused entries to step over, and handing it the sparse reservations themselves --
+  // round 5's first attempt, with page counts -- unbalanced its wavefronts: 300 boxes 170 -> 290 us.)
   unsigned res_base;
   int res_len, listed_total;
 
@@ -292,11 +295,11 @@ struct SlideK {
             const int rows_left = nout - (j - js);
             const unsigned want = ((unsigned)(rows_left * kLanes) + (unsigned)a.chunk - 1u) / (unsigned)a.chunk * (unsigned)a.chunk;
             unsigned base = 0;
-            if (L.lane == 0) base = atomicAdd(a.blocked_count, want);
+            if (L.lane == 0) base = atomicAdd(a.blocked_count + 4, want);
             res_base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             res_len = (int)want;
           }
-          if (listed) a.blocked_list[res_base + (unsigned)(listed_total + rank)] = (unsigned)(mo + (size_t)j * a.rows + icol);
+          if (listed) a.scratch[res_base + (unsigned)(listed_total + rank)] = (unsigned)(mo + (size_t)j * a.rows + icol);
           listed_total += n;
         }
         if (!walk) bstore_f(rs_out, L.o_main0, so, out);
@@ -307,15 +310,19 @@ struct SlideK {
     bstore_f(rs_out, L.o_main0, so, out);
   }
   __device__ __forceinline__ void finish() {
-    if (res_len == 0) return;  // (uniform)
-    // the page counts of my reservation: full pages, one partly filled, empty ones behind it
-    const int pages = res_len / a.chunk;
-    const unsigned p0 = res_base / (unsigned)a.chunk;  // (every reservation is a whole number of pages: so is every base)
-    for (int p = L.lane; p < pages; p += kLanes) {
-      const int c = listed_total - p * a.chunk;
-      a.page_count[p0 + (unsigned)p] = (unsigned)(c < 0 ? 0 : (c > a.chunk ? a.chunk : c));
+    if (listed_total == 0) return;  // (uniform)
+    // my cells from the scratch into the list, padded to whole wavefronts (the stores above were this wave's own: a
+    // workgroup-scope fence orders them before the loads below; the CU's L1 is coherent for its own waves)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const unsigned want = ((unsigned)listed_total + (unsigned)kLanes - 1u) & ~((unsigned)kLanes - 1u);
+    unsigned base = 0;
+    if (L.lane == 0) {
+      base = atomicAdd(a.blocked_count, want);
+      atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
     }
-    if (L.lane == 0) atomicAdd(a.blocked_count + 1, (unsigned)listed_total);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    for (unsigned q = (unsigned)L.lane; q < want; q += (unsigned)kLanes)
+      a.blocked_list[base + q] = q < (unsigned)listed_total ? a.scratch[res_base + q] : kF4NoCell;
   }
 };
 
@@ -334,10 +341,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF5Waves
   SlideK<Q> k(a);
   // the last block of a row of blocks is shifted left: the columns it shares with its neighbour are the neighbour's
   // (one list entry per cell; both store the same value)
-  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) {
-    a.blocked_count[2] = (unsigned)a.chunk;    // the page size of this pass, for k_fp_blocked
-    a.blocked_count[3] = (unsigned)a.k_start;  // ... and the first spiral entry that can be the first untraversable cell of a listed disc
-  }
+  if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) a.blocked_count[3] = (unsigned)a.k_start;  // for k_fp_blocked: the first spiral entry that can be untraversable in a listed disc
   k.init(lane, i0, bx * kLanes, js, jend, mo, lds);
   march5<Q>(k, js, jend);
   k.finish();
@@ -430,7 +434,7 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   const int shape = d.Q, R = d.R;
   if (shape < 1 || R < 1 || 2 * R + 1 > 31 || p.reach != R || g.rows < kLanes || g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;  // 32-bit list entries and byte offsets within a pass
-  if (!L.fp_blocked || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch > (double)L.fp_blocked_cap) return false;
+  if (!L.fp_blocked || !L.fp_scratch || !L.fp_blocked_count || (double)g.rows * (double)g.cols * (double)g.batch > (double)L.fp_blocked_cap) return false;
   // the fixed-point scale: the T-sum of a whole disc (npoints cells of at most cap * 2^k + 1/2 each) must stay below
   // 2^27 -- the untraversable flag's bit -- and the default value that replaces NaN has to fit as well
   if (!(tcap >= 0.0) || !(p.def >= 0.0)) return false;
@@ -489,7 +493,7 @@ bool footprint_slide5(const Geo& g, const FootprintParams& p, const Layers& L, c
   }
   a.blocked_list = L.fp_blocked;
   a.blocked_count = L.fp_blocked_count;
-  a.page_count = L.fp_page_count;
+  a.scratch = L.fp_scratch;
   a.chunk = kF4Chunk;
   a.list_cap = L.fp_blocked_cap;
   a.untrav_flags = L.untrav_flags;

@@ -121,8 +121,10 @@ struct Layers {
   uint8_t* untrav;     // !isTraversableForFilters per cell
   float* tie_scratch;          // one float per cell: the step filter at a tie radius (te_fast_step.hip); nullptr: not allocated
   unsigned* fp_blocked;        // k_fp_slide4's list of cells whose disc holds an untraversable cell (one entry per cell at most) ...
-  unsigned* fp_blocked_count;  // ... [0] entries reserved, [1] cells listed (k_fp_mask resets both), [2] entries per page (the sum kernel's chunk)
-  unsigned* fp_page_count;     // the list in pages of [2] entries: how many entries of page p hold a cell (the rest of a reservation is unused)
+  unsigned* fp_blocked_count;  // ... [0] entries of the list (some hold kF4NoCell), [1] cells listed, [3] first spiral entry that can be untraversable
+                               // in a listed disc, [4] entries of the scratch reserved (k_fp_mask resets [0], [1], [4])
+  unsigned* fp_scratch;        // k_fp_slide5 collects a block's cells here (one reservation per block, sized for its whole strip) and copies
+                               // them to the list when the strip is done: the list stays dense whatever the reservations
   size_t fp_blocked_cap;       // entries the list holds (cells + fast::f4_list_slack)
   int* block_flags;    // one flag per block of the shape-specialised normals kernel ("needs the fix-up pass")
   uint8_t* untrav_flags;  // one byte per 64 x 4 cells: "holds an untraversable cell" as of the mask kernel's last pass over them (1 until then);

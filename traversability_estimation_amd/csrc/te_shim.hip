@@ -856,8 +856,8 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     const size_t guard = ((size_t)kSlabGuardRows * (size_t)rows * sizeof(float) + 255) & ~(size_t)255;
     // (+ one byte per 64 x 4 cells: "holds an untraversable cell", written by the mask kernel, 1 = unknown until then)
     const size_t ufb = (untrav_flag_bytes(rows, cols, batch) + 255) & ~(size_t)255;
-    // (+ the list's page counts: one word per 64 entries at most -- the smallest chunk a sum kernel reserves)
-    const size_t pcb = ((list_cap / 64 + 2) * sizeof(unsigned) + 255) & ~(size_t)255;
+    // (+ the sum kernel's scratch: a second array of the list's size, see Layers::fp_scratch)
+    const size_t pcb = qb;
     const size_t total = guard + 13 * lb + ub + fb + qb + 256 + ufb + pcb + guard;
     hipError_t e = hipMalloc(&slab, total);
     if (e != hipSuccess) return fail(TE_ERR_HIP, "te_set_geometry: hipMalloc(%zu bytes): %s", total, hipGetErrorString(e));
@@ -872,12 +872,11 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
     c->L.fp_blocked_count = (unsigned*)(b + 13 * lb + ub + fb + qb);
     c->L.fp_blocked_cap = list_cap;
     c->L.untrav_flags = (uint8_t*)(b + 13 * lb + ub + fb + qb + 256);
-    c->L.fp_page_count = (unsigned*)(b + 13 * lb + ub + fb + qb + 256 + ufb);
+    c->L.fp_scratch = list_cap < ((size_t)1 << 32) ? (unsigned*)(b + 13 * lb + ub + fb + qb + 256 + ufb) : nullptr;
     c->layer_elems = elems;
     // outputs read as NaN until computed, like GridMap::add()
     HIP_TRY(hipMemsetAsync(slab, 0xFF, guard + 13 * lb + ub + fb, c->stream));
     HIP_TRY(hipMemsetAsync(b + 13 * lb + ub + fb + qb + 256 + ufb + pcb, 0xFF, guard, c->stream));
-    HIP_TRY(hipMemsetAsync(c->L.fp_page_count, 0, pcb, c->stream));
     HIP_TRY(hipMemsetAsync(c->L.untrav_flags, 0x01, ufb, c->stream));
     // the mask layer holds 0 / 1 only (k_fp_slide5 packs the byte as it is): "untraversable" until the mask kernel has
     // looked at the cell, as a byte of 0xFF would also say -- but 1 stays inside the packed word's flag bit
