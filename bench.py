@@ -347,24 +347,41 @@ def main():
                 ctx.run_chain(capi.RUN_KEEP_NORMALS)
                 nrm = [ctx.download(k) for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z")]
                 best = None
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    ctx.upload_layer("surface_normal_z", nrm[2])
-                    ctx.run_filter("slope")
-                    o1 = ctx.download("traversability_slope")
-                    ctx.upload_elevation(stack)
-                    ctx.run_filter("step")
-                    o2 = ctx.download("traversability_step")
-                    ctx.upload_layer("surface_normal_x", nrm[0])
-                    ctx.upload_layer("surface_normal_y", nrm[1])
-                    ctx.run_filter("roughness")
-                    o3 = ctx.download("traversability_roughness")
-                    ctx.sync()
-                    d = time.perf_counter() - t0
-                    best = d if best is None or d < best else best
-                host_path["three_plugins_ms"] = best * 1e3
+                for prefetch in (False, True):
+                    best = None
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        # SlopeFilter::update (plugins/src/SlopeFilter.cpp)
+                        ctx.upload_layer("surface_normal_z", nrm[2])
+                        if prefetch:
+                            ctx.prefetch_layers({"elevation": stack})
+                        ctx.run_filter("slope")
+                        o1 = ctx.download("traversability_slope")
+                        if prefetch:
+                            ctx.wait_prefetch()
+                        # StepFilter::update
+                        if not prefetch:
+                            ctx.upload_elevation(stack)
+                        else:
+                            ctx.prefetch_layers({"surface_normal_x": nrm[0], "surface_normal_y": nrm[1]})
+                        ctx.run_filter("step")
+                        o2 = ctx.download("traversability_step")
+                        if prefetch:
+                            ctx.wait_prefetch()
+                        # RoughnessFilter::update
+                        if not prefetch:
+                            ctx.upload_layer("surface_normal_x", nrm[0])
+                            ctx.upload_layer("surface_normal_y", nrm[1])
+                        ctx.run_filter("roughness")
+                        o3 = ctx.download("traversability_roughness")
+                        ctx.sync()
+                        d = time.perf_counter() - t0
+                        best = d if best is None or d < best else best
+                    host_path["three_plugins_ms" if prefetch else "three_plugins_no_prefetch_ms"] = best * 1e3
                 host_path["three_plugins_what"] = ("te_run_filter(slope / step / roughness) with host layers in and out, 4 uploads "
-                                                   "(elevation and surface_normal_z once), 3 downloads, pageable buffers, best of 3")
+                                                   "(elevation and surface_normal_z once), 3 downloads, pageable buffers, best of 3; the "
+                                                   "uploads of the NEXT plugin's inputs start beside each plugin's kernel and download "
+                                                   "(te_prefetch_layers, as plugins/src/DeviceMap.cpp does); _no_prefetch_: one transfer at a time")
                 del nrm, o1, o2, o3
             except (capi.TeError, KeyError, TypeError, ValueError) as e:
                 host_path["three_plugins_error"] = str(e)

@@ -204,3 +204,60 @@ def test_region_footprint_with_a_shape_only_the_general_kernel_takes(capi, oracl
     want = oracle.chain(g, op, maps[1])
     want["traversability_footprint"] = oracle.footprint(g, op, maps[1], want)
     assert_layers_match(got, want, layers=OUT_LAYERS + ("traversability_footprint",), ctx="region run, general footprint kernel")
+
+
+def test_prefetched_layers_equal_uploaded_layers(capi, oracle):
+    """te_prefetch_layers: the reference's three plugins in the unchanged-YAML order with the next plugin's inputs sent
+    beside each plugin's filter and download -- same layers as with one upload at a time, and as the oracle's."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 1536, 1200, 0.05  # (layers above the 4 MiB below which transfers are not staged)
+    elev = synth.perlin_elevation(rows, cols, seed=77, amplitude=0.6)
+    r = synth.benchmark_radius(4, res)
+    op = oracle.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r)
+    g = oracle.geom(rows, cols, res)
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    try:
+        want = oracle.chain(g, op, elev, want_normals=True)
+    finally:
+        oracle.set_threads(1)
+    nrm = {k: want[k] for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z")}
+    outs = {}
+    for prefetch in (False, True):
+        with capi.Context(0) as ctx:
+            ctx.set_params(to_te_params(capi, op))
+            ctx.set_geometry(rows, cols, 1, res)
+            ctx.upload_layer("surface_normal_z", nrm["surface_normal_z"])
+            if prefetch:
+                ctx.prefetch_layers({"elevation": elev})
+            ctx.run_filter("slope")
+            a = ctx.download("traversability_slope")
+            if prefetch:
+                ctx.wait_prefetch()
+                ctx.prefetch_layers({"surface_normal_x": nrm["surface_normal_x"], "surface_normal_y": nrm["surface_normal_y"]})
+            else:
+                ctx.upload_elevation(elev)
+            ctx.run_filter("step")
+            b = ctx.download("traversability_step")
+            if prefetch:
+                ctx.wait_prefetch()
+            else:
+                ctx.upload_layer("surface_normal_x", nrm["surface_normal_x"])
+                ctx.upload_layer("surface_normal_y", nrm["surface_normal_y"])
+            ctx.run_filter("roughness")
+            c = ctx.download("traversability_roughness")
+            ctx.sync()
+            outs[prefetch] = {"traversability_slope": a, "traversability_step": b, "traversability_roughness": c}
+    for k in outs[True]:
+        assert np.array_equal(outs[True][k], outs[False][k], equal_nan=True), k
+    assert_layers_match(outs[True], want, layers=("traversability_slope", "traversability_step", "traversability_roughness"),
+                        ctx="three plugins with prefetched inputs")
+    # a prefetch that nobody waits for is finished by the next call that needs the context to itself
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.prefetch_layers({"elevation": elev})
+        ctx.run_chain(0)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+        ctx.wait_prefetch()
+    assert_layers_match(got, want, ctx="chain after an unawaited prefetch")

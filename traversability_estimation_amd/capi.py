@@ -32,7 +32,7 @@ OPT_FP_BLOCKED_WALK, OPT_FP_BLOCKED_BLOCKS_PER_CU, OPT_POLYGON_PER_CELL = 1, 2, 
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",
            "te_set_params", "te_get_params", "te_set_option", "te_set_geometry", "te_upload_elevation", "te_upload_tile", "te_download_tile",
            "te_upload_tile_async", "te_download_tile_async",
-           "te_device_ptr", "te_set_layer_present", "te_upload_layer", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
+           "te_device_ptr", "te_set_layer_present", "te_upload_layer", "te_prefetch_layers", "te_wait_prefetch", "te_upload_layer_circular", "te_download_layer_circular", "te_run_filter", "te_run_chain", "te_run_chain_region", "te_run_footprint", "te_check_footprint_paths",
            "te_sync",
            "te_download_layer", "te_time_chain", "te_time_chain_samples", "te_last_error", "te_version",
            "te_msg_parse", "te_msg_layer", "te_msg_write", "te_upload_msg", "te_download_msg", "te_bag_find_message",
@@ -137,6 +137,8 @@ def load():
         L.te_set_layer_present.argtypes = [vp, C.c_int, C.c_int]
         L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_upload_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+        L.te_prefetch_layers.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(fp)]
+        L.te_wait_prefetch.argtypes = [vp]
         L.te_download_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         L.te_run_filter.argtypes = [vp, C.c_int, C.c_uint]
         L.te_run_chain.argtypes = [vp, C.c_uint]
@@ -397,6 +399,24 @@ class Context:
         assert a.size % per == 0, (a.size, per)
         _check(load().te_upload_layer(self._h, LAYERS[layer] if isinstance(layer, str) else int(layer),
                                       a.ctypes.data_as(C.POINTER(C.c_float)), int(map0), a.size // per))
+
+    def prefetch_layers(self, layers):
+        """{layer: array}: whole-layer uploads that run beside the calls that follow, until wait_prefetch() (te_prefetch_layers).
+        The arrays are kept alive by this object until then."""
+        names = list(layers)
+        arrs = [np.ascontiguousarray(layers[k], dtype=np.float32).reshape(-1) for k in names]
+        for a in arrs:
+            assert a.size == self.rows * self.cols * self.batch, (a.size, self.rows, self.cols, self.batch)
+        ids = (C.c_int * len(names))(*[LAYERS[k] if isinstance(k, str) else int(k) for k in names])
+        ptrs = (C.POINTER(C.c_float) * len(names))(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
+        self._prefetch_keep = arrs
+        _check(load().te_prefetch_layers(self._h, len(names), ids, ptrs))
+
+    def wait_prefetch(self):
+        try:
+            _check(load().te_wait_prefetch(self._h))
+        finally:
+            self._prefetch_keep = None
 
     def upload_layer_circular(self, layer, data, start_index, map_index=0):
         """Upload ONE map's layer given in GridMap buffer order (start_index = GridMap::getStartIndex())."""

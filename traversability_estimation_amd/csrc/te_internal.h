@@ -209,6 +209,7 @@ struct HostStager {
   hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_order = nullptr;
   hipStream_t stream = nullptr;
+  int pool = 0;  // which of the process' copy-thread pools serves this ring (te_stage.hip)
   ~HostStager();
   void release();      // (with the context's device current)
   hipError_t ensure();

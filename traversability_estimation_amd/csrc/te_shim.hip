@@ -8,7 +8,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <dlfcn.h>
+#include <functional>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -187,7 +189,46 @@ struct te_ctx {
   int in_next = 0, out_next = 0;
   bool tiles_pending = false;  // te_sync has copy streams to wait for
   HostStager stager;           // whole-layer transfers through pageable host buffers (te_stage.hip)
+  // te_prefetch_layers: whole-layer uploads on a thread of their own, through a second staging ring and the second copy
+  // pool, beside whatever the caller does meanwhile (a filter on other layers, the download of its output)
+  HostStager prefetcher;
+  hipStream_t prefetch_order = nullptr;  // stands in for the compute stream of HostStager::upload
+  // (one worker per context, started by the first prefetch and kept: a new thread's first HIP call pays the runtime's
+  // per-thread set-up, milliseconds that a 3 ms transfer cannot afford)
+  std::thread prefetch_thread;
+  std::mutex pf_mu;
+  std::condition_variable pf_cv;
+  std::function<void()> pf_job;
+  bool pf_quit = false;
+  bool prefetch_running = false, prefetch_elev = false;  // (prefetch_running: a job is queued or being worked on; under pf_mu)
+  std::atomic<int> prefetch_rc{TE_OK};
 };
+
+namespace {
+// joins a running prefetch (caller holds c->mu); its result stays in c->prefetch_rc until te_wait_prefetch reports it
+void finish_prefetch_locked(te_ctx* c) {
+  {
+    std::unique_lock<std::mutex> pl(c->pf_mu);
+    if (!c->prefetch_running && !c->prefetch_elev) return;
+    c->pf_cv.wait(pl, [c] { return !c->prefetch_running; });
+  }
+  if (c->prefetch_elev && c->prefetch_rc.load() == TE_OK) {
+    c->have_elev = true;
+    c->invalid_cells = -1;  // (not counted: the dense-hole march serves, like after tile uploads)
+    c->chain_done = false;
+    c->footprint_done = false;
+  }
+  c->prefetch_elev = false;
+}
+// Every entry point takes the context's mutex through this: a prefetch that is still running is finished first -- except
+// in the calls that are meant to run beside one (te_run_filter, te_download_layer*, the parameter calls).
+struct CtxLock {
+  std::lock_guard<std::mutex> lk;
+  explicit CtxLock(te_ctx* c, bool beside_prefetch = false) : lk(c->mu) {
+    if (!beside_prefetch) finish_prefetch_locked(c);
+  }
+};
+}  // namespace
 
 namespace {
 
@@ -744,11 +785,21 @@ int te_create(int device, te_ctx** out) {
 int te_destroy(te_ctx* c) {
   if (!c) return TE_OK;
   {
-    std::lock_guard<std::mutex> lk(c->mu);
+    CtxLock lk(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->prefetch_thread.joinable()) {
+      {
+        std::lock_guard<std::mutex> pl(c->pf_mu);
+        c->pf_quit = true;
+      }
+      c->pf_cv.notify_all();
+      c->prefetch_thread.join();
+    }
     free_layers(c);
     c->stager.release();
+    c->prefetcher.release();
+    if (c->prefetch_order) (void)hipStreamDestroy(c->prefetch_order);
     if (c->d_spiral) (void)hipFree(c->d_spiral);
     if (c->d_count) (void)hipFree(c->d_count);
     if (c->hole_queue) (void)hipFree(c->hole_queue);
@@ -780,7 +831,7 @@ int te_set_params(te_ctx* c, const te_params* p) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_params: NULL ctx");
   int rc = te_params_validate(p);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c, /*beside_prefetch*/ true);
   te_params old = c->params;
   c->params = *p;
   c->have_params = true;
@@ -799,7 +850,7 @@ int te_set_params(te_ctx* c, const te_params* p) {
 
 int te_set_option(te_ctx* c, int option, int value) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_option: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   switch (option) {
     case TE_OPT_FP_BLOCKED_WALK:
       if (value < 0 || value > 2) return fail(TE_ERR_INVALID_ARG, "te_set_option: TE_OPT_FP_BLOCKED_WALK takes 0 (by list length), 1 (per wavefront), 2 (per lane)");
@@ -821,7 +872,7 @@ int te_set_option(te_ctx* c, int option, int value) {
 
 int te_get_params(te_ctx* c, te_params* p) {
   if (!c || !p) return fail(TE_ERR_INVALID_ARG, "te_get_params: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c, /*beside_prefetch*/ true);
   *p = c->params;
   return TE_OK;
 }
@@ -830,7 +881,7 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_geometry: NULL ctx");
   if (rows <= 0 || cols <= 0 || batch <= 0 || !(res > 0.0) || !isfinite(res) || !isfinite(pos_x) || !isfinite(pos_y))
     return fail(TE_ERR_INVALID_ARG, "te_set_geometry: rows=%d cols=%d batch=%d res=%g", rows, cols, batch, res);
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const size_t elems = (size_t)rows * cols * batch;
@@ -903,7 +954,7 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
 
 int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_elevation: geometry not set");
   if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
     return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
@@ -920,7 +971,7 @@ int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
 
 int te_upload_tile(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
   if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_tile: geometry not set");
   if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
       col0 + w > c->geo.cols)
@@ -974,7 +1025,7 @@ int tile_streams(te_ctx* c) {
 
 int te_download_tile(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
   if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (const int rc = check_tile(c, "te_download_tile", map, row0, col0, h, w)) return rc;
   const float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile: bad layer %d", layer);
@@ -988,7 +1039,7 @@ int te_download_tile(te_ctx* c, int layer, int map, int row0, int col0, int h, i
 
 int te_upload_tile_async(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
   if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile_async: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (const int rc = check_tile(c, "te_upload_tile_async", map, row0, col0, h, w)) return rc;
   HIP_TRY(hipSetDevice(c->device));
   if (const int rc = tile_streams(c)) return rc;
@@ -1014,7 +1065,7 @@ int te_upload_tile_async(te_ctx* c, const float* host_tile, int map, int row0, i
 
 int te_download_tile_async(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
   if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (const int rc = check_tile(c, "te_download_tile_async", map, row0, col0, h, w)) return rc;
   const float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: bad layer %d", layer);
@@ -1040,7 +1091,7 @@ int te_download_tile_async(te_ctx* c, int layer, int map, int row0, int col0, in
 
 int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
   if (!c || !dptr) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_device_ptr: geometry not set");
   if (const int rc = ensure_input_layer(c, layer)) return rc;
   // (robot_slope: handing out the pointer does not make the layer present -- the buffer is all NaN until the caller
@@ -1061,7 +1112,7 @@ int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
 
 int te_set_layer_present(te_ctx* c, int layer, int present) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (layer != TE_LAYER_ROBOT_SLOPE) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: only the optional input layer robot_slope can be declared present / absent");
   if (present && !c->robot_slope) return fail(TE_ERR_NOT_READY, "te_set_layer_present: robot_slope was never uploaded nor handed out (te_device_ptr)");
   c->have_robot_slope = present != 0;
@@ -1071,7 +1122,7 @@ int te_set_layer_present(te_ctx* c, int layer, int present) {
 int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: NULL");
   if (layer == TE_LAYER_ELEVATION) return te_upload_elevation(c, host, map0, nmaps);
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer: geometry not set");
   if (const int rc = ensure_input_layer(c, layer)) return rc;
   float* p = layer_ptr(c, layer);
@@ -1126,7 +1177,7 @@ int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, i
 static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col,
                                          int expect_rows, int expect_cols) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer_circular: geometry not set");
   if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
     return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
@@ -1157,7 +1208,7 @@ int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int s
 static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
                                            int expect_rows, int expect_cols) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c, /*beside_prefetch*/ true);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer_circular: geometry not set");
   if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
     return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
@@ -1223,7 +1274,7 @@ int te_upload_msg(te_ctx* c, const void* m, size_t len, const char* layer_name, 
   const te_msg_info& mi = v.info;
   bool same;
   {
-    std::lock_guard<std::mutex> lk(c->mu);
+    CtxLock lk(c);
     same = c->have_geo && c->geo.rows == mi.rows && c->geo.cols == mi.cols && c->geo.batch == 1 && c->geo.res == mi.resolution &&
            c->geo.pos_x == mi.pose[0] && c->geo.pos_y == mi.pose[1];
   }
@@ -1242,7 +1293,7 @@ int te_download_msg(te_ctx* c, const te_msg_info* info, int n_layers, const int*
   if (!c || !info || !written || (n_layers > 0 && (!layers || !names))) return fail(TE_ERR_INVALID_ARG, "te_download_msg: NULL");
   te_msg_info mi = *info;
   {
-    std::lock_guard<std::mutex> lk(c->mu);
+    CtxLock lk(c);
     if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_msg: geometry not set");
     mi.rows = c->geo.rows;
     mi.cols = c->geo.cols;
@@ -1283,7 +1334,7 @@ int te_bag_write(const void* m, size_t msg_len, const char* topic, uint32_t stam
 
 int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_filter: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c, /*beside_prefetch*/ true);
   if (!c->have_geo || !c->have_params) return fail(TE_ERR_NOT_READY, "te_run_filter: set params and geometry first");
   if (!c->tables_ready) {
     int rc = rebuild_tables(c);
@@ -1312,14 +1363,14 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
 
 int te_run_chain(te_ctx* c, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain: geometry not set");
   return run_whole_locked(c, flags);
 }
 
 int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, int h, int w) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain_region: geometry not set");
   if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
       col0 + w > c->geo.cols)
@@ -1357,7 +1408,7 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
 
 int te_run_footprint(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_footprint: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   return run_footprint_locked(c, TE_RUN_FOOTPRINT_MEMO);
 }
 
@@ -1365,7 +1416,7 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
                              unsigned char* is_safe, double* traversability, int* status) {
   if (!c || n_paths < 0 || (n_paths > 0 && (!pose_offset || !pose_xy || !is_safe || !traversability || !status)))
     return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: NULL argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: run the chain with the footprint pass first");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: map %d of %d", map, c->geo.batch);
@@ -1406,7 +1457,7 @@ int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_of
 
 int te_set_check_robot_inclination(te_ctx* c, int enabled) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_check_robot_inclination: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   c->check_inclination = enabled != 0;
   return TE_OK;
 }
@@ -1441,7 +1492,7 @@ int check_inclination_locked(te_ctx* c, int map, int n, const double* start_end_
 int te_check_inclination(te_ctx* c, int map, int n_segments, const double* start_end_xy, unsigned char* ok, int* status) {
   if (!c || n_segments < 0 || (n_segments > 0 && (!start_end_xy || !ok || !status)))
     return fail(TE_ERR_INVALID_ARG, "te_check_inclination: NULL argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   return check_inclination_locked(c, map, n_segments, start_end_xy, ok, status, "te_check_inclination");
 }
 
@@ -1452,7 +1503,7 @@ int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, d
   if (!isfinite(yaw)) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: yaw is not finite");
   for (int k = 0; k < 2 * n_points; ++k)
     if (!isfinite(points_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: footprint point %d is not finite", k / 2);
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_run_polygon_footprint: run the chain with the footprint pass first (it marks the untraversable cells)");
   if (c->geo.cols > 65535) return fail(TE_ERR_UNSUPPORTED, "te_run_polygon_footprint: more than 65535 columns");
@@ -1534,7 +1585,7 @@ int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* verte
                             unsigned char* is_traversable, double* traversability) {
   if (!c || n_polygons < 0 || (n_polygons > 0 && (!vertex_offset || !vertex_xy || !is_traversable || !traversability)))
     return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: NULL argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_polygons_traversable: run the chain with the footprint pass first (it marks the untraversable cells)");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: map %d of %d", map, c->geo.batch);
@@ -1557,7 +1608,7 @@ int te_polygon_untraversable_hull(te_ctx* c, int map, int n_vertices, const doub
   if (n_vertices < 1) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: a polygon needs at least one vertex");
   for (long k = 0; k < 2L * n_vertices; ++k)
     if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: vertex %ld is not finite", k / 2);
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_polygon_untraversable_hull: run the chain with the footprint pass first (it marks the untraversable cells)");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: map %d of %d", map, c->geo.batch);
@@ -1600,7 +1651,7 @@ int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int*
     return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
   for (int k = 0; k < 3 * n_points; ++k)
     if (!isfinite(points_xyz[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: footprint point %d is not finite", k / 3);
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo || !c->footprint_done)
     return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: run the chain with the footprint pass first (it marks the untraversable cells)");
   if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: map %d of %d", map, c->geo.batch);
@@ -1742,7 +1793,7 @@ static int sync_tiles(te_ctx* c) {  // the copy streams of the streaming-tile ca
 
 int te_sync(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   HIP_TRY(hipSetDevice(c->device));
   // A blocking hipStreamSynchronize parks the thread and is woken by an interrupt; for the launches of this library
   // (a few hundred microseconds) that wake-up is a visible part of the latency, so the stream is polled first
@@ -1763,7 +1814,7 @@ int te_sync(te_ctx* c) {
 
 int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer: NULL");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c, /*beside_prefetch*/ true);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer: geometry not set");
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer: bad layer %d", layer);
@@ -1772,6 +1823,91 @@ int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
   HIP_TRY(hipSetDevice(c->device));
   const size_t per = (size_t)c->geo.rows * c->geo.cols;
   HIP_TRY(c->stager.download(host, p + per * map0, per * nmaps * sizeof(float), c->stream));
+  return TE_OK;
+}
+
+// Whole-layer uploads that run BESIDE the calls that follow (see travgpu.h).  The reference's chain hands every plugin the
+// whole map (SlopeFilter.cpp:62-63, StepFilter.cpp:105-107, RoughnessFilter.cpp:76-77), so a plugin knows the layers its
+// successors will read: their upload can cross PCIe host -> device while its own output crosses device -> host.
+int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* hosts) {
+  if (!c || n <= 0 || n > 8 || !layers || !hosts) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: bad argument");
+  CtxLock lk(c);  // (an earlier prefetch is finished first)
+  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_prefetch_layers: geometry not set");
+  if (c->prefetch_rc.load() != TE_OK) return fail(TE_ERR_HIP, "te_prefetch_layers: an earlier prefetch failed (te_wait_prefetch reports it)");
+  struct Job {
+    float* dev;
+    const float* host;
+  };
+  std::vector<Job> jobs;
+  bool elev = false;
+  for (int k = 0; k < n; ++k) {
+    if (!hosts[k]) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: NULL host buffer");
+    if (layers[k] != TE_LAYER_ELEVATION) {
+      if (const int rc = ensure_input_layer(c, layers[k])) return rc;
+    }
+    float* p = layer_ptr(c, layers[k]);
+    if (!p) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: bad layer %d", layers[k]);
+    jobs.push_back(Job{p, hosts[k]});
+    elev = elev || layers[k] == TE_LAYER_ELEVATION;
+    if (layers[k] == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
+    if (layers[k] == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->prefetch_order) HIP_TRY(hipStreamCreateWithFlags(&c->prefetch_order, hipStreamNonBlocking));
+  // what the compute stream has queued so far may still read these layers
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->prefetch_order, c->ev0, 0));
+  c->prefetcher.pool = 1;
+  const size_t bytes = c->layer_elems * sizeof(float);
+  const int device = c->device;
+  auto work = [c, jobs, bytes, device] {
+    int rc = TE_OK;
+    if (hipSetDevice(device) != hipSuccess) rc = TE_ERR_HIP;
+    for (size_t k = 0; k < jobs.size() && rc == TE_OK; ++k)
+      if (c->prefetcher.upload(jobs[k].dev, jobs[k].host, bytes, c->prefetch_order) != hipSuccess) rc = TE_ERR_HIP;
+    if (rc == TE_OK && hipStreamSynchronize(c->prefetch_order) != hipSuccess) rc = TE_ERR_HIP;
+    if (rc != TE_OK) (void)hipGetLastError();
+    c->prefetch_rc.store(rc);
+  };
+  c->prefetch_elev = elev;
+  if (!c->prefetch_thread.joinable()) {
+    try {
+      c->prefetch_thread = std::thread([c] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> pl(c->pf_mu);
+            c->pf_cv.wait(pl, [c] { return c->pf_quit || (bool)c->pf_job; });
+            if (c->pf_quit) return;
+            job.swap(c->pf_job);
+          }
+          job();
+          {
+            std::lock_guard<std::mutex> pl(c->pf_mu);
+            c->prefetch_running = false;
+          }
+          c->pf_cv.notify_all();
+        }
+      });
+    } catch (...) {  // no thread to be had: the uploads happen here and now
+      work();
+      return TE_OK;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> pl(c->pf_mu);
+    c->pf_job = work;
+    c->prefetch_running = true;
+  }
+  c->pf_cv.notify_all();
+  return TE_OK;
+}
+
+int te_wait_prefetch(te_ctx* c) {
+  if (!c) return fail(TE_ERR_INVALID_ARG, "te_wait_prefetch: NULL ctx");
+  CtxLock lk(c);  // (joins the prefetch)
+  const int rc = c->prefetch_rc.exchange(TE_OK);
+  if (rc != TE_OK) return fail(rc, "te_prefetch_layers: a transfer failed");
   return TE_OK;
 }
 
@@ -1911,7 +2047,7 @@ int te_sync_multi(te_ctx** ctxs, int n) {
 
 int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_per_iter) {
   if (!c || !ms_per_iter || iters <= 0 || warmup < 0) return fail(TE_ERR_INVALID_ARG, "te_time_chain: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_time_chain: geometry not set");
   for (int k = 0; k < warmup; ++k) {
     int rc = run_whole_locked(c, flags);
@@ -1932,7 +2068,7 @@ int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_pe
 
 int te_time_chain_samples(te_ctx* c, unsigned flags, int warmup, int iters, float* ms) {
   if (!c || !ms || iters <= 0 || warmup < 0) return fail(TE_ERR_INVALID_ARG, "te_time_chain_samples: bad argument");
-  std::lock_guard<std::mutex> lk(c->mu);
+  CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_time_chain_samples: geometry not set");
   for (int k = 0; k < warmup; ++k) {
     int rc = run_whole_locked(c, flags);

@@ -32,9 +32,14 @@ namespace {
 // 24 GB/s on these hosts).
 class CopyPool {
  public:
-  static CopyPool& get() {
-    static CopyPool* p = new CopyPool;  // (never destroyed: its threads sleep on its condition variable until the process ends)
-    return *p;
+  // Two pools per process: 0 for the transfers a call waits for, 1 for the prefetches that run beside them
+  // (te_prefetch_layers: PCIe is full duplex, one pool's copies are not)
+  static CopyPool& get(int which = 0) {
+    static CopyPool* p[2] = {new CopyPool, nullptr};  // (never destroyed: their threads sleep on a condition variable until the process ends)
+    if (which == 0) return *p[0];
+    static std::once_flag once;
+    std::call_once(once, [] { p[1] = new CopyPool; });
+    return *p[1];
   }
   // fork(): the child has the pool's state but none of its threads -- it copies on the calling thread from then on
   // (registered once, by the constructor; the locks are not taken around the fork: a child only ever reads `forked_`)
@@ -202,7 +207,7 @@ hipError_t HostStager::upload(void* dev, const void* host, size_t bytes, hipStre
     const size_t off = k * kChunk, n = bytes - off < kChunk ? bytes - off : kChunk;
     if (k >= (size_t)kSlots) e = hipEventSynchronize(ev[s]);  // the slot's previous chunk has left it
     if (e != hipSuccess) break;
-    CopyPool::get().copy(slot[s], (const char*)host + off, n);
+    CopyPool::get(pool).copy(slot[s], (const char*)host + off, n);
     e = hipMemcpyAsync((char*)dev + off, slot[s], n, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipEventRecord(ev[s], stream);
   }
@@ -244,7 +249,7 @@ hipError_t HostStager::download(void* host, const void* dev, size_t bytes, hipSt
     const size_t off = k * kChunk, n = bytes - off < kChunk ? bytes - off : kChunk;
     e = hipEventSynchronize(ev[s]);
     if (e != hipSuccess) break;
-    CopyPool::get().copy((char*)host + off, slot[s], n);
+    CopyPool::get(pool).copy((char*)host + off, slot[s], n);
     if (k + kSlots < nchunks) e = issue(k + kSlots);
   }
   if (e != hipSuccess) (void)hipStreamSynchronize(stream);  // chunks still in flight into the slots: drain before the next transfer reuses them

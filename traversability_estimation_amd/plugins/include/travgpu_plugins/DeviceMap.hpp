@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include <grid_map_core/GridMap.hpp>
 
@@ -32,6 +34,11 @@ class DeviceMap {
   // the buffer (every cell; TRAVGPU_PLUGIN_HASH=sampled reads ~4096 cells and then relies on the stamp, TRAVGPU_PLUGIN_CACHE=0
   // always uploads).
   bool upload(const grid_map::GridMap& map, const std::string& layer, int te_layer);
+  // Starts the upload of layers the NEXT plugins of the reference's chain will read (those of them `map` holds and the
+  // device does not): it runs beside this plugin's filter and the download of its output (te_prefetch_layers).  The
+  // plugin calls finishPrefetch() before its update() returns -- `map`'s buffers belong to the caller after that.
+  bool prefetch(const grid_map::GridMap& map, const std::vector<std::pair<std::string, int>>& layers);
+  bool finishPrefetch();
   // after a download into `layer`: the device layer and that host buffer are the same thing
   bool noteResident(const grid_map::GridMap& map, const std::string& layer, int te_layer);
   unsigned long uploads() const { return uploads_; }               // transfers actually made / avoided (tests, logging)
@@ -55,9 +62,11 @@ class DeviceMap {
     uint64_t stamp, hash;
     size_t n;
     int start_row, start_col;
+    bool prefetched;  // put there by prefetch(): the upload() it anticipated is the same transfer, not one avoided
   };
   static const int kLayers = 16;
   LayerKey resident_[kLayers];  // what each device layer holds, as far as the plugins put it there
+  bool prefetching_;
   void forget();                // after a geometry change or a launch that overwrites input layers
   unsigned long uploads_, uploads_skipped_;
   std::string error_;

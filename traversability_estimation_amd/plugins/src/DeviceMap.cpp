@@ -11,7 +11,7 @@ DeviceMap& DeviceMap::instance() {
 }
 
 DeviceMap::DeviceMap()
-    : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0), uploads_(0), uploads_skipped_(0) {
+    : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0), uploads_(0), uploads_skipped_(0), prefetching_(false) {
   forget();
 }
 
@@ -109,13 +109,16 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
   static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
   const float* data = map.get(layer).data();
   const size_t n = (size_t)rows_ * cols_;
-  LayerKey key = {true, (uint64_t)map.getTimestamp(), 0, n, start_row_, start_col_};
+  LayerKey key = {true, (uint64_t)map.getTimestamp(), 0, n, start_row_, start_col_, false};
   if (cache_on && te_layer >= 0 && te_layer < kLayers) {
     key.hash = hash_layer(data, n, hash_sampled());
     const LayerKey& r = resident_[te_layer];
     // (a sampled hash only stands in for the content together with a real time stamp)
     if (r.valid && (!hash_sampled() || key.stamp != 0) && r.stamp == key.stamp && r.hash == key.hash && r.n == key.n && r.start_row == key.start_row && r.start_col == key.start_col) {
-      ++uploads_skipped_;
+      if (r.prefetched)
+        resident_[te_layer].prefetched = false;  // (counted as an upload when it was started)
+      else
+        ++uploads_skipped_;
       return true;
     }
   }
@@ -129,11 +132,53 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
   return ok;
 }
 
+bool DeviceMap::prefetch(const grid_map::GridMap& map, const std::vector<std::pair<std::string, int>>& layers) {
+  static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
+  static const bool prefetch_on = !(getenv("TRAVGPU_PLUGIN_PREFETCH") && atoi(getenv("TRAVGPU_PLUGIN_PREFETCH")) == 0);
+  // (a moved map -- circular buffer -- takes the rectangle copies of te_upload_layer_circular: no prefetch; without the
+  // cache the next plugin would upload again anyway)
+  if (!cache_on || !prefetch_on || start_row_ || start_col_ || prefetching_) return true;
+  const size_t n = (size_t)rows_ * cols_;
+  int ids[8];
+  const float* hosts[8];
+  LayerKey keys[8];
+  int m = 0;
+  for (const auto& l : layers) {
+    if (m >= 8 || l.second < 0 || l.second >= kLayers || !map.exists(l.first)) continue;
+    const float* data = map.get(l.first).data();
+    const LayerKey key = {true, (uint64_t)map.getTimestamp(), hash_layer(data, n, hash_sampled()), n, start_row_, start_col_, true};
+    const LayerKey& r = resident_[l.second];
+    if (r.valid && (!hash_sampled() || key.stamp != 0) && r.stamp == key.stamp && r.hash == key.hash && r.n == key.n && r.start_row == key.start_row &&
+        r.start_col == key.start_col)
+      continue;  // the device holds it
+    ids[m] = l.second;
+    hosts[m] = data;
+    keys[m] = key;
+    ++m;
+  }
+  if (m == 0) return true;
+  if (!check(te_prefetch_layers(ctx_, m, ids, hosts))) return false;
+  prefetching_ = true;
+  for (int k = 0; k < m; ++k) {
+    resident_[ids[k]] = keys[k];  // (valid once finishPrefetch() has succeeded; cleared there otherwise)
+    ++uploads_;
+  }
+  return true;
+}
+
+bool DeviceMap::finishPrefetch() {
+  if (!prefetching_) return true;
+  prefetching_ = false;
+  if (check(te_wait_prefetch(ctx_))) return true;
+  forget();
+  return false;
+}
+
 bool DeviceMap::noteResident(const grid_map::GridMap& map, const std::string& layer, int te_layer) {
   static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
   if (!cache_on || te_layer < 0 || te_layer >= kLayers || !map.exists(layer)) return true;
   const size_t n = (size_t)rows_ * cols_;
-  const LayerKey key = {true, (uint64_t)map.getTimestamp(), hash_layer(map.get(layer).data(), n, hash_sampled()), n, start_row_, start_col_};
+  const LayerKey key = {true, (uint64_t)map.getTimestamp(), hash_layer(map.get(layer).data(), n, hash_sampled()), n, start_row_, start_col_, false};
   resident_[te_layer] = key;
   return true;
 }

@@ -46,8 +46,12 @@ bool SlopeFilter<T>::update(const T& mapIn, T& mapOut) {
   bool ok = dev.prepare(mapOut) && dev.params(p);
   if (ok) {
     p.slope_critical = criticalValue_;
+    // (the layers StepFilter and RoughnessFilter read next -- robot_filter_parameter.yaml:10-28 -- start their way to the
+    // device beside this plugin's kernel and the download of its output)
     ok = dev.setParams(p) && dev.upload(mapOut, "surface_normal_z", TE_LAYER_NORMAL_Z) &&
-         dev.runFilter(TE_FILTER_SLOPE) && dev.download(mapOut, type_, TE_LAYER_SLOPE);
+         dev.prefetch(mapOut, {{"elevation", TE_LAYER_ELEVATION}}) && dev.runFilter(TE_FILTER_SLOPE) &&
+         dev.download(mapOut, type_, TE_LAYER_SLOPE);
+    ok = dev.finishPrefetch() && ok;
   }
   if (!ok) ROS_ERROR("SlopeFilter (MI355X): %s", dev.error().c_str());
   return ok;

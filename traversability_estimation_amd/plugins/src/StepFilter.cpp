@@ -73,8 +73,11 @@ bool StepFilter<T>::update(const T& mapIn, T& mapOut) {
     p.step_radius1 = firstWindowRadius_;
     p.step_radius2 = secondWindowRadius_;
     p.step_ncrit = nCellCritical_;
-    ok = dev.setParams(p) && dev.upload(mapOut, "elevation", TE_LAYER_ELEVATION) && dev.runFilter(TE_FILTER_STEP) &&
-         dev.download(mapOut, type_, TE_LAYER_STEP);
+    // (the normals RoughnessFilter reads next start their way to the device beside this plugin's kernels and its download)
+    ok = dev.setParams(p) && dev.upload(mapOut, "elevation", TE_LAYER_ELEVATION) &&
+         dev.prefetch(mapOut, {{"surface_normal_x", TE_LAYER_NORMAL_X}, {"surface_normal_y", TE_LAYER_NORMAL_Y}, {"surface_normal_z", TE_LAYER_NORMAL_Z}}) &&
+         dev.runFilter(TE_FILTER_STEP) && dev.download(mapOut, type_, TE_LAYER_STEP);
+    ok = dev.finishPrefetch() && ok;
   }
   if (!ok) ROS_ERROR("StepFilter (MI355X): %s", dev.error().c_str());
   return ok;
