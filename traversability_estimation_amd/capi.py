@@ -137,8 +137,9 @@ def load():
         L.te_set_layer_present.argtypes = [vp, C.c_int, C.c_int]
         L.te_upload_layer.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int]
         L.te_upload_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
-        L.te_prefetch_layers.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(fp)]
-        L.te_wait_prefetch.argtypes = [vp]
+        if "TRAVGPU_LIB" not in os.environ or hasattr(L, "te_prefetch_layers"):  # (an A/B library of an earlier round lacks the pair)
+            L.te_prefetch_layers.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(fp)]
+            L.te_wait_prefetch.argtypes = [vp]
         L.te_download_layer_circular.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         L.te_run_filter.argtypes = [vp, C.c_int, C.c_uint]
         L.te_run_chain.argtypes = [vp, C.c_uint]

@@ -271,26 +271,25 @@ __device__ bool check_step(const Geo& g, const Disc& d, const TileView& elev, co
 // pair_blocks() -- does not depend on the centre cell; only the direction filter :830-832 does.  Next to a kerb every
 // candidate is met by up to 21 centres (circle(2.5 res)), each of which used to walk the candidate's rays again: one cell
 // beside a tall edge ran 189 pairs, ~1500 instructions each, 70 us in its thread, and the tile waited for it.  Now a tile
-// evaluates the pairs of its candidates ONCE (pair_mask: one bit per submap cell, for every tile cell that can be a
-// candidate and has a lower step neighbour -- the cells of t_kl), all threads sharing the candidates, and a centre's check
-// is a look at 21 masks plus the direction filter for the set bits.
-__device__ unsigned pair_mask(const Geo& g, const TileView& elev, const float* __restrict__ t_elev, const float* __restrict__ t_key, int idx,
-                              int ii, int ij, double crit_step, double max_gap) {
+// evaluates the pairs of its candidates ONCE (pair_bit: one bit per submap cell, for every tile cell that can be a
+// candidate and has a lower step neighbour -- the cells of t_kl; one PAIR per thread: a candidate on a straight edge has
+// three pairs to walk, and a thread that took them all was the tile's critical path), and a centre's check is a look at 21
+// masks plus the direction filter for the set bits.
+// one pair: submap cell `lin` of candidate (ii, ij) (tile index idx); true: its bit belongs into the candidate's mask
+__device__ bool pair_bit(const Geo& g, const TileView& elev, const float* __restrict__ t_elev, const float* __restrict__ t_key, int idx,
+                         int ii, int ij, int lin, double crit_step, double max_gap) {
   const Submap sm = submap_of(g, ii, ij);
+  if (lin >= sm.sr * sm.sc) return false;
   const double height = (double)t_elev[idx];  // :823
   const double lowest = height - crit_step;
-  unsigned f = 0;
-  for (int lin = 0; lin < sm.sr * sm.sc; ++lin) {
-    const int a = lin % sm.sr, b = lin / sm.sr;
-    const int m = idx + (sm.tj + b - ij) * MTW + (sm.ti + a - ii);
-    const float km = t_key[m];  // elevation where the step score is 0 (NaN elsewhere): :825
-    if (!((double)km < lowest)) continue;
-    double vx, vy;
-    pair_vector(g, ii, ij, sm, a, b, vx, vy);
-    if (sqrt(vx * vx + vy * vy) < 0.025) continue;  // :829
-    if (pair_blocks(g, elev, ii, ij, vx, vy, height, crit_step, max_gap)) f |= 1u << lin;
-  }
-  return f;
+  const int a = lin % sm.sr, b = lin / sm.sr;
+  const int m = idx + (sm.tj + b - ij) * MTW + (sm.ti + a - ii);
+  const float km = t_key[m];  // elevation where the step score is 0 (NaN elsewhere): :825
+  if (!((double)km < lowest)) return false;
+  double vx, vy;
+  pair_vector(g, ii, ij, sm, a, b, vx, vy);
+  if (sqrt(vx * vx + vy * vy) < 0.025) return false;  // :829
+  return pair_blocks(g, elev, ii, ij, vx, vy, height, crit_step, max_gap);
 }
 // circle(2.5 res) is the tie-free shape Q = 5 (rows dj = 0, +-1 span |di| <= 2, rows dj = +-2 span |di| <= 1); cells
 // outside the map are NaN in t_key and fail the candidate test like being skipped.
@@ -347,6 +346,7 @@ struct MaskArgs {
   // every flag of its strip is clear.)
   uint8_t* untrav_flags;
   int flag_ntx, flag_nfy;
+  int whatif;  // lab library only (TE_MASK_WHATIF; 0 in the product): 1 no pair masks are evaluated, 2 the slow cells are not decided
 };
 
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
     // The tile holds a vertical face.  Every wavefront stays (real barriers: such a tile has slow cells to share):
     //   1. the candidates with a lower step neighbour -- the non-NaN cells of t_kl -- are collected from the whole tile
     //      (own cells and halo), by the threads that computed them;
-    //   2. their pair masks are evaluated, 256 candidates at a time (pair_mask: the reference's ray / line geometry, once
-    //      per candidate instead of once per centre that meets it);
+    //   2. their pair masks are evaluated, 256 (candidate, submap cell) pairs at a time (pair_bit: the reference's ray /
+    //      line geometry, once per candidate instead of once per centre that meets it);
     //   3. the slow cells are listed and shared as below, their step check being check_step_memo.
     // t_kl is dead once every thread is through the screening pass: its memory holds the candidate list (later the slow
     // cells' list) and the pair masks, one unsigned short each per tile cell.
@@ -659,14 +659,15 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       if (klbits & 0x80000000u) klist[at++] = (unsigned short)((1 + (tid >> 2)) * MTW + ((tid & 3) == 0 ? 1 : MTW - 5 + (tid & 3)));
     }
     __syncthreads();
-    // (2)
+    // (2) one (candidate, submap cell) pair per thread; the few that block OR their bit into the candidate's mask
     {
-      const int n_kl = nkl;
+      const int n_jobs = (a.whatif & 1) ? 0 : nkl * 9;
 #pragma unroll 1
-      for (int k = tid; k < n_kl; k += MX * MBY) {
-        const int idx = klist[k];
+      for (int k = tid; k < n_jobs; k += MX * MBY) {
+        const int idx = klist[k / 9], lin = k - (k / 9) * 9;
         const int lb = idx / MTW, la2 = idx - lb * MTW;
-        fmask[idx] = (unsigned short)pair_mask(g, ve, t_elev, t_key, idx, i0 - MH + la2, j0 - MH + lb, a.crit_step, a.max_gap);
+        if (pair_bit(g, ve, t_elev, t_key, idx, i0 - MH + la2, j0 - MH + lb, lin, a.crit_step, a.max_gap))
+          atomicOr(reinterpret_cast<unsigned*>(fmask) + (idx >> 1), (1u << lin) << ((idx & 1) * 16));
       }
     }
     __syncthreads();
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const fl
       }
     });
     __syncthreads();
-    const int n_todo2 = ntodo;
+    const int n_todo2 = (a.whatif & 2) ? 0 : ntodo;
 #pragma unroll 1
     for (int k = tid; k < n_todo2; k += MX * MBY) {
       const int e = todo2[k];
@@ -1228,6 +1229,8 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   m.untrav_flags = L.untrav_flags;
   m.flag_ntx = untrav_flag_ntx(g.rows);
   m.flag_nfy = untrav_flag_nfy(g.cols);
+  static const int mask_whatif = lab_int("TE_MASK_WHATIF", 0);  // (timing experiments: wrong results by construction)
+  m.whatif = mask_whatif;
   // A region run (te_run_chain_region with the footprint flag): isTraversableForFilters of a cell reads scores within
   // 3 cells (circle(3 res), circle(2.5 res) and the 3x3 blocks around its cells), so the mask is recomputed on the
   // region grown by MH; the footprint of a cell reads the mask and the traversability within the footprint's reach.
