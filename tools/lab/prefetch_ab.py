@@ -24,6 +24,16 @@ def best(f, reps=10):
 
 
 def main():
+    if os.environ.get("PREFETCH_AB_TORCH"):  # (bench.py's process also holds torch's HIP context and thread pools)
+        import torch
+        torch.cuda.synchronize()
+    if os.environ.get("PREFETCH_AB_OMP"):    # ... and has run the OpenMP oracle on 64 threads
+        from oracle import oracle as O
+        O.build()
+        O.set_threads(64)
+        g = O.geom(256, 256, 0.05)
+        O.chain(g, O.default_params(), synth.perlin_elevation(256, 256, seed=1))
+        O.set_threads(1)
     capi.load()
     n, res = 4096, 0.05
     elev = synth.perlin_elevation(n, n, seed=1235)
@@ -38,21 +48,22 @@ def main():
         ctx.sync()
         nrm = [ctx.download(k) for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z")]
         buf = np.empty(n * n, np.float32)
-        out["upload_ms"] = best(lambda: (ctx.upload_layer("surface_normal_x", nrm[0]), ctx.sync()))
-        out["download_ms"] = best(lambda: ctx.download_into("traversability_slope", buf))
-        out["prefetch_alone_ms"] = best(lambda: (ctx.prefetch_layers({"surface_normal_x": nrm[0]}), ctx.wait_prefetch()))
+        if not os.environ.get("PREFETCH_AB_SKIP_MICRO"):
+            out["upload_ms"] = best(lambda: (ctx.upload_layer("surface_normal_x", nrm[0]), ctx.sync()))
+            out["download_ms"] = best(lambda: ctx.download_into("traversability_slope", buf))
+            out["prefetch_alone_ms"] = best(lambda: (ctx.prefetch_layers({"surface_normal_x": nrm[0]}), ctx.wait_prefetch()))
 
-        def both():
-            ctx.prefetch_layers({"surface_normal_x": nrm[0]})
-            ctx.download_into("traversability_slope", buf)
-            ctx.wait_prefetch()
-        out["download_beside_prefetch_ms"] = best(both)
+            def both():
+                ctx.prefetch_layers({"surface_normal_x": nrm[0]})
+                ctx.download_into("traversability_slope", buf)
+                ctx.wait_prefetch()
+            out["download_beside_prefetch_ms"] = best(both)
 
-        def both2():
-            ctx.prefetch_layers({"surface_normal_x": nrm[0], "surface_normal_y": nrm[1]})
-            ctx.download_into("traversability_slope", buf)
-            ctx.wait_prefetch()
-        out["download_beside_two_prefetched_layers_ms"] = best(both2)
+            def both2():
+                ctx.prefetch_layers({"surface_normal_x": nrm[0], "surface_normal_y": nrm[1]})
+                ctx.download_into("traversability_slope", buf)
+                ctx.wait_prefetch()
+            out["download_beside_two_prefetched_layers_ms"] = best(both2)
 
         def plugins(prefetch):
             ctx.upload_layer("surface_normal_z", nrm[2])
@@ -75,8 +86,33 @@ def main():
             ctx.run_filter("roughness")
             ctx.download("traversability_roughness")
             ctx.sync()
-        out["three_plugins_ms"] = best(lambda: plugins(False), 5)
-        out["three_plugins_prefetch_ms"] = best(lambda: plugins(True), 5)
+        if os.environ.get("PREFETCH_AB_HOSTPATH"):  # what bench.py does before its three-plugin block
+            names = ["traversability_slope", "traversability_step", "traversability_roughness", "traversability"]
+            for _ in range(3):
+                ctx.upload_elevation(elev)
+                ctx.run_chain(0)
+                outs = [ctx.download(k) for k in names]
+                ctx.sync()
+            bufs = [np.empty(elev.size, np.float32) for _ in names]
+            for b in [elev] + bufs:
+                capi.pin_host(b)
+            for _ in range(3):
+                ctx.upload_elevation(elev)
+                ctx.run_chain(0)
+                for k, b in zip(names, bufs):
+                    ctx.download_into(k, b)
+                ctx.sync()
+            for b in [elev] + bufs:
+                capi.unpin_host(b)
+            del bufs, outs
+            ctx.run_chain(capi.RUN_KEEP_NORMALS)
+            nrm[:] = [ctx.download(k) for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z")]
+        if os.environ.get("PREFETCH_AB_ORDER") == "TF":
+            out["three_plugins_prefetch_ms"] = best(lambda: plugins(True), 3)
+            out["three_plugins_ms"] = best(lambda: plugins(False), 3)
+        else:
+            out["three_plugins_ms"] = best(lambda: plugins(False), 3)
+            out["three_plugins_prefetch_ms"] = best(lambda: plugins(True), 3)
     print(json.dumps(out))
 
 
