@@ -66,3 +66,13 @@ def test_plugins_match_the_oracle_on_the_gpu(driver):
     r = subprocess.run([driver, "--device"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (0 failures)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plugins_with_prefetched_inputs_on_the_gpu(driver):
+    """TRAVGPU_PLUGIN_PREFETCH=1: SlopeFilter / StepFilter start the upload of the layers their successors read beside their
+    own kernel and download (DeviceMap::prefetch -> te_prefetch_layers); same results, same number of transfers."""
+    import os
+    r = subprocess.run([driver, "--device"], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRAVGPU_PLUGIN_PREFETCH="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK (0 failures)" in r.stdout
