@@ -2,8 +2,8 @@
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels with
 the gpurun snapshot, so the GPU box uses the prebuilt file.  Every source is compiled to its own object
-(in parallel, cached under _build/ by modification time; build_lib(force=True) compiles every object again) and the
-objects are linked into the library.
+(in parallel, cached under _build/ by modification time; build_lib(force=True) compiles every object again,
+build_lib(relink=True) only what is stale and then links) and the objects are linked into the library.
 
 `python -m traversability_estimation_amd.build --lab` builds libtravgpu_lab.so (-DTE_LAB, objects under _build_lab/): the
 same sources with their measurement switches (environment variables such as TE_NO_F4, TE_N3_BLOCKS_PER_CU) compiled in.
@@ -78,9 +78,12 @@ def _compile(unit, verbose, lab=False):
     os.replace(out + ".tmp", out)
 
 
-def build_lib(force=False, verbose=False, lab=False):
+def build_lib(force=False, verbose=False, lab=False, relink=False):
+    """force: every object is compiled again (about 6 minutes on 8 cores); relink: objects older than their source or
+    than any header are compiled, and the library is linked again even if nothing was (what __graft_entry__.build() asks
+    for: on a fresh clone that IS a full build, on a warm tree it is the link check)."""
     lib = LAB_LIB if lab else LIB
-    if not force and not stale(lab):
+    if not force and not relink and not stale(lab):
         return lib
     os.makedirs(LAB_OBJDIR if lab else OBJDIR, exist_ok=True)
     newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
@@ -101,4 +104,4 @@ def build_lib(force=False, verbose=False, lab=False):
 
 if __name__ == "__main__":
     import sys
-    print(build_lib(force="--force" in sys.argv or "--lab" not in sys.argv, verbose=True, lab="--lab" in sys.argv))
+    print(build_lib(force="--force" in sys.argv, relink=True, verbose=True, lab="--lab" in sys.argv))
