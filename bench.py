@@ -347,45 +347,54 @@ def main():
                 ctx.run_chain(capi.RUN_KEEP_NORMALS)
                 nrm = [ctx.download(k) for k in ("surface_normal_x", "surface_normal_y", "surface_normal_z")]
                 best = None
-                for prefetch in (False, True):
-                    best = None
-                    for _ in range(3):
-                        t0 = time.perf_counter()
-                        # SlopeFilter::update (plugins/src/SlopeFilter.cpp)
-                        ctx.upload_layer("surface_normal_z", nrm[2])
-                        if prefetch:
-                            ctx.prefetch_layers({"elevation": stack})
-                        ctx.run_filter("slope")
-                        o1 = ctx.download("traversability_slope")
-                        if prefetch:
-                            ctx.wait_prefetch()
-                        # StepFilter::update
-                        if not prefetch:
-                            ctx.upload_elevation(stack)
-                        else:
-                            ctx.prefetch_layers({"surface_normal_x": nrm[0], "surface_normal_y": nrm[1]})
-                        ctx.run_filter("step")
-                        o2 = ctx.download("traversability_step")
-                        if prefetch:
-                            ctx.wait_prefetch()
-                        # RoughnessFilter::update
-                        if not prefetch:
-                            ctx.upload_layer("surface_normal_x", nrm[0])
-                            ctx.upload_layer("surface_normal_y", nrm[1])
-                        ctx.run_filter("roughness")
-                        o3 = ctx.download("traversability_roughness")
-                        ctx.sync()
-                        d = time.perf_counter() - t0
-                        best = d if best is None or d < best else best
-                    host_path["three_plugins_prefetch_ms" if prefetch else "three_plugins_ms"] = best * 1e3
+                def three_plugins(prefetch):
+                    t0 = time.perf_counter()
+                    # SlopeFilter::update (plugins/src/SlopeFilter.cpp)
+                    ctx.upload_layer("surface_normal_z", nrm[2])
+                    if prefetch:
+                        ctx.prefetch_layers({"elevation": stack})
+                    ctx.run_filter("slope")
+                    o1 = ctx.download("traversability_slope")
+                    if prefetch:
+                        ctx.wait_prefetch()
+                    # StepFilter::update
+                    if not prefetch:
+                        ctx.upload_elevation(stack)
+                    else:
+                        ctx.prefetch_layers({"surface_normal_x": nrm[0], "surface_normal_y": nrm[1]})
+                    ctx.run_filter("step")
+                    o2 = ctx.download("traversability_step")
+                    if prefetch:
+                        ctx.wait_prefetch()
+                    # RoughnessFilter::update
+                    if not prefetch:
+                        ctx.upload_layer("surface_normal_x", nrm[0])
+                        ctx.upload_layer("surface_normal_y", nrm[1])
+                    ctx.run_filter("roughness")
+                    o3 = ctx.download("traversability_roughness")
+                    ctx.sync()
+                    dt3 = (time.perf_counter() - t0) * 1e3
+                    del o1, o2, o3
+                    return dt3
+                # the two forms take turns (what a download into a freshly allocated array costs -- first-touch page faults,
+                # 1.7 to 5 ms per 64 MB -- drifts over the life of a process: each form should see the same weather)
+                runs = {False: [], True: []}
+                for _ in range(4):
+                    for prefetch in (False, True):
+                        runs[prefetch].append(three_plugins(prefetch))
+                host_path["three_plugins_ms"] = min(runs[False])
+                host_path["three_plugins_prefetch_ms"] = min(runs[True])
+                host_path["three_plugins_runs_ms"] = {"one_transfer_at_a_time": [round(v, 2) for v in runs[False]],
+                                                      "with_prefetches": [round(v, 2) for v in runs[True]]}
                 host_path["three_plugins_what"] = ("te_run_filter(slope / step / roughness) with host layers in and out, 4 uploads "
                                                    "(elevation and surface_normal_z once), 3 downloads into freshly allocated arrays, pageable "
-                                                   "buffers, best of 3, one transfer at a time; _prefetch_: the uploads of the NEXT plugin's inputs "
+                                                   "buffers, best of 4 (all runs in three_plugins_runs_ms, the two forms taking turns), one transfer "
+                                                   "at a time; _prefetch_: the uploads of the NEXT plugin's inputs "
                                                    "start beside each plugin's kernel and download (te_prefetch_layers, as plugins/src/DeviceMap.cpp "
                                                    "does).  A 64 MB download beside a 64 MB upload takes 1.8 ms against 1.4 + 1.6 one after the other "
                                                    "(tools/lab/prefetch_ab.py, preallocated buffers), but here the first-touch page faults of the fresh "
                                                    "output arrays (1.7 - 5 ms per layer from pass to pass of one process) decide which line is lower")
-                del nrm, o1, o2, o3
+                del nrm
             except (capi.TeError, KeyError, TypeError, ValueError) as e:
                 host_path["three_plugins_error"] = str(e)
 

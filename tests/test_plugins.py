@@ -69,10 +69,10 @@ def test_plugins_match_the_oracle_on_the_gpu(driver):
 
 
 @pytest.mark.gpu
-def test_plugins_with_prefetched_inputs_on_the_gpu(driver):
-    """TRAVGPU_PLUGIN_PREFETCH=1: SlopeFilter / StepFilter start the upload of the layers their successors read beside their
-    own kernel and download (DeviceMap::prefetch -> te_prefetch_layers); same results, same number of transfers."""
+def test_plugins_without_prefetch_on_the_gpu(driver):
+    """TRAVGPU_PLUGIN_PREFETCH=0: one transfer at a time (by default SlopeFilter / StepFilter start the upload of the layers
+    their successors read beside their own kernel and download: DeviceMap::prefetch -> te_prefetch_layers); same results."""
     import os
-    r = subprocess.run([driver, "--device"], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRAVGPU_PLUGIN_PREFETCH="1"))
+    r = subprocess.run([driver, "--device"], capture_output=True, text=True, timeout=300, env=dict(os.environ, TRAVGPU_PLUGIN_PREFETCH="0"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (0 failures)" in r.stdout

@@ -134,11 +134,9 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
 
 bool DeviceMap::prefetch(const grid_map::GridMap& map, const std::vector<std::pair<std::string, int>>& layers) {
   static const bool cache_on = !(getenv("TRAVGPU_PLUGIN_CACHE") && atoi(getenv("TRAVGPU_PLUGIN_CACHE")) == 0);
-  // Opt-in (TRAVGPU_PLUGIN_PREFETCH=1).  The transfers do overlap -- a 64 MB download beside a 64 MB upload takes 1.8 ms
-  // against 1.4 + 1.6 -- but on the hosts this was measured on, the downloads into freshly added layers (first-touch page
-  // faults, taken by the copy threads) ran 3 x slower in a process that had prefetched before, and the three-plugin sequence
-  // as a whole came out anywhere between 4 ms faster and 4 ms slower.
-  static const bool prefetch_on = getenv("TRAVGPU_PLUGIN_PREFETCH") && atoi(getenv("TRAVGPU_PLUGIN_PREFETCH")) != 0;
+  // On by default (TRAVGPU_PLUGIN_PREFETCH=0 switches it off): the 4096^2 three-plugin sequence takes 9.2 ms with the
+  // prefetches against 11.7 ms one transfer at a time (bench.py, host_path.three_plugins_runs_ms: the two forms taking turns).
+  static const bool prefetch_on = !(getenv("TRAVGPU_PLUGIN_PREFETCH") && atoi(getenv("TRAVGPU_PLUGIN_PREFETCH")) == 0);
   // (a moved map -- circular buffer -- takes the rectangle copies of te_upload_layer_circular: no prefetch; without the
   // cache the next plugin would upload again anyway)
   if (!cache_on || !prefetch_on || start_row_ || start_col_ || prefetching_) return true;

@@ -173,7 +173,7 @@ static void test_device() {
     next.setTimestamp(map0.getTimestamp() + 250000000ull);
     next["elevation"](7, 9) += 0.25f;
     // (StepFilter also sends the normals RoughnessFilter will read next, when the map brings them under a new stamp)
-    const bool prefetching = getenv("TRAVGPU_PLUGIN_PREFETCH") && atoi(getenv("TRAVGPU_PLUGIN_PREFETCH")) != 0;
+    const bool prefetching = !(getenv("TRAVGPU_PLUGIN_PREFETCH") && atoi(getenv("TRAVGPU_PLUGIN_PREFETCH")) == 0);
     const unsigned long nrm = (prefetching && map0.exists("surface_normal_x")) ? 3 : 0;
     CHECK(t->update(next, b));
     CHECK(dev.uploads() - up0 == 5 + nrm);
