@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the OpenMP all-core run of the oracle")
     ap.add_argument("--cpu-all-cores", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle parity check of the timed result (profiler runs)")
+    ap.add_argument("--check-crops", action="store_true", help="parity check on a corner crop and a full-width band (244 496 cells per layer) instead "
+                    "of EVERY cell of the map (the default up to 4096^2: the OpenMP oracle takes a few seconds for it on the GPU box's host)")
     ap.add_argument("--holes", type=float, default=0.0, help="fraction of invalid (NaN) cells: speckle if < 0.5, else "
                     "solid unobserved regions covering about (value - 0.5) of the map (not the BASELINE workload)")
     ap.add_argument("--sequential", action="store_true", help="profiling aid: no two-stream overlap inside the chain")
@@ -155,10 +157,10 @@ def cpu_baseline(args, elev_full, p, with_footprint, threads=1):
     return res
 
 
-def parity_check(args, ctx, elev, p, with_fp, n):
-    """The layers on the device (map 0 of this rank) against the oracle: a corner crop (two map borders) and one
-    full-width band (every block column and strip seam of the marching kernels).  Cells closer to a cut edge of the
-    crop than the reach of the chain (+ the footprint's) see a cut neighbourhood in the crop and are left out."""
+def parity_check(args, ctx, elev, p, with_fp, n, whole=False):
+    """The layers on the device (map 0 of this rank) against the oracle: every cell of the map (whole), or a corner crop
+    (two map borders) and one full-width band (every block column and strip seam of the marching kernels); cells closer to
+    a cut edge of a crop than the reach of the chain (+ the footprint's) see a cut neighbourhood there and are left out."""
     from oracle import oracle as O
     from tests.helpers import OUT_LAYERS, TOL, compare_layer
     names = list(OUT_LAYERS) + (["traversability_footprint"] if with_fp else [])
@@ -172,7 +174,9 @@ def parity_check(args, ctx, elev, p, with_fp, n):
     crop_n = min(n, 320)
     band = min(n, 2 * margin + 40)
     windows = [("corner crop %dx%d" % (crop_n, crop_n), (slice(0, crop_n), slice(0, crop_n)))]
-    if n > crop_n:
+    if whole:
+        windows = [("whole map %dx%d" % (n, n), (slice(0, n), slice(0, n)))]
+    elif n > crop_n:
         j0 = (n // 2 // 64) * 64 + 17  # not aligned with anything
         j0 = min(j0, n - band)
         windows.append(("full-width band, rows %d..%d" % (j0, j0 + band), (slice(j0, j0 + band), slice(0, n))))
@@ -291,7 +295,7 @@ def main():
     # parity of what the timed launches left on the device (rank 0, map 0)
     check = None
     if rank == 0 and not args.no_check:
-        check = parity_check(args, ctx, elevs[0], p, with_fp, n)
+        check = parity_check(args, ctx, elevs[0], p, with_fp, n, whole=(not args.check_crops) and n * n <= 4096 * 4096)
 
     # plugin-shaped path: host buffers in, host buffers out (PCIe both ways); reported next to, never as, `value`
     host_path = None

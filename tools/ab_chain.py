@@ -42,7 +42,10 @@ def main():
     ap.add_argument("--check", action="store_true", help="after the timing, compare what the launches left on the device with the "
                     "oracle (bench.py's parity_check: a corner crop and a full-width band; exit code 1 on a mismatch) -- no number "
                     "goes into profiles/ from an unchecked run")
+    ap.add_argument("--check-whole", action="store_true", help="--check on EVERY cell of the map (the OpenMP oracle on the whole map, at the map's own "
+                    "resolution: no crop, so checkForStep's position-rounding ties are the map's own)")
     a = ap.parse_args()
+    a.check = a.check or a.check_whole
     from traversability_estimation_amd import capi, synth
     capi.load()
     n, B = a.size, a.batch
@@ -121,7 +124,7 @@ def main():
             ctx.run_chain(flags)
             ctx.sync()
             args = types.SimpleNamespace(radius_cells=a.radius_cells, res=a.res)
-            rep = bench.parity_check(args, ctx, elevs[0], p, not a.no_footprint, n)
+            rep = bench.parity_check(args, ctx, elevs[0], p, not a.no_footprint, n, whole=a.check_whole)
             out["parity_check"] = {"ok": rep["ok"], "windows": rep["windows"],
                                    "mismatches": {k: v["mismatches"] for k, v in rep["layers"].items()},
                                    "max_abs_err": max(v["max_abs_err"] for v in rep["layers"].values()),

@@ -11,9 +11,10 @@ echo "[" > $O/obstacles.json
 first=1
 for b in 0 3 30 300 3000; do
   timeout 120 python $ROOT/tools/ab_chain.py --boxes $b --tag chain > $O/b_$b.json 2> $O/b_$b.err
-  # parity of the same map at a dyadic resolution (checkForStep's geometric ties depend on the absolute cell positions at
-  # 0.05 m, which the oracle's crop does not share with the map: DESIGN.md section 2)
-  timeout 240 python $ROOT/tools/ab_chain.py --boxes $b --res 0.0625 --iters 20 --tag check --check > $O/c_$b.json 2>> $O/b_$b.err
+  # parity of the same map, EVERY cell, at the BASELINE resolution: the OpenMP oracle on the whole map (round 3-4 checked
+  # crops at a dyadic resolution: checkForStep's geometric ties depend on the absolute cell positions at 0.05 m, which a
+  # crop does not share with the map -- the whole map does)
+  timeout 900 python $ROOT/tools/ab_chain.py --boxes $b --iters 20 --tag check --check-whole > $O/c_$b.json 2>> $O/b_$b.err
   timeout 180 rocprofv3 --kernel-trace --stats -d $O/kt_$b -o p --output-format csv -- python $ROOT/tools/ab_chain.py --sequential --iters 30 --boxes $b > $O/kt_$b.log 2>&1
   python - >> $O/obstacles.json <<PY
 import csv, glob, json, re
@@ -25,7 +26,7 @@ for f in glob.glob("$O/kt_$b/**/*kernel_stats.csv", recursive=True):
         if m and m.group(0) != "k_count_invalid": k[m.group(0)] = round(float(r["AverageNs"]) / 1e3, 1)
 pc = json.loads(open("$O/c_$b.json").read().strip().splitlines()[-1]).get("parity_check", {})
 print(("" if $first else ",") + json.dumps({"boxes": $b, "ms_per_launch": round(d["ms_median"], 4), "kernel_us_alone": k,
-                                            "parity_ok_at_res_0.0625": pc.get("ok"), "parity_mismatches": sum(pc.get("mismatches", {"-": -1}).values())}))
+                                            "parity_ok_whole_map_res_0.05": pc.get("ok"), "parity_mismatches": sum(pc.get("mismatches", {"-": -1}).values()), "parity_cells_per_layer": pc.get("cells_per_layer")}))
 PY
   first=0
 done
