@@ -261,3 +261,26 @@ def test_prefetched_layers_equal_uploaded_layers(capi, oracle):
         got = {k: ctx.download(k) for k in OUT_LAYERS}
         ctx.wait_prefetch()
     assert_layers_match(got, want, ctx="chain after an unawaited prefetch")
+
+
+@pytest.mark.parametrize("kind,amount", [("boxes", 300), ("speckle", 0.001)])
+def test_whole_4096_map_against_the_oracle_at_res_005(capi, oracle, kind, amount):
+    """The BASELINE size AND resolution, every cell: 4096^2 at 0.05 m, radius 9 cells, footprint 6 + 3 cells, with 300 boxes
+    (k_fp_mask's memoised checkForStep, the inner disc, k_fp_blocked) or 0.1 % speckle (the sparse-hole march) -- all five
+    layers and the memo layers against the OpenMP oracle on the WHOLE map (no crop: checkForStep's position-rounding ties are
+    the map's own).  The oracle takes some ten seconds on the GPU box's host cores."""
+    from traversability_estimation_amd import synth
+    from tests.test_gpu_fullsize import _rough_map
+    n, res = 4096, 0.05
+    elev = _rough_map(synth, n, 1235, kind, amount)
+    r = synth.benchmark_radius(9, res)
+    over = dict(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=synth.benchmark_radius(6, res),
+                fp_offset=synth.benchmark_radius(3, res))
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    try:
+        got, want, op = both_fp(capi, oracle, elev, n, n, res, **over)
+    finally:
+        oracle.set_threads(1)
+    check_fp(got, want, op, f"4096^2 at res 0.05, {kind} {amount}: whole map against the oracle")
+    for k in ("slope_footprint", "step_footprint"):
+        assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
