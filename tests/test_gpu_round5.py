@@ -284,3 +284,45 @@ def test_whole_4096_map_against_the_oracle_at_res_005(capi, oracle, kind, amount
     check_fp(got, want, op, f"4096^2 at res 0.05, {kind} {amount}: whole map against the oracle")
     for k in ("slope_footprint", "step_footprint"):
         assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
+
+
+@pytest.mark.parametrize("cells,keep", [(9, False), (5, True), (3, False)])
+def test_unobserved_regions(capi, oracle, cells, keep):
+    """Unobserved REGIONS (counted at upload, too many cells for the sparse march): k_normals3's dense march on strips of 32
+    rows -- more blocks than resident slots --, the clean first attempt handing over at the row it reached, and the steps
+    inside a region that find not one cell in the ring's window (nothing to compute).  Regions in the interior, in a
+    corner of the map, a band narrower than a strip's window, a column of the map, and a few scattered cells; all layers
+    (and the surface normals with TE_RUN_KEEP_NORMALS) against the oracle on the whole map."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 600, 520, 0.05
+    elev = synth.perlin_elevation(rows, cols, seed=700 + cells, amplitude=0.6).copy()
+    a0, a1 = elev.shape
+    elev[int(0.30 * a0):int(0.72 * a0), int(0.25 * a1):int(0.70 * a1)] = np.nan   # interior, wider and taller than a window
+    elev[:int(0.22 * a0), :int(0.3 * a1)] = np.nan                                # a corner of the map
+    elev[int(0.80 * a0):int(0.84 * a0), int(0.1 * a1):int(0.9 * a1)] = np.nan     # a band one way ...
+    elev[int(0.1 * a0):int(0.95 * a0), int(0.86 * a1):int(0.89 * a1)] = np.nan    # ... and the other
+    elev[:, -1] = np.nan
+    elev[-1, :] = np.inf
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        elev[rng.integers(0, a0), rng.integers(0, a1)] = np.nan
+    assert 0.2 < np.mean(~np.isfinite(elev)) < 0.5
+    r = synth.benchmark_radius(cells, res)
+    over = dict(normals_radius=r, rough_radius=r, step_radius1=synth.benchmark_radius(3, res), step_radius2=synth.benchmark_radius(3, res),
+                fp_radius=synth.benchmark_radius(6, res), fp_offset=synth.benchmark_radius(3, res))
+    if not keep:
+        got, want, op = both_fp(capi, oracle, elev, rows, cols, res, pos=(1.0, 2.0), **over)
+        check_fp(got, want, op, f"unobserved regions, radius {cells} cells")
+        return
+    op = oracle.default_params(**over)
+    g = oracle.geom(rows, cols, res, (1.0, 2.0))
+    want = oracle.chain(g, op, elev, want_normals=True)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, (1.0, 2.0))
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_KEEP_NORMALS)
+        ctx.sync()
+        layers = list(OUT_LAYERS) + ["surface_normal_x", "surface_normal_y", "surface_normal_z"]
+        got = {k: ctx.download(k) for k in layers}
+    assert_layers_match(got, want, layers=layers, ctx=f"unobserved regions, normals kept, radius {cells} cells")

@@ -74,8 +74,11 @@ __device__ __forceinline__ int general_tail3(double res, int n, int si, int sj, 
   double lam = 0.0;
   const double tr2 = 2.0 * tr;
   bool ok = c1 > 0.0 && tr < 1e9 && tr > 1e-12;  // the float32 seeds of the reciprocals stay in range
+#ifndef TE_EIG3_ITERS
+#define TE_EIG3_ITERS 6
+#endif
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < TE_EIG3_ITERS; ++it) {
     const double p = fma(lam, fma(lam, tr - lam, -c1), det);
     const double dp = fma(lam, fma(-3.0, lam, tr2), -c1);  // < 0 left of the smallest root
     const double step = p * rcp_fast(dp);

@@ -137,6 +137,9 @@ struct Layers {
   int sparse_holes;  // 1: at most a few per mille of the elevation cells are invalid (counted at upload): k_normals3 takes its sparse march
   int no_holes;      // 1: none of them is (counted at upload): the clean march alone, on its slim ring (k_normals3s)
   int skip_clean;    // 1: scattered invalid cells, several per strip on average (sparse march): the clean march is not attempted first
+  int short_strips;  // 1: invalid cells counted, too many for the sparse march -- unobserved regions as a rule: k_normals3 cuts the map
+                     // into strips of 32 rows, more blocks than resident slots (a strip along the edge of a region takes 2.6x
+                     // the time of a clean one and the pass lasted as long as its slowest strip: te_normals3.hip, launch3)
   char* hole_queue;  // its scratch: normals_hole_queue_bytes() (te_normals3.hip), nullptr: the dense march serves
 };
 

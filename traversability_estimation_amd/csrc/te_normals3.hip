@@ -55,6 +55,9 @@ namespace {
 #ifndef TE_N3_WHATIF
 #define TE_N3_WHATIF 0
 #endif
+#ifndef TE_N3_HWHATIF  // (the sparse-hole march's measurement builds, tools/lab/r05_exp11.sh)
+#define TE_N3_HWHATIF 0
+#endif
 constexpr int kN3Waves = TE_N3_WAVES;  // waves per SIMD the kernel is compiled for
 // Sparse-hole march: the cells whose disc holds an invalid cell wait in a per-block queue (global scratch, it stays in L2)
 // until 64 of them fill a wavefront for the general tail.  An item is 48 bytes: Sz, Siz, Sjz, Szz, the six x/y moments
@@ -90,6 +93,7 @@ struct N3Args {
   int sparse_holes;           // the map holds few invalid cells (host's count at upload): HOLES = 1 instead of 2
   int no_holes;               // ... none at all: the clean march alone, on its slim ring (k_normals3s)
   int skip_clean;             // sparse holes on nearly every strip: straight to the HOLES = 1 march (Layers::skip_clean)
+  int short_strips;           // dense march, invalid cells counted: strips of 32 rows, more blocks than resident slots (launch3)
   char* hole_queue;           // HOLES = 1: kHoleQueueBytes of global scratch per block (cells waiting for the general tail)
   float inv_slope_crit, inv_rough_crit;
   float band_slope, band_rough;  // a raw score within this of the clip at 0 is left to the fix-up pass (kExactNaNBits, te_internal.h)
@@ -144,8 +148,11 @@ typedef float __attribute__((address_space(1))) gfloat;
 // lane's own cell of the ring row that was overwritten one step earlier -- read back just before that.  18 rows of 82
 // doubles at R = 9 are 11 808 bytes: 12 single-wave blocks per CU instead of 11 (tools/census.hip: 12 288 bytes admit 12,
 // 13 120 admit 11), i.e. three waves on every SIMD and strips 8 % shorter.
+// Returns the first row of the strip that is NOT done: jend, or -- HOLES = 0 only -- the row at which the clean march met an
+// invalid cell (every row before it is finished and stored, its tile flags written; the caller runs [that row, jend) with
+// the march that handles invalid cells).
 template <int Q, bool KEEP, bool GENERAL, int HOLES, bool TIES = false, bool SLIM = false>
-__device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
+__device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned long long (*hm)[2], const int i0, const int own_lo, const int js,
                                        const int jend) {
   constexpr int R = Shape<Q>::R;
   constexpr int W = kLanes + 2 * R;
@@ -201,6 +208,11 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
 
   // bit k: row (oldest row of the ring + k) holds an invalid cell of the map inside this block's window ("dirty")
   unsigned dmask = 0;
+  // HOLES = 2, bit k likewise: no cell of that row's window is there at all (invalid, or outside the map) -- while that holds
+  // for every row of the ring, inside an unobserved region, a step has nothing to compute (the march loop below)
+  unsigned amask = 0;
+  bool row_void = false;
+  constexpr unsigned kAllRows = NR >= 32 ? 0xffffffffu : ((1u << NR) - 1u);
   constexpr unsigned kTopBit = 1u << (NR - 1);
   constexpr unsigned kDiscMask = (1u << (2 * R + 1)) - 1u;  // the rows j-R .. j+R of the disc of row j
   bool row_dirty = false;
@@ -249,6 +261,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       row_dirty = (mm | mh) != 0ull;
     } else {
       row_dirty = rin && __any(!__builtin_isfinite(pm) || (!__builtin_isfinite(ph) && halo_in));
+      if (HOLES == 2) row_void = !__any(okm || okh);
     }
   };
   // The march starts with the disc of its first row summed directly: rows js-R .. js+R+1 go into ring rows 0 .. 2R+1
@@ -282,11 +295,12 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     for (int k = 0; k < C; ++k) {
       stage_row(js - OLD + c * C + k, vb[c], k, pmq[k], phq[k]);
       dmask |= row_dirty ? 1u << (c * C + k) : 0u;
+      if (HOLES == 2) amask |= row_void ? 1u << (c * C + k) : 0u;
     }
   });
 #pragma unroll
   for (int k = 0; k < C; ++k) load_row(js + R + LEAD + k, pmq[k], phq[k]);  // rows j + LEAD + R of the first C steps
-  if (!TIES && HOLES == 0 && __builtin_expect(dmask != 0, 0)) return false;  // an invalid cell: this strip needs the other march (SLIM: the fix-up pass, see k_normals3s)
+  if (!TIES && HOLES == 0 && __builtin_expect(dmask != 0, 0)) return js;  // an invalid cell: this strip needs the other march (SLIM: the fix-up pass, see k_normals3s)
 
   double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
   static_for<2 * R + 1>([&](auto ec) __attribute__((always_inline)) {
@@ -523,7 +537,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     if (__builtin_expect(dmask != 0, 0)) {  // an invalid cell among the first rows
       leave_to_fixup(js);
       write_flags();
-      return true;
+      return jend;
     }
   }
   // ---- rows whose disc holds invalid cells ------------------------------------------------------------------------------
@@ -539,6 +553,10 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
   auto flush_queue = [&](unsigned count) {
     // the items were written by other lanes of THIS wave: workgroup scope -- wait for the stores, the CU's L1 is coherent
     // for its own waves.  (Agent scope writes back and invalidates the XCD's L2 on this chip: the launch took 2.8 ms.)
+#if TE_N3_HWHATIF == 3  // (measurement only: the queue is filled and never read)
+    qhead += count;
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const bool act = (unsigned)lane < count;
     const char* it = qb + (size_t)((qhead + (unsigned)lane) & (kHoleQueueItems - 1)) * kHoleItemBytes;
@@ -587,6 +605,13 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
     int hn = 0, hi_ = 0, hj = 0, hii = 0, hij = 0, hjj = 0;
     bool nocentre = false;
     unsigned bits = dmask & kDiscMask;  // bit k: map row j - R + k is dirty (uniform)
+#if TE_N3_HWHATIF == 1  // (measurement only: the invalid cells are not looked at)
+    bits = 0;
+#endif
+    // (Taking the invalid cells one at a time for all lanes -- scalar loops over the uniform row masks, a lane only tests
+    // di^2 <= Q - dj^2 -- measured slower: the pass 0.60 ms against 0.32 at 0.1 % speckle, tools/lab/r05_exp12.sh.  That
+    // build smeared bit 31 of a mask over its upper word -- phantom cells in one dirty row of 80 --, which does not explain
+    // a factor; it was not measured again.)
     while (bits) {
       const int k = __builtin_ctz(bits);
       bits &= bits - 1u;
@@ -611,10 +636,13 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         hjj += dj * dj;
       }
     }
-    if constexpr (!GENERAL && !KEEP) {
+    if constexpr (!GENERAL && !KEEP && TE_N3_HWHATIF != 4) {  // (4: the general tail in place for every row with a dirty row in its disc)
       // Interior blocks: the lanes whose disc holds no invalid cell take the closed form like on a clean row; the
       // others (22 % of the cells at 0.1 % speckle, while 79 % of the ROWS hold at least one) are put into the queue
       // with their moments and get the general tail later, 64 at a time (flush_queue).
+#if TE_N3_HWHATIF == 2  // (measurement only: the walk, but nobody waits for a general tail)
+      hn = 0;
+#endif
       deferred = hn > 0;  // (for tail(): neither these lanes nor the invalid centres below are its business)
       tail(j);
       deferred = hn > 0 && !nocentre && own;
@@ -939,9 +967,12 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       if constexpr (TIES) {  // the rest of the strip belongs to the fix-up pass
         leave_to_fixup(j);
         write_flags();
-        return true;
+        return jend;
       }
-      return false;
+      // rows [js, j) are done: the invalid cell is in the map row that the step of row j - 1 staged, j + R (SLIM) or
+      // j + 1 + R -- beyond the disc of row j - 1
+      if (__builtin_expect(flag_rows != 0, 0)) write_flags();
+      return j;
     }
   } else {
     bool done = false;
@@ -959,7 +990,15 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
           holes = true;
         }
         deferred = false;
-        if ((dmask & kDiscMask) == 0) {
+        // Inside an unobserved region: not one cell in the window of the ring's rows, j - R .. j + 1 + R.  Every disc of this
+        // row is empty -- no normal, slope or roughness (the centre is invalid) -- and the slide would add and take away
+        // nothing: the moments (all zero, the z-sums a few markers) are those of the next row's discs as they stand.
+        // (One branch around the tail and one around the slide: a step of its own with the staging and the stores a second
+        // time cost the speckled maps 5 % -- the kernel's code is larger than the instruction cache as it is.)
+        const bool void_step = HOLES == 2 && holes && amask == kAllRows;  // (uniform)
+        if (__builtin_expect(void_step, 0)) {
+          o_slope = o_rough = fx = fy = fz = __builtin_nanf("");
+        } else if ((dmask & kDiscMask) == 0) {
           if (GENERAL) {
             const int ky = j < R ? R - j : (a.cols - 1 - j < R ? -(R - (a.cols - 1 - j)) : 0);  // uniform
             tail_clipped(j, ky);
@@ -971,12 +1010,15 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
         } else {
           tail_dense(j, uc);
         }
-        if (HOLES == 2 && holes)
+        if (__builtin_expect(void_step, 0)) {
+        } else if (HOLES == 2 && holes) {
           slide_holes(uc);
-        else
+        } else {
           slide(uc);
+        }
         stage_row(j + 2 + R, vb[0], u, pmq[u], phq[u]);
         dmask = (dmask >> 1) | (row_dirty ? kTopBit : 0u);
+        if (HOLES == 2) amask = (amask >> 1) | (row_void ? kTopBit : 0u);
         if (HOLES == 2) holes = holes && dmask != 0;  // the last dirty row has left the ring: the table / closed form serves again
         load_row(j + 2 + R + C, pmq[u], phq[u]);
         store_row();
@@ -990,7 +1032,7 @@ __device__ __forceinline__ bool march3(const N3Args& a, double* ring, unsigned l
       while (qtail != qhead) flush_queue(qtail - qhead < (unsigned)kLanes ? qtail - qhead : (unsigned)kLanes);
   }
   if (__builtin_expect(flag_rows != 0, 0)) write_flags();
-  return true;
+  return jend;
 }
 
 // Which strip a block works on (uniform): blocks [0, nb_fast) are the interior columns x interior rows, then come the edge
@@ -1021,6 +1063,7 @@ __device__ __forceinline__ bool n3_block(const N3Args& a, int& i0, int& own_lo, 
   return js < jend;
 }
 
+constexpr int kN3ShortStripRows = 32;  // strip height of the dense march on maps with counted invalid cells (launch3)
 constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 bytes of scratch (local copies of the moments, the general
                                 // tail on every row); compiled for 2 waves the compiler takes all 256 and spills 500 bytes on top
 template <int Q, bool KEEP, int HM, bool TIES = false>
@@ -1047,15 +1090,15 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(TIES ? k
       march3<Q, KEEP, false, 0, true>(a, ring, hmask, i0, own_lo, js, jend);
     return;
   }
-  const bool clean = (HM == 1 && a.skip_clean) ? false  // (uniform) nearly every strip holds an invalid cell: no first attempt
-                      : general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
-                                : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
-  if (__builtin_expect(!clean, 0)) {  // the strip holds invalid cells: once more, with the march that handles them
+  const int jr = (HM == 1 && a.skip_clean) ? js  // (uniform) nearly every strip holds an invalid cell: no first attempt
+                  : general ? march3<Q, KEEP, true, 0>(a, ring, hmask, i0, own_lo, js, jend)
+                            : march3<Q, KEEP, false, 0>(a, ring, hmask, i0, own_lo, js, jend);
+  if (__builtin_expect(jr < jend, 0)) {  // the strip holds invalid cells: from the row that met the first one on, the march that handles them
     __syncthreads();
     if (general)
-      march3<Q, KEEP, true, HM>(a, ring, hmask, i0, own_lo, js, jend);
+      march3<Q, KEEP, true, HM>(a, ring, hmask, i0, own_lo, jr, jend);
     else
-      march3<Q, KEEP, false, HM>(a, ring, hmask, i0, own_lo, js, jend);
+      march3<Q, KEEP, false, HM>(a, ring, hmask, i0, own_lo, jr, jend);
   }
 }
 
@@ -1083,14 +1126,15 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kN3Waves
     int i0, own_lo, js, jend;
     bool general;
     if (!n3_block(a, i0, own_lo, js, jend, general)) return;
-    const bool clean = general ? march3<Q, false, true, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend)
-                               : march3<Q, false, false, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend);
-    if (__builtin_expect(!clean, 0)) {
-      // an invalid cell after all: the whole strip goes to the fix-up pass (NaN in my cells, every tile the strip touches
-      // flagged -- the pass takes the valid cells of a flagged tile whose slope is NaN; rows the march had already stored
-      // are simply computed again)
+    const int jr = general ? march3<Q, false, true, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend)
+                           : march3<Q, false, false, 0, false, true>(a, ring, nullptr, i0, own_lo, js, jend);
+    if (__builtin_expect(jr < jend, 0)) {
+      // an invalid cell after all: the rest of the strip goes to the fix-up pass (NaN in my cells, every tile those rows
+      // touch flagged -- the pass takes the valid cells of a flagged tile whose slope is NaN; rows of such a tile that the
+      // march had already stored are simply computed again)
       const int lane = threadIdx.x;
       const size_t mo = (size_t)(a.map >= 0 ? a.map : (int)blockIdx.z) * (size_t)a.map_cells;
+      js = jr;
       if (i0 + lane >= own_lo)
         for (int jj = js; jj < jend; ++jj) {
           const size_t o = mo + (size_t)jj * a.rows + (size_t)(i0 + lane);
@@ -1190,6 +1234,14 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
       }
     }
   }
+  // UNOBSERVED REGIONS.  A strip that runs along the edge of a region is in "holes" mode on every row -- 2.6x the time of a
+  // clean strip --, and with one strip per resident slot the pass lasts as long as its slowest strip: 0.34-0.41 ms against
+  // 0.16 with 5-20 % of the bench map unobserved, most of the device idle for the second half.  With strips of 32 rows there
+  // are three times as many blocks as slots, the hardware hands them out as slots free up, and the pass takes 0.23-0.30 ms
+  // (profiles/r05_experiments.json, exp13: 64 / 47 / 32 / 24 rows 0.274 / 0.247 / 0.232 / 0.229 ms at 5 %; scattered invalid
+  // cells -- 1 % speckle, every strip alike -- neither gain nor lose: 0.425 -> 0.428).  Only when the upload counted invalid
+  // cells and the dense march serves them (Layers::short_strips): a clean map would pay the extra strip starts for nothing.
+  if (a.short_strips && !slim && a.n_ties == 0 && fits && rows_int > kN3ShortStripRows) rows_int = kN3ShortStripRows;
   static const int rows_env = lab_int("TE_N3_STRIP_ROWS", 0);  // measurement aid
   if (rows_env > 0) rows_int = rows_env;
   a.rows_int = rows_int;
@@ -1360,6 +1412,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.sparse_holes = L.sparse_holes && L.hole_queue ? 1 : 0;
   a.no_holes = L.no_holes;
   a.skip_clean = L.skip_clean;
+  a.short_strips = L.short_strips;
   a.hole_queue = L.hole_queue;
   a.SIIi = (int)sii;
   a.K1h = 0.5 * N * g.res * g.res * (double)sii;

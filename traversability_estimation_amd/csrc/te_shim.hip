@@ -115,14 +115,25 @@ bool same_disc(const Disc& a, const Disc& b) {
 
 }  // namespace
 
-// Invalid (non-finite) cells of a layer: one pass at upload time.  The count picks the march k_normals3 uses for strips
-// with invalid cells (sparse speckle vs unobserved regions, te_normals3.hip).
+// Invalid (non-finite) cells of a layer: one pass at upload time.  out[0]: their number; out[1]: the number of RUNS of them
+// in memory order (an invalid cell whose predecessor is valid, or that is the layer's first).  The two pick the march
+// k_normals3 uses for strips with invalid cells and its strip height: scattered cells (runs of one) against unobserved
+// regions (runs as long as the regions are wide), te_normals3.hip.
 __global__ void k_count_invalid(const float* __restrict__ v, size_t n, unsigned long long* __restrict__ out) {
-  unsigned cnt = 0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
-    cnt += __builtin_isfinite(v[k]) ? 0u : 1u;
-  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor((int)cnt, d);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
+  unsigned cnt = 0, runs = 0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+    const bool bad = !__builtin_isfinite(v[k]);
+    cnt += bad ? 1u : 0u;
+    runs += (bad && (k == 0 || __builtin_isfinite(v[k - 1]))) ? 1u : 0u;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    cnt += __shfl_xor((int)cnt, d);
+    runs += __shfl_xor((int)runs, d);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicAdd(out, (unsigned long long)cnt);
+    if (runs) atomicAdd(out + 1, (unsigned long long)runs);
+  }
 }
 
 struct te_ctx {
@@ -162,6 +173,7 @@ struct te_ctx {
   int opt_fb_walk = 0, opt_fb_blocks_per_cu = 0, opt_polygon_per_cell = 0;
   // invalid cells of the elevation layer as of the last whole upload (-1: unknown -- tiles, device pointer): see sparse_holes()
   long long invalid_cells = -1;
+  long long invalid_runs = -1;  // runs of invalid cells in memory order (k_count_invalid); meaningful with invalid_cells >= 0
   unsigned long long* d_count = nullptr;
   char* hole_queue = nullptr;  // scratch of k_normals3's sparse-hole march (allocated when a launch first picks it)
   float* tie_scratch = nullptr;  // one float per cell: the step filter at a tie radius (allocated when a launch first needs it, freed with the layers)
@@ -205,6 +217,7 @@ struct te_ctx {
 };
 
 namespace {
+int count_invalid_elevation(te_ctx* c);
 // joins a running prefetch (caller holds c->mu); its result stays in c->prefetch_rc until te_wait_prefetch reports it
 void finish_prefetch_locked(te_ctx* c) {
   {
@@ -214,9 +227,14 @@ void finish_prefetch_locked(te_ctx* c) {
   }
   if (c->prefetch_elev && c->prefetch_rc.load() == TE_OK) {
     c->have_elev = true;
-    c->invalid_cells = -1;  // (not counted: the dense-hole march serves, like after tile uploads)
     c->chain_done = false;
     c->footprint_done = false;
+    // the invalid cells are counted like te_upload_elevation counts them (the count picks the normals kernel's march and
+    // strip height); a failure leaves the count unknown, which every kernel serves
+    if (hipSetDevice(c->device) != hipSuccess || count_invalid_elevation(c) != TE_OK) {
+      (void)hipGetLastError();
+      c->invalid_cells = -1;
+    }
   }
   c->prefetch_elev = false;
 }
@@ -235,16 +253,17 @@ namespace {
 // counts the invalid cells of the whole elevation layer on the context's stream and waits for the result
 int count_invalid_elevation(te_ctx* c) {
   c->invalid_cells = -1;
-  if (!c->d_count) HIP_TRY(hipMalloc((void**)&c->d_count, sizeof(unsigned long long)));
-  HIP_TRY(hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), c->stream));
+  if (!c->d_count) HIP_TRY(hipMalloc((void**)&c->d_count, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(c->d_count, 0, 2 * sizeof(unsigned long long), c->stream));
   const size_t n = c->layer_elems;
   int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(k_count_invalid, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->L.elev, n, c->d_count);
-  unsigned long long h = 0;
-  HIP_TRY(hipMemcpyAsync(&h, c->d_count, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  unsigned long long h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, c->d_count, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  c->invalid_cells = (long long)h;
+  c->invalid_cells = (long long)h[0];
+  c->invalid_runs = (long long)h[1];
   return TE_OK;
 }
 
@@ -252,10 +271,16 @@ int count_invalid_elevation(te_ctx* c) {
 // at 1 % 1.4x slower; MI355X, 4096^2, R = 9).  Unknown counts take the dense march, whose cost does not depend on the map.
 // (A map without invalid cells takes the dense kernel too: its clean march is the same code, and a tile with invalid
 // cells uploaded later -- tiles are not counted -- is then in safe hands.)
+// Unobserved REGIONS rather than scattered cells: the invalid cells come in runs of eight and more on average (speckle: runs
+// of one; a region 100 cells wide: runs of 100).
+bool clustered_holes(const te_ctx* c) {
+  return c->invalid_cells > 0 && c->invalid_runs >= 0 && c->invalid_runs * 8 <= c->invalid_cells;
+}
 bool sparse_holes(const te_ctx* c) {
   static const int force = lab_int("TE_N3_HOLES", 0);  // measurement aid: 1 sparse, 2 dense
   if (force == 1 || force == 2) return force == 1;
-  return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems;
+  // (a region, however small: the sparse march walks every invalid cell of a disc -- 5x the dense march inside a region)
+  return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems && !clustered_holes(c);
 }
 
 // Sparse holes, and so many of them that hardly a strip is free of them (a strip's window is some 8 000 cells: from three
@@ -267,6 +292,16 @@ bool skip_clean_march(const te_ctx* c) {
   return false;
 #endif
   return sparse_holes(c) && (double)c->invalid_cells * 8000.0 >= 3.0 * (double)c->layer_elems;
+}
+
+// Unobserved regions (counted at upload): the dense march on short strips (Layers::short_strips).  Scattered invalid cells
+// keep the long strips -- every strip costs alike there, and the extra strip starts and the second round of blocks cost
+// the launch 10 % (1 % speckle: 0.61 -> 0.69 ms) --, and so does an unknown count (tile uploads): a map without invalid
+// cells would pay for nothing.
+bool short_strips(const te_ctx* c) {
+  static const int force = lab_int("TE_N3_SHORT_STRIPS", -1);  // measurement aid: 0 never, 1 whenever invalid cells were counted
+  if (force >= 0) return force == 1 && c->invalid_cells > 0 && !sparse_holes(c);
+  return clustered_holes(c) && !sparse_holes(c);
 }
 
 // the sparse march's queues; false (and the dense kernel) if the allocation fails
@@ -579,6 +614,7 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.sparse_holes = sparse_holes(c) && ensure_hole_queue(c) ? 1 : 0;  // (run_whole_locked allocates before it captures)
   c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
   c->L.skip_clean = c->L.sparse_holes && skip_clean_march(c) ? 1 : 0;
+  c->L.short_strips = short_strips(c) ? 1 : 0;
   c->L.hole_queue = c->hole_queue;
   ensure_tie_scratch(c);  // (likewise)
   c->L.tie_scratch = c->tie_scratch;
@@ -626,7 +662,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
     int slot = -1;
     // (the captured launches bake in which k_normals3 variant runs: the hint is part of the key)
     ensure_tie_scratch(c);
-    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u) | (c->invalid_cells == 0 ? 0x40000000u : 0u) | (skip_clean_march(c) ? 0x20000000u : 0u);
+    const unsigned key = flags | (sparse_holes(c) && ensure_hole_queue(c) ? 0x80000000u : 0u) | (c->invalid_cells == 0 ? 0x40000000u : 0u) | (skip_clean_march(c) ? 0x20000000u : 0u) | (short_strips(c) ? 0x10000000u : 0u);
     for (int k = 0; k < te_ctx::kGraphs; ++k)
       if (c->graph_exec[k] && c->graph_flags[k] == key) slot = k;
     if (slot < 0) {
@@ -1351,6 +1387,7 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   c->L.hole_queue = c->hole_queue;
   c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
   c->L.skip_clean = c->L.sparse_holes && skip_clean_march(c) ? 1 : 0;
+  c->L.short_strips = short_strips(c) ? 1 : 0;
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
   // A single plugin's filter overwrites score layers from whatever inputs are resident (TE_FILTER_NORMALS also slope
   // and roughness, with the normals radius): the layers no longer form one chain result, so region re-filters, the
