@@ -54,7 +54,8 @@ def draw_case(seed):
         elev = synth.with_holes(elev, float(rng.choice([0.002, 0.02, 0.2])), seed=seed + 2)
     elif hole < 0.5 and rows > 20 and cols > 20:  # a solid unobserved region
         a, b = int(rng.integers(0, rows - 10)), int(rng.integers(0, cols - 10))
-        elev[b:b + int(rng.integers(5, 40)), a:a + int(rng.integers(5, 40))] = np.nan
+        lim = 40 if max(rows, cols) < 260 else 240  # (large maps: regions wider than a strip's window -- the steps with an empty ring)
+        elev[b:b + int(rng.integers(5, lim)), a:a + int(rng.integers(5, lim))] = np.nan
     pos = (float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20)))
     return rows, cols, res, pos, elev, over
 

@@ -1024,6 +1024,8 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
         store_row();
         ++j;
       });
+      // (looking at the queue inside the last step of the chunk, before that step's row prefetch is issued -- so that the
+      // flush's fence does not wait for a load just sent -- changed nothing: 0.3229 / 0.3257 ms, tools/lab/r05_exp17.sh)
       if constexpr (HOLES == 1 && !GENERAL && !KEEP)
         while (qtail - qhead >= (unsigned)kLanes) flush_queue(kLanes);
       if (!done) rotate();
