@@ -127,8 +127,9 @@ typedef float __attribute__((address_space(1))) gfloat;
 // clipped) disc from the table and the general tail -- the blocks of the first / last block column and of the top / bottom
 // frame rows; otherwise every disc of the block lies inside the map and the closed-form tail is used.
 // HOLES (0 / 1 / 2): how the march deals with invalid cells.
-//   0: not at all -- it gives up at the first invalid cell it stages and returns false; the kernel then runs the strip
-//      again with HOLES = 1.
+//   0: not at all -- it stops at the first invalid cell it stages and returns the row it had reached (every row before it
+//      is finished); the kernel runs the rest of the strip with HOLES = 1 or 2.  (Rounds 3-4 started the strip again:
+//      with 0.01-0.03 % speckle a third of the pass, 0.28 -> 0.22-0.25 ms.)
 //   1: SPARSE holes.  Every ring row carries a bit mask of its invalid cells (hm); a disc that holds such a row subtracts
 //      the x/y moments of the invalid cells it contains from those of the full (or clipped) disc and takes the general
 //      tail.  The work is proportional to the dirty rows in the disc and the invalid cells in them: with 0.1 % speckle
@@ -138,8 +139,11 @@ typedef float __attribute__((address_space(1))) gfloat;
 //      allocates registers for the union, 168 + scratch instead of 151).
 //   2: DENSE holes.  Invalid cells are held in the ring as a marker value and the six x/y moments of the VALID cells are
 //      slid like the z-moments while a dirty row is in the ring (about 240 integer operations per row, whatever the
-//      number of holes).  A clean strip -- the common case by
-// far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
+//      number of holes).  Inside an unobserved region -- not one cell in the window of the ring's rows -- a step has nothing
+//      to compute and only stages the next row (void_step below).  With counted REGIONS the launch cuts the map into strips
+//      of 32 rows (launch3, Layers::short_strips): a strip along a region's edge costs 2.6x a clean one, and the pass lasted
+//      as long as its slowest strip.
+// A clean strip -- the common case by far -- thus runs code that contains nothing of the hole handling: kept in one loop behind run-time tests it cost the
 // clean map 8 % (the compiler merges what the two kinds of step have in common into a maze of conditional regions).
 // SLIM (clean march of a shape whose centre column alone reaches rows j +- R, i.e. hw(1) < R -- the radii just above a
 // whole number of cells, the bench's 9.000009 among them): the ring holds the 2R rows j-R+1 .. j+R only.  The two cells

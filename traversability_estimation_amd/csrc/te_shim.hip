@@ -285,8 +285,8 @@ bool sparse_holes(const te_ctx* c) {
 
 // Sparse holes, and so many of them that hardly a strip is free of them (a strip's window is some 8 000 cells: from three
 // expected invalid cells per window on): k_normals3's clean first attempt would be given up within its first rows on
-// nearly every strip (0.1 % speckle: 99.99 % of them) -- it is skipped.  (Clustered holes -- unobserved regions -- take the
-// dense march by their count and keep the attempt: most of their strips ARE clean.)
+// nearly every strip (0.1 % speckle: 99.99 % of them) -- it is skipped.  (Unobserved regions take the dense march -- by
+// their run count, clustered_holes -- and keep the attempt: most of their strips ARE clean.)
 bool skip_clean_march(const te_ctx* c) {
 #ifdef TE_NO_SKIP_CLEAN  // (A/B builds only)
   return false;
