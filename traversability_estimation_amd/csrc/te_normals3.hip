@@ -455,50 +455,84 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
   };
   // ---- tie radii (TIES march, clean strips): the moments of the shape with its circle minus the circle cells that
   // isInside() rejects for this centre, general tail.  A strip with an invalid cell is left to the fix-up pass whole.
-  unsigned long long xfail_p = 0ull, xfail_m = 0ull;  // lanes for which (icol + R, j) / (icol - R, j) is rejected: dy = 0, the same for every j
+  // (+-R, 0): dy = 0, the decision is the same for every row -- taken once per lane, with its share of the x/y moments
+  bool xf_p = false, xf_m = false;
+  int xn = 0, xsi = 0, xsii = 0;
+  int n0 = 0, si0 = 0, sj0 = 0, sii0 = 0, sij0 = 0, sjj0 = 0;  // interior blocks: the moments of the unclipped shape (one table entry)
   if constexpr (TIES) {
     const double xi = a.ax + a.res * (double)(-icol);  // cell_x (te_geom.h)
     const double dxp = (a.ax + a.res * (double)(-(icol + R))) - xi, dxm = (a.ax + a.res * (double)(-(icol - R))) - xi;
-    xfail_p = __ballot(!(dxp * dxp + 0.0 <= a.r2) && icol + R < a.rows);
-    xfail_m = __ballot(!(dxm * dxm + 0.0 <= a.r2) && icol - R >= 0);
+    xf_p = !(dxp * dxp + 0.0 <= a.r2) && icol + R < a.rows;
+    xf_m = !(dxm * dxm + 0.0 <= a.r2) && icol - R >= 0;
+    xn = (xf_p ? 1 : 0) + (xf_m ? 1 : 0);
+    xsi = (xf_p ? R : 0) - (xf_m ? R : 0);
+    xsii = R * R * xn;
+    if constexpr (!GENERAL) {
+      const int* gt = a.gtab + (R * (2 * R + 1) + R) * 6;
+      n0 = gt[0]; si0 = gt[1]; sj0 = gt[2]; sii0 = gt[3]; sij0 = gt[4]; sjj0 = gt[5];
+    }
   }
   auto tail_ties = [&](int j, int ky, auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
-    const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
-    auto zat = [&](int di, int dj) __attribute__((always_inline)) {
-      int sl = slot0 + dj + R;
-      sl = sl >= NR ? sl - NR : sl;
-      sl = sl >= NR ? sl - NR : sl;
-      return ring[sl * W + lane + R + di];
+    constexpr int pc = u + R;  // ring position of map row j
+    // my window's cell (di, row at ring position p): chunk base register + immediate, like the slide's reads
+    auto cell = [&](auto pst, auto dst) __attribute__((always_inline)) {
+      constexpr int p = decltype(pst)::value, di = decltype(dst)::value;
+      return *reinterpret_cast<const double*>(ringb + vb[(p / C) % NC] + ((p % C) * RB + (R + di) * 8));
     };
-    const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
-    int n = gt[0], si = gt[1], sj = gt[2], sii = gt[3], sij = gt[4], sjj = gt[5];
-    double lSz = Sz, lSiz = Siz, lSjz = Sjz, lSzz = Szz;
-    auto take_out = [&](bool fail, int di, int dj, double z) __attribute__((always_inline)) {  // fail: rejected and inside the map
-      n -= fail ? 1 : 0;
-      si -= fail ? di : 0;
-      sj -= fail ? dj : 0;
-      sii -= fail ? di * di : 0;
-      sij -= fail ? di * dj : 0;
-      sjj -= fail ? dj * dj : 0;
-      const double zz = fail ? z : 0.0;
-      lSz -= zz;
-      lSiz = fma(-(double)di, zz, lSiz);
-      lSjz = fma(-(double)dj, zz, lSjz);
-      lSzz = fma(-zz, zz, lSzz);
-    };
-    take_out(((xfail_p >> lane) & 1ull) != 0ull, R, 0, zat(R, 0));
-    take_out(((xfail_m >> lane) & 1ull) != 0ull, -R, 0, zat(-R, 0));
+    typedef std::integral_constant<int, R> RP;
+    typedef std::integral_constant<int, -R> RM;
+    typedef std::integral_constant<int, 0> Z0;
+    int n, si, sj, sii, sij, sjj;
+    if constexpr (GENERAL) {
+      const int* gt = a.gtab + ((ky + R) * (2 * R + 1) + (kx + R)) * 6;
+      n = gt[0]; si = gt[1]; sj = gt[2]; sii = gt[3]; sij = gt[4]; sjj = gt[5];
+    } else {
+      n = n0; si = si0; sj = sj0; sii = sii0; sij = sij0; sjj = sjj0;
+    }
+    n -= xn;
+    si -= xsi;
+    sii -= xsii;
+    const double zp = xf_p ? cell(std::integral_constant<int, pc>{}, RP{}) : 0.0;
+    const double zm = xf_m ? cell(std::integral_constant<int, pc>{}, RM{}) : 0.0;
+    double lSz = (Sz - zp) - zm;
+    double lSiz = fma((double)R, zm, fma(-(double)R, zp, Siz));
+    double lSjz = Sjz;
+    double lSzz = fma(-zm, zm, fma(-zp, zp, Szz));
+    // (0, +-R): dx = 0, the same answer for every lane (uniform branches)
     const double yj = a.ay + a.res * (double)(-j);  // cell_y
-#pragma unroll
-    for (int sgn = -1; sgn <= 1; sgn += 2) {  // (0, +-R): dx = 0, the same answer for every lane
-      const int jj = j + sgn * R;
-      if ((unsigned)jj < (unsigned)a.cols) {
+    {
+      const int jj = j - R;
+      if (jj >= 0) {
         const double dy = (a.ay + a.res * (double)(-jj)) - yj;
-        if (!(0.0 + dy * dy <= a.r2)) take_out(true, 0, sgn * R, zat(0, sgn * R));
+        if (!(0.0 + dy * dy <= a.r2)) {
+          const double z = cell(std::integral_constant<int, pc - R>{}, Z0{});
+          n -= 1;
+          sj += R;
+          sjj -= R * R;
+          lSz -= z;
+          lSjz = fma((double)R, z, lSjz);
+          lSzz = fma(-z, z, lSzz);
+        }
       }
     }
-    if (a.n_gen != 0) {
+    {
+      const int jj = j + R;
+      if (jj < a.cols) {
+        const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+        if (!(0.0 + dy * dy <= a.r2)) {
+          const double z = cell(std::integral_constant<int, pc + R>{}, Z0{});
+          n -= 1;
+          sj -= R;
+          sjj -= R * R;
+          lSz -= z;
+          lSjz = fma(-(double)R, z, lSjz);
+          lSzz = fma(-z, z, lSzz);
+        }
+      }
+    }
+    if (a.n_gen != 0) {  // the other circle cells (3-4-5 radii): both coordinates decide, cell by cell
+      const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
       const double xi = a.ax + a.res * (double)(-icol);
 #pragma unroll 1
       for (int t = 0; t < a.n_gen; ++t) {
@@ -506,7 +540,20 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
         const int di = (int)(signed char)(e & 0xff), dj = (int)(signed char)((e >> 8) & 0xff);
         const double dx = (a.ax + a.res * (double)(-(icol + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
         const bool fail = !(dx * dx + dy * dy <= a.r2) && (unsigned)(icol + di) < (unsigned)a.rows && (unsigned)(j + dj) < (unsigned)a.cols;
-        take_out(fail, di, dj, zat(di, dj));
+        int sl = slot0 + dj + R;
+        sl = sl >= NR ? sl - NR : sl;
+        sl = sl >= NR ? sl - NR : sl;
+        const double zz = fail ? ring[sl * W + lane + R + di] : 0.0;
+        n -= fail ? 1 : 0;
+        si -= fail ? di : 0;
+        sj -= fail ? dj : 0;
+        sii -= fail ? di * di : 0;
+        sij -= fail ? di * dj : 0;
+        sjj -= fail ? dj * dj : 0;
+        lSz -= zz;
+        lSiz = fma(-(double)di, zz, lSiz);
+        lSjz = fma(-(double)dj, zz, lSjz);
+        lSzz = fma(-zz, zz, lSzz);
       }
     }
     double qs = 0.0;
