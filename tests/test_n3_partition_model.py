@@ -141,3 +141,29 @@ def test_short_strips_only_shorten():
         assert b["rows_int"] <= a["rows_int"] and b["nblocks"] >= a["nblocks"]
         if a["rows_int"] <= SHORT:
             assert a == b
+
+
+@pytest.mark.parametrize("R", [1, 2, 5, 9, 10])
+@pytest.mark.parametrize("slim", [False, True])
+def test_clean_march_hands_over_at_a_finished_row(R, slim):
+    """march3<HOLES = 0>: the rows it stages before it stops (the first window, then row j + LEAD + R in the step of row
+    j) and the row it returns, for every position of the first dirty row: every row below the returned one was finished
+    with a disc that holds no dirty row, and the march does not stop earlier than the staging makes it."""
+    js, jend = 40, 40 + 37
+    lead = 1 if slim else 2
+    first_window = range(js - R, js + R + 1) if slim else range(js - R, js + R + 2)  # (SLIM: row js - R is the lane's own cell, read apart)
+    for dirty in range(js - R - 3, jend + R + 4):
+        if dirty in first_window:
+            ret = js
+        else:
+            ret, j = jend, js
+            while j < jend:
+                staged = j + lead + R   # tail(j), slide, stage_row(staged), store_row, ++j
+                j += 1
+                if staged == dirty and j < jend:
+                    ret = j
+                    break
+        for r in range(js, ret):  # finished by the clean march: closed form, no invalid cell may be in the disc
+            assert not (r - R <= dirty <= r + R), (dirty, r, ret)
+        if ret < jend:            # ... and the row it hands over is the first one the dirty row can matter to, or one before
+            assert ret + R >= dirty - 1
