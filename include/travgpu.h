@@ -204,8 +204,9 @@ int te_upload_layer(te_ctx* ctx, int layer, const float* host, int map0, int nma
  * once; a thread of the library stages the buffers through a second ring of page-locked slots.  Until te_wait_prefetch
  * returns, the host buffers must stay valid and the named device layers must not be used: only te_run_filter on OTHER
  * layers, te_download_layer(_circular), te_get_params / te_set_params may be called in between -- every other entry point
- * finishes the prefetch first.  A prefetched elevation layer is not scanned for invalid cells (the chain then takes the
- * dense-hole march, as after te_upload_tile).  n <= 8. */
+ * finishes the prefetch first.  A prefetched elevation layer is scanned for invalid cells when the prefetch is joined (one
+ * short kernel on the context's stream and a wait for its two counters, as te_upload_elevation does): the count and the
+ * run count pick the normals kernel's march and strip height (hole-free, scattered cells, unobserved regions).  n <= 8. */
 int te_prefetch_layers(te_ctx* ctx, int n, const int* layers, const float* const* hosts);
 int te_wait_prefetch(te_ctx* ctx);
 int te_upload_layer_circular(te_ctx* ctx, int layer, const float* host, int map, int start_row, int start_col);
