@@ -18,8 +18,11 @@ alone the same way (12 B/cell); `roofline_issue` prices the same launch against 
 issue rate, which is what bounds these kernels.
 `cpu_baseline` times the CPU oracle (our restatement of the reference; kind "port") on one host thread
 over a bounded crop of the same map; `cpu_baseline_all_cores` the same oracle with OpenMP over rows on every host core.
-`parity_check` (every run, rank 0): the layers the timed launches left on the device are compared with the oracle on a
-corner crop and on one full-width band of the map; a mismatch fails the run (exit code 1) after the line is printed.
+`parity_check` (every run, rank 0): the layers the timed launches left on the device are compared with the oracle on EVERY
+cell of the map (up to 4096^2; `--check-crops`: a corner crop and one full-width band); a mismatch fails the run (exit
+code 1) after the line is printed.
+`ranks`: how many ranks ran, over which backend, on which device each.  `--gpus N` without a launcher starts the N ranks
+itself (torch.distributed.run, one per GPU); a WORLD_SIZE that differs from --gpus is an error.
 
 Order of the run: upload -> event-timed samples of the launch (they also bring the GPU to its working clocks) -> W
 warm-up steps -> barrier + sync -> K timed steps -> sync + barrier -> parity check -> host path -> CPU baselines.
@@ -216,13 +219,24 @@ def main():
     from traversability_estimation_amd import capi, synth
 
     from traversability_estimation_amd import dist as tdist
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same command
+    # line under torch.distributed.run) -- a single process must never report an N-GPU figure
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(tdist.relaunch_under_torchrun(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     # TE_DIST_BACKEND=gloo lets a 1-GPU box exercise the N>1 code path (ranks then share device 0)
-    rank, world, local_rank = tdist.init_process_group(os.environ.get("TE_DIST_BACKEND"))
-    local_rank %= max(1, torch.cuda.device_count())
+    backend_req = os.environ.get("TE_DIST_BACKEND")
+    n_dev = torch.cuda.device_count()
+    if args.gpus > max(1, n_dev) and (backend_req or "nccl") == "nccl":
+        sys.exit(f"bench.py: --gpus {args.gpus} but this node has {n_dev} GPU(s): RCCL needs one device per rank "
+                 "(TE_DIST_BACKEND=gloo lets the ranks share a device to exercise the code path; it is not a scaling figure)")
+    rank, world, local_rank = tdist.init_process_group(backend_req)
+    local_rank %= max(1, n_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 "(or without a launcher: bench.py starts its own ranks)")
     torch.cuda.set_device(local_rank)
     capi.load()
 
@@ -260,6 +274,7 @@ def main():
                     r0, c0 = int(rng.integers(0, n - h)), int(rng.integers(0, n - w))
                     elevs[b][c0:c0 + w, r0:r0 + h] = np.nan
                     area += h * w
+    ranks = tdist.ranks_report(local_rank)  # (collective: every rank calls it)
     ctx = capi.Context(local_rank)
     ctx.set_params(p)
     ctx.set_geometry(n, n, B, args.res)
@@ -411,6 +426,7 @@ def main():
             "value": cells_per_step * args.steps / dt,
             "unit": "cells/s",
             "n_gpus": world,
+            "ranks": ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -71,3 +71,45 @@ def test_shard_ranges_partition_the_batch():
             assert all(spans[k][1] == spans[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+LAUNCHED = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["TE_ROOT"])
+from traversability_estimation_amd import dist
+if "WORLD_SIZE" not in os.environ:  # first entry: no launcher -> start the ranks, as bench.py --gpus N does
+    sys.exit(dist.relaunch_under_torchrun(int(sys.argv[1]), [os.path.abspath(__file__)] + sys.argv[1:]))
+rank, world, local_rank = dist.init_process_group("gloo")
+rep = dist.ranks_report(10 + local_rank)
+if rank == 0:
+    open(os.environ["TE_OUT"], "w").write(json.dumps(rep))
+dist.barrier()
+'''
+
+
+def test_a_script_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """bench.py --gpus N under plain `python`: N processes must run and the report must say so."""
+    import json
+    out = tmp_path / "ranks.json"
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TE_ROOT=ROOT, TE_OUT=str(out))
+    r = subprocess.run([sys.executable, str(script), "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rep = json.loads(out.read_text())
+    assert rep == {"world": 3, "backend": "gloo", "devices": [10, 11, 12]}
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """A launcher that started another number of ranks than --gpus says is an error, never a silent 1-rank figure."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", TE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+    # and RCCL ranks need a device each: two ranks on a node with fewer GPUs is refused before anything is measured
+    env = {k: v for k, v in os.environ.items() if k not in ("TE_DIST_BACKEND",)}
+    env.update(WORLD_SIZE="64", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "one device per rank" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]

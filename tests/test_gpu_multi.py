@@ -140,3 +140,26 @@ def test_bcast_params_across_devices_over_rccl(capi):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks(capi):
+    """`python bench.py --gpus 2` with no torchrun around it (the driver's plain form) must start two ranks itself and say so
+    in the line; on a one-GPU box the two gloo ranks share device 0 (TE_DIST_BACKEND=gloo), on a node with >= 2 GPUs the
+    same command runs over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    rccl = capi.device_count() >= 2
+    if not rccl:
+        env["TE_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--check-crops"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"]["world"] == 2
+    assert line["ranks"]["backend"] == ("nccl" if rccl else "gloo")
+    assert line["ranks"]["devices"] == ([0, 1] if rccl else [0, 0])
+    assert line["scaling"] == "weak" and line["parity_check"]["ok"]
+    # two maps of 4096^2 went through the chain per step
+    assert abs(line["value"] - 2 * 4096 * 4096 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-6 * line["value"]

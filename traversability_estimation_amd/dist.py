@@ -32,6 +32,37 @@ def init_process_group(backend=None):
     return rank, world, local_rank
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_under_torchrun(n_ranks, argv):
+    """Start `argv` (script + arguments) as n_ranks processes of ONE node under torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1; returns the launcher's exit code.  What `python bench.py --gpus N` does when no launcher set
+    WORLD_SIZE."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_report(device_index):
+    """{"world", "backend", "devices": [device index of every rank, gathered]} -- what the bench line carries so that a
+    reader can see how many ranks ran and where."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {"world": 1, "backend": None, "devices": [int(device_index)]}
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, int(device_index))
+    return {"world": dist.get_world_size(), "backend": str(dist.get_backend()), "devices": [int(v) for v in got]}
+
+
 def _device():
     import torch
     import torch.distributed as dist
