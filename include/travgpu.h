@@ -197,20 +197,23 @@ int te_upload_layer(te_ctx* ctx, int layer, const float* host, int map0, int nma
  * (j + start_col) % cols) (grid_map_core getBufferIndexFromIndex; start index = GridMap::getStartIndex(), non-zero after
  * GridMap::move).  The reference's filters see maps in this form: their iterators (StepFilter.cpp:112,124) hide the
  * start index.  The device layers are always in logical order. */
+int te_upload_layer_circular(te_ctx* ctx, int layer, const float* host, int map, int start_row, int start_col);
+int te_download_layer_circular(te_ctx* ctx, int layer, float* host, int map, int start_row, int start_col);
 /* Whole-layer uploads (all maps of the batch) that run BESIDE the calls that follow: the reference's FilterChain hands every
  * plugin the whole map (SlopeFilter.cpp:62-63, StepFilter.cpp:105-107, RoughnessFilter.cpp:76-77), so a plugin knows which
  * layers its successors will read (StepFilter: elevation; RoughnessFilter: elevation + surface_normal_{x,y,z}) and can send
  * them host -> device while its own filter runs and its output crosses device -> host -- PCIe is full duplex.  Returns at
  * once; a thread of the library stages the buffers through a second ring of page-locked slots.  Until te_wait_prefetch
- * returns, the host buffers must stay valid and the named device layers must not be used: only te_run_filter on OTHER
- * layers, te_download_layer(_circular), te_get_params / te_set_params may be called in between -- every other entry point
- * finishes the prefetch first.  A prefetched elevation layer is scanned for invalid cells when the prefetch is joined (one
+ * returns the host buffers must stay valid.  te_run_filter, te_download_layer(_circular), te_get_params / te_set_params
+ * run BESIDE a prefetch in flight as long as they neither read nor write one of its layers; a call that does (e.g.
+ * TE_FILTER_STEP beside an elevation prefetch, a download of a prefetched layer) and every other entry point finish the
+ * prefetch first -- no call ever sees a half-written layer.  A prefetch that failed leaves its layers undefined:
+ * te_wait_prefetch reports it, and an elevation layer among them must be uploaded again before the next chain
+ * (TE_ERR_NOT_READY until then).  A prefetched elevation layer is scanned for invalid cells when the prefetch is joined (one
  * short kernel on the context's stream and a wait for its two counters, as te_upload_elevation does): the count and the
  * run count pick the normals kernel's march and strip height (hole-free, scattered cells, unobserved regions).  n <= 8. */
 int te_prefetch_layers(te_ctx* ctx, int n, const int* layers, const float* const* hosts);
 int te_wait_prefetch(te_ctx* ctx);
-int te_upload_layer_circular(te_ctx* ctx, int layer, const float* host, int map, int start_row, int start_col);
-int te_download_layer_circular(te_ctx* ctx, int layer, float* host, int map, int start_row, int start_col);
 /* Run ONE of the reference's plugins on the resident layers (see te_filter). */
 int te_run_filter(te_ctx* ctx, int filter, unsigned flags);
 int te_run_chain(te_ctx* ctx, unsigned flags);

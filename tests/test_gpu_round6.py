@@ -1,0 +1,106 @@
+"""Round 6: the shapes the reference's DEFAULT parameters take at common map resolutions, through the C-ABI against the oracle.
+
+robot_filter_parameter.yaml has normals / roughness radius 0.05 m and step windows 0.04 m.  On a 0.05 m map the 0.05 m radius is a
+TIE radius of exactly ONE cell -- the runs hold the centre alone, the four edge neighbours lie on the circle and are kept or
+dropped centre by centre by the rounding of the positions (CircleIterator::isInside) -- and the step windows hold one cell; on a
+0.04 m map the step windows are the one-cell tie and the normals disc is the 5-point one.  Rounds 1-5 served a one-cell tie
+radius with the generic kernels (k_normals: 0.99 ms on 4096^2 against 0.09 ms for the neighbouring tie-free shape)."""
+import numpy as np
+import pytest
+
+from tests.helpers import OUT_LAYERS, assert_layers_match, to_te_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from traversability_estimation_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1
+    return capi
+
+
+def _map(synth, rows, cols, seed, boxes=8, holes=False):
+    e = synth.with_steps(synth.perlin_elevation(rows, cols, seed=seed, amplitude=0.12), boxes, seed=seed + 7)
+    if holes:
+        e = synth.with_holes(e, 0.004, seed=seed + 1)
+        e[cols // 2:cols // 2 + 5, 30:70] = np.nan
+    return e
+
+
+@pytest.mark.parametrize("res,origin,holes,keep", [(0.05, (0.0, 0.0), False, False), (0.05, (1.5, -2.0), True, False), (0.05, (12.3, -7.7), False, True),
+                                                   (0.04, (0.0, 0.0), False, False), (0.04, (-3.17, 8.4), True, False), (0.1, (0.35, 0.05), True, True),
+                                                   (0.025, (0.0, 0.0), False, False)])
+def test_default_yaml_radii_on_maps_where_they_are_one_cell_ties(capi, oracle, res, origin, holes, keep):
+    """Default parameters, map resolutions that make 0.05 m / 0.04 m exactly one cell (res 0.05: normals + roughness; res
+    0.04: the step windows; res 0.025: two cells; res 0.1: neither) -- k_normals3<1, .., TIES>, k_step_*_ties<CENTRE>."""
+    from traversability_estimation_amd import synth
+    rows, cols = 330, 210
+    elev = _map(synth, rows, cols, 900 + int(res * 1000), holes=holes)
+    op = oracle.default_params()
+    g = oracle.geom(rows, cols, res, origin)
+    want = oracle.chain(g, op, elev, want_normals=keep)
+    want["traversability_footprint"] = oracle.footprint(g, op, elev, want)
+    layers = list(OUT_LAYERS) + ["traversability_footprint"] + (["surface_normal_x", "surface_normal_y", "surface_normal_z"] if keep else [])
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, origin)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT | (capi.RUN_KEEP_NORMALS if keep else 0))
+        ctx.sync()
+        got = {k: ctx.download(k) for k in layers}
+    assert_layers_match(got, want, layers=layers, ctx=f"default YAML at res {res}, origin {origin}")
+
+
+def test_one_cell_tie_radius_on_a_batch_and_a_region(capi, oracle):
+    """The same one-cell tie shapes on a batch of maps (blockIdx.z) and through te_run_chain_region after a tile changed."""
+    from traversability_estimation_amd import synth
+    rows, cols, res, B = 256, 192, 0.05, 3
+    elevs = np.stack([_map(synth, rows, cols, 40 + b, holes=(b == 1)) for b in range(B)])
+    op = oracle.default_params(step_radius1=0.05, step_radius2=0.05)  # (all four radii one cell)
+    g = oracle.geom(rows, cols, res, (0.7, 0.2))
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, B, res, (0.7, 0.2))
+        ctx.upload_elevation(elevs)
+        ctx.run_chain(0)
+        ctx.sync()
+        per = rows * cols
+        for b in range(B):
+            want = oracle.chain(g, op, elevs[b])
+            got = {k: ctx.download(k)[b * per:(b + 1) * per] for k in OUT_LAYERS}
+            assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx=f"batch map {b}")
+        # a dirty tile in map 2
+        tile = (elevs[2][60:124, 100:164] + 0.07).astype(np.float32)
+        elevs[2][60:124, 100:164] = tile
+        ctx.upload_tile(np.ascontiguousarray(tile), 2, 100, 60)
+        ctx.run_chain_region(2, 100, 60, 64, 64)
+        ctx.sync()
+        want = oracle.chain(g, op, elevs[2])
+        got = {k: ctx.download(k)[2 * per:3 * per] for k in OUT_LAYERS}
+        assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx="region run after a dirty tile")
+
+
+def test_whole_1024_map_default_yaml_res_005_against_the_oracle(capi, oracle):
+    """Every cell of a 1024^2 map at res 0.05 with the default parameters (one-cell tie normals, footprint radius 0.45 m = 9 cells)."""
+    from traversability_estimation_amd import synth
+    n, res = 1024, 0.05
+    elev = synth.with_steps(synth.perlin_elevation(n, n, seed=1234), 40, seed=5)
+    op = oracle.default_params()
+    g = oracle.geom(n, n, res)
+    oracle.set_threads(16)
+    try:
+        want = oracle.chain(g, op, elev)
+        want["traversability_footprint"] = oracle.footprint(g, op, elev, want)
+    finally:
+        oracle.set_threads(1)
+    layers = list(OUT_LAYERS) + ["traversability_footprint"]
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(n, n, 1, res)
+        ctx.upload_elevation(elev)
+        ctx.run_chain(capi.RUN_FOOTPRINT)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in layers}
+    assert_layers_match(got, want, layers=layers, ctx="1024^2, default YAML, res 0.05")

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""The reference's DEFAULT parameters (robot_filter_parameter.yaml: normals / roughness radius 0.05 m, step windows 0.04 m) on
+maps at the resolutions elevation_mapping is commonly run at: at res 0.05 m the 0.05 m radius is a TIE radius of exactly
+one cell (the four edge neighbours are on the circle: kept or dropped per centre by the rounding of the positions), the
+step windows hold the centre alone; at res 0.03 m (the bag) they are 9- and 5-point discs.  Event-timed launches, chain and
+chain + footprint, fast paths and (--generic) the generic kernels.  Prints one JSON object.  Needs an MI355X."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from traversability_estimation_amd import capi, synth  # noqa: E402
+
+
+def main():
+    capi.load()
+    sizes = [int(v) for v in os.environ.get("TE_SIZES", "256,1024,4096").split(",")]
+    out = {}
+    for res in (0.05, 0.03):
+        for n in sizes:
+            e = synth.perlin_elevation(n, n, seed=1234)
+            with capi.Context(0) as c:
+                c.set_params(capi.default_params())
+                c.set_geometry(n, n, 1, res)
+                c.upload_elevation(e)
+                row = {}
+                for name, flags in (("chain", 0), ("chain+footprint", capi.RUN_FOOTPRINT), ("chain generic", capi.RUN_GENERIC_KERNELS),
+                                    ("normals only", capi.RUN_NORMALS_ONLY), ("normals only generic", capi.RUN_NORMALS_ONLY | capi.RUN_GENERIC_KERNELS)):
+                    if "profile" in sys.argv and "generic" in name:
+                        continue
+                    s = c.time_chain_samples(flags, warmup=5, iters=10 if "profile" in sys.argv else 50)
+                    row[name] = {"ms": round(float(np.median(s)), 4), "cells_per_s": round(n * n / (float(np.median(s)) * 1e-3))}
+                out[f"res {res} {n}x{n}"] = row
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,13 +2,15 @@
 
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels with
 the gpurun snapshot, so the GPU box uses the prebuilt file.  Every source is compiled to its own object
-(in parallel, cached under _build/ by modification time; build_lib(force=True) compiles every object again,
+(in parallel, cached under _build/ by a CONTENT hash of the source, every header and the flags -- an unpack that resets
+modification times cannot make a stale object look fresh; build_lib(force=True) compiles every object again,
 build_lib(relink=True) only what is stale and then links) and the objects are linked into the library.
 
 `python -m traversability_estimation_amd.build --lab` builds libtravgpu_lab.so (-DTE_LAB, objects under _build_lab/): the
 same sources with their measurement switches (environment variables such as TE_NO_F4, TE_N3_BLOCKS_PER_CU) compiled in.
 The shipped libtravgpu.so never reads the environment; tools/ load the lab library through TRAVGPU_LIB.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -16,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip"]
+SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip", "csrc/te_trace.hip"]
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")
@@ -40,16 +42,49 @@ def hipcc():
     return exe
 
 
-def _mtime(rel):
-    return os.path.getmtime(os.path.join(_HERE, rel))
+def _read(rel):
+    with open(os.path.join(_HERE, rel), "rb") as f:
+        return f.read()
+
+
+def _headers_digest():
+    h = hashlib.sha256()
+    for rel in HEADERS:
+        h.update(rel.encode() + b"\0" + _read(rel))
+    return h.digest()
+
+
+def _key(unit, lab, headers=None):
+    """Content key of one object: its source, every header, the flags and the part it is."""
+    src, part = unit
+    h = hashlib.sha256()
+    h.update(headers if headers is not None else _headers_digest())
+    h.update(_read(src))
+    h.update(repr((CFLAGS, EXTRA_CFLAGS.get(src, []), PARTS.get(src), part, bool(lab))).encode())
+    return h.hexdigest()
+
+
+def _fresh(unit, lab, headers=None):
+    obj = _obj(*unit, lab=lab)
+    try:
+        with open(obj + ".key") as f:
+            return os.path.exists(obj) and f.read().strip() == _key(unit, lab, headers)
+    except OSError:
+        return False
+
+
+def _lib_key(lab, headers=None):
+    headers = headers if headers is not None else _headers_digest()
+    return hashlib.sha256(("".join(_key(u, lab, headers) for u in _units()) + repr(LDFLAGS)).encode()).hexdigest()
 
 
 def stale(lab=False):
     lib = LAB_LIB if lab else LIB
-    if not os.path.exists(lib):
+    try:
+        with open(lib + ".key") as f:
+            return not os.path.exists(lib) or f.read().strip() != _lib_key(lab)
+    except OSError:
         return True
-    t = os.path.getmtime(lib)
-    return any(_mtime(f) > t for f in SOURCES + HEADERS)
 
 
 def _units():
@@ -74,23 +109,25 @@ def _compile(unit, verbose, lab=False):
                                os.path.join(_HERE, src), "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
+    key = _key(unit, lab)  # (of the text that is about to be compiled)
     subprocess.check_call(cmd)
     os.replace(out + ".tmp", out)
+    with open(out + ".key", "w") as f:
+        f.write(key)
 
 
 def build_lib(force=False, verbose=False, lab=False, relink=False):
-    """force: every object is compiled again (about 6 minutes on 8 cores); relink: objects older than their source or
-    than any header are compiled, and the library is linked again even if nothing was (what __graft_entry__.build() asks
+    """force: every object is compiled again (about 6 minutes on 8 cores); relink: objects whose content key is stale
+    are compiled, and the library is linked again even if nothing was (what __graft_entry__.build() asks
     for: on a fresh clone that IS a full build, on a warm tree it is the link check)."""
     lib = LAB_LIB if lab else LIB
     if not force and not relink and not stale(lab):
         return lib
     os.makedirs(LAB_OBJDIR if lab else OBJDIR, exist_ok=True)
-    newest_header = max(_mtime(h) for h in HEADERS + ["build.py"])
-    # force: every object is compiled again (the driver's "does it build" check must not be answered from a cache);
-    # otherwise only what is older than its source or than any header
-    todo = [u for u in _units()
-            if force or not os.path.exists(_obj(*u, lab=lab)) or os.path.getmtime(_obj(*u, lab=lab)) < max(_mtime(u[0]), newest_header)]
+    headers = _headers_digest()
+    # force: every object is compiled again; otherwise only objects whose content key (source + headers + flags) differs
+    # from the one they were compiled from
+    todo = [u for u in _units() if force or not _fresh(u, lab, headers)]
     todo.sort(key=lambda u: u[0] not in PARTS)  # the long ones first
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
         list(pool.map(lambda u: _compile(u, verbose, lab), todo))
@@ -99,6 +136,8 @@ def build_lib(force=False, verbose=False, lab=False, relink=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(lib + ".tmp", lib)
+    with open(lib + ".key", "w") as f:
+        f.write(_lib_key(lab))
     return lib
 
 

@@ -200,6 +200,12 @@ def default_params(**over):
     return p
 
 
+def validate_params(p):
+    """The range checks of the reference's configure()s (te_params_validate); raises TeError with the reference's message."""
+    _check(load().te_params_validate(C.byref(p)))
+    return p
+
+
 def params_to_bytes(p):
     return bytes(p)
 

@@ -33,13 +33,23 @@ __device__ __forceinline__ bool tie_inside(const Geo& g, const TieArgs& t, int i
 }
 
 // StepFilter.cpp:112-144 finished: sh holds the maximum, sh_min the minimum over the valid cells of the disc without its circle
+// CENTRE: a radius of exactly ONE cell -- the runs hold the centre alone (0.04 m windows on a 0.04 m map): no march comes
+// first, the running maximum and minimum start from the centre's own elevation
+template <bool CENTRE>
 __global__ __launch_bounds__(256) void k_step_height_ties(Geo g, TieArgs t, const float* __restrict__ elev, float* __restrict__ sh,
                                                           const float* __restrict__ sh_min, Region rg) {
   const int i = rg.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = rg.j0 + (int)blockIdx.y;
   if (i >= rg.i1) return;
   const size_t mo = (size_t)(rg.map >= 0 ? rg.map : (int)blockIdx.z) * g.rows * g.cols;
   const size_t o = mo + (size_t)j * g.rows + i;
-  float vmx = sh[o], vmn = sh_min[o];
+  float vmx, vmn;
+  if constexpr (CENTRE) {
+    const float zc = elev[o];
+    vmx = vmn = __builtin_isfinite(zc) ? zc : qnan();
+  } else {
+    vmx = sh[o];
+    vmn = sh_min[o];
+  }
   for (int k = 0; k < t.n_ties; ++k) {
     const int ii = i + t.di[k], jj = j + t.dj[k];
     if ((unsigned)ii >= (unsigned)g.rows || (unsigned)jj >= (unsigned)g.cols || !tie_inside(g, t, i, j, k)) continue;
@@ -53,14 +63,24 @@ __global__ __launch_bounds__(256) void k_step_height_ties(Geo g, TieArgs t, cons
 }
 
 // StepFilter.cpp:147-178 finished: out holds the maximum of the valid step heights, cnt how many exceed the critical value
+template <bool CENTRE>
 __global__ __launch_bounds__(256) void k_step_score_ties(Geo g, TieArgs t, double crit, float crit_lo, int ncrit, const float* __restrict__ shl,
                                                          float* __restrict__ out, const float* __restrict__ cnt, Region rg) {
   const int i = rg.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = rg.j0 + (int)blockIdx.y;
   if (i >= rg.i1) return;
   const size_t mo = (size_t)(rg.map >= 0 ? rg.map : (int)blockIdx.z) * g.rows * g.cols;
   const size_t o = mo + (size_t)j * g.rows + i;
-  float m = out[o];
-  int count = __float_as_int(cnt[o]);
+  float m;
+  int count;
+  if constexpr (CENTRE) {  // the window without its circle is the centre: its own step height, if it has one
+    const float hc = shl[o];
+    const bool v = __builtin_isfinite(hc);
+    m = v ? hc : qnan();
+    count = (v && hc > crit_lo) ? 1 : 0;
+  } else {
+    m = out[o];
+    count = __float_as_int(cnt[o]);
+  }
   for (int k = 0; k < t.n_ties; ++k) {
     const int ii = i + t.di[k], jj = j + t.dj[k];
     if ((unsigned)ii >= (unsigned)g.rows || (unsigned)jj >= (unsigned)g.cols || !tie_inside(g, t, i, j, k)) continue;
@@ -86,14 +106,14 @@ constexpr bool tie_free_part(int Q) { return Q == 2 || Q == 8 || Q == 13 || Q ==
 // the shape of a tie disc without its circle (largest norm in its runs), its ties as kernel arguments; false: not a
 // whole-cell radius this file serves
 bool tie_disc(const Disc& d, int* q_free, TieArgs* t) {
-  if (d.n_ties == 0 || d.n_ties > kMaxTies || d.R < 1) return false;
+  if (d.n_ties == 0 || d.n_ties > kMaxTies || d.R < 0) return false;
   int q = 0;
   for (int b = 0; b <= d.R; ++b)
     if (d.hw[b] >= 0 && d.hw[b] * d.hw[b] + b * b > q) q = d.hw[b] * d.hw[b] + b * b;
   const int n2 = d.reach * d.reach;
   for (int k = 0; k < d.n_ties; ++k)
     if ((int)d.tie_di[k] * d.tie_di[k] + (int)d.tie_dj[k] * d.tie_dj[k] != n2) return false;
-  if (!tie_free_part(q)) return false;
+  if (!tie_free_part(q) && !(q == 0 && d.reach == 1)) return false;  // (q = 0: a radius of one cell, the centre-only kernels)
   *q_free = q;
   t->n_ties = d.n_ties;
   for (int k = 0; k < kMaxTies; ++k) {
@@ -120,8 +140,12 @@ bool step_height_ties(const Disc& d, const Geo& g, const float* elev, float* sh,
   int q = 0;
   TieArgs t;
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
+  if (q == 0) {
+    hipLaunchKernelGGL(k_step_height_ties<true>, cell_grid(g, r), dim3(256), 0, s, g, t, elev, sh, (const float*)nullptr, r);
+    return true;
+  }
   if (!step_height5(q, g, elev, sh, scratch, r, s)) return false;
-  hipLaunchKernelGGL(k_step_height_ties, cell_grid(g, r), dim3(256), 0, s, g, t, elev, sh, (const float*)scratch, r);
+  hipLaunchKernelGGL(k_step_height_ties<false>, cell_grid(g, r), dim3(256), 0, s, g, t, elev, sh, (const float*)scratch, r);
   return true;
 }
 
@@ -138,8 +162,12 @@ bool step_score_ties(const Disc& d, const Geo& g, double crit, int ncrit, const 
   if (off || !scratch || r.i1 - r.i0 < kLanes || !tie_disc(d, &q, &t)) return false;
   float lo = (float)crit;  // largest float <= crit
   if ((double)lo > crit) lo = nextafterf(lo, -INFINITY);
+  if (q == 0) {
+    hipLaunchKernelGGL(k_step_score_ties<true>, cell_grid(g, r), dim3(256), 0, s, g, t, crit, lo, ncrit, sh, out, (const float*)nullptr, r);
+    return true;
+  }
   if (!step_score5(q, g, crit, ncrit, sh, out, scratch, r, s)) return false;
-  hipLaunchKernelGGL(k_step_score_ties, cell_grid(g, r), dim3(256), 0, s, g, t, crit, lo, ncrit, sh, out, (const float*)scratch, r);
+  hipLaunchKernelGGL(k_step_score_ties<false>, cell_grid(g, r), dim3(256), 0, s, g, t, crit, lo, ncrit, sh, out, (const float*)scratch, r);
   return true;
 }
 

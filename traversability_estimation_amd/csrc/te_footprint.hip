@@ -1278,7 +1278,11 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // (Round 5 what-ifs, recorded in profiles/r05_experiments.json and kept as tools/lab/attic/r05_whatif_footprint.patch:
   // the sum kernel on the second stream BESIDE the mask kernel -- 2-3 % slower than behind it -- and ONE kernel that stages
   // elevation and the three scores itself: 264 us alone against 67 + 51.)
-  launch_mask(t_lo, t_hi, stream);
+  {
+    TraceRange tr(combine ? "footprint: isTraversableForFilters mask + weighted combine" : "footprint: isTraversableForFilters mask");
+    launch_mask(t_lo, t_hi, stream);
+  }
+  TraceRange tr_sum("footprint: disc sums (+ blocked discs)");
   const Region* rfp = region ? &rf : nullptr;
   SpiralArgs a;
   const Disc& d = p.fp_disc;

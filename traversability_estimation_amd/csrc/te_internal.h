@@ -27,6 +27,19 @@ constexpr int lab_int(const char*, int dflt) { return dflt; }
 constexpr bool lab_flag(const char*) { return false; }
 #endif
 
+// A roctx range over the enclosing scope (te_trace.hip): the phases of a launch in `rocprofv3 --marker-trace`.
+class TraceRange {
+ public:
+  explicit TraceRange(const char* name);
+  ~TraceRange();
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+
+ private:
+  bool live_;
+};
+bool trace_available();
+
 constexpr int kMaxRadiusCells = 32;  // largest stencil radius (in cells) a launch supports
 // The marching kernels of te_march5.h load the rows above / below a map unconditionally (and stage them as "nothing
 // there"): up to the stencil radius above the first row, and the radius plus the prefetch distance below the last.  The

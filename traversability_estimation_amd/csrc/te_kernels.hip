@@ -586,6 +586,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
     (void)hipStreamWaitEvent(ss, L.ev_fork, 0);
   }
   if (!normals_only) {
+    TraceRange tr("chain: step filter (height, score)");
     if (!(use_fast && (fast::step_height_fast(p.step1.Q, g, L.elev, L.step_height, r1, ss) ||
                        fast::step_height_ties(p.step1, g, L.elev, L.step_height, L.tie_scratch, r1, ss))))
       hipLaunchKernelGGL(k_step_height, tile_grid(g, r1), blk, tile_bytes(p.step1.reach), ss, g, p.step1, L.elev,
@@ -621,6 +622,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   const bool fused_combine = whole && !overlap && !normals_only && !(flags & kDeferCombine);
   FastGrid fg;
   bool combined = false;
+  TraceRange tr_normals("chain: normals + slope + roughness (+ fix-up)");
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream, &combined)) {
     na.combine = combined ? 1 : 0;

@@ -1413,7 +1413,20 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
     for (int t = 0; t < d.n_ties; ++t)
       if ((int)d.tie_di[t] * d.tie_di[t] + (int)d.tie_dj[t] * d.tie_dj[t] != shape) return false;
   }
-  if (R < 1 || shape < 1 || d.npoints < 3) return false;
+  // cells and sum(di^2) of the shape the kernel slides (a tie disc WITH its circle: at a radius of exactly one cell the runs
+  // hold the centre alone and the four edge neighbours are all ties -- robot_filter_parameter.yaml's 0.05 m on a 0.05 m map)
+  int shape_points = d.npoints;
+  long long sii = 0;  // of the runs (the constants of the closed-form tail below)
+  for (int dj = -d.R; dj <= d.R; ++dj) {
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) sii += di * di;
+  }
+  long long shape_sii = sii;
+  for (int t = 0; t < d.n_ties; ++t) {
+    ++shape_points;
+    shape_sii += (int)d.tie_di[t] * d.tie_di[t];
+  }
+  if (R < 1 || shape < 1 || shape_points < 3) return false;
   N3Args a;
   a.i_lo = r.i0;
   a.i_hi = r.i1;
@@ -1422,13 +1435,10 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   if (a.i_hi - a.i_lo < kLanes || a.j_hi <= a.j_lo || !L.clip_table) return false;
   if (g.rows < 2 * R + 1 || g.cols < 2 * R + 1) return false;  // both borders inside one disc: the clip codes do not cover that
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;  // 32-bit byte offsets inside a map
-  long long sii = 0;
-  for (int dj = -R; dj <= R; ++dj) {
-    const int hw = d.hw[dj < 0 ? -dj : dj];
-    for (int di = -hw; di <= hw; ++di) sii += di * di;
-  }
-  const double N = (double)d.npoints;
-  if (!(g.res * g.res * ((double)sii / N) > 1e-8)) return false;  // NormalVectorsFilter's eigenvalue test would fail everywhere
+  if (!(g.res * g.res * ((double)shape_sii / (double)shape_points) > 1e-8)) return false;  // NormalVectorsFilter's eigenvalue test would fail everywhere
+  // (N, sii of the runs: the constants of the closed-form tail of the tie-free marches; the TIES march takes every disc's
+  // x/y moments from its clip table and the general tail)
+  const double N = (double)(d.npoints > 1 ? d.npoints : 2);
   a.elev = L.elev;
   a.slope = L.slope;
   a.rough = L.rough;

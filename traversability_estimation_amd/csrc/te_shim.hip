@@ -213,6 +213,9 @@ struct te_ctx {
   std::function<void()> pf_job;
   bool pf_quit = false;
   bool prefetch_running = false, prefetch_elev = false;  // (prefetch_running: a job is queued or being worked on; under pf_mu)
+  // bit TE_LAYER_* of every layer the prefetch in flight is writing (under mu): a call that runs beside a prefetch joins
+  // it first if it reads or writes one of them (te_run_filter, te_download_layer*)
+  unsigned prefetch_mask = 0;
   std::atomic<int> prefetch_rc{TE_OK};
 };
 
@@ -222,30 +225,59 @@ int count_invalid_elevation(te_ctx* c);
 void finish_prefetch_locked(te_ctx* c) {
   {
     std::unique_lock<std::mutex> pl(c->pf_mu);
-    if (!c->prefetch_running && !c->prefetch_elev) return;
+    if (!c->prefetch_running && !c->prefetch_mask) return;
     c->pf_cv.wait(pl, [c] { return !c->prefetch_running; });
   }
-  if (c->prefetch_elev && c->prefetch_rc.load() == TE_OK) {
-    c->have_elev = true;
+  const unsigned mask = c->prefetch_mask;
+  c->prefetch_mask = 0;
+  c->prefetch_elev = false;
+  const bool ok = c->prefetch_rc.load() == TE_OK;
+  if (mask & (1u << TE_LAYER_ELEVATION)) {
+    // whatever was computed from the previous elevation no longer describes the layer, arrived or torn
     c->chain_done = false;
     c->footprint_done = false;
-    // the invalid cells are counted like te_upload_elevation counts them (the count picks the normals kernel's march and
-    // strip height); a failure leaves the count unknown, which every kernel serves
-    if (hipSetDevice(c->device) != hipSuccess || count_invalid_elevation(c) != TE_OK) {
-      (void)hipGetLastError();
-      c->invalid_cells = -1;
+    c->invalid_cells = -1;
+    c->invalid_runs = -1;
+    if (ok) {
+      c->have_elev = true;
+      // the invalid cells are counted like te_upload_elevation counts them (the count picks the normals kernel's march and
+      // strip height); a failure leaves the count unknown, which every kernel serves
+      if (hipSetDevice(c->device) != hipSuccess || count_invalid_elevation(c) != TE_OK) {
+        (void)hipGetLastError();
+        c->invalid_cells = -1;
+      }
+    } else {
+      c->have_elev = false;  // partly overwritten: the next chain needs a complete upload
     }
   }
-  c->prefetch_elev = false;
+  if (ok) {  // (what an arrived layer changes for the later calls: only once it HAS arrived)
+    if (mask & (1u << TE_LAYER_ROBOT_SLOPE)) c->have_robot_slope = true;
+    if (mask & (1u << TE_LAYER_TRAVERSABILITY)) c->trav_external = c->trav_ptr_out = true;
+  }
 }
 // Every entry point takes the context's mutex through this: a prefetch that is still running is finished first -- except
 // in the calls that are meant to run beside one (te_run_filter, te_download_layer*, the parameter calls).
 struct CtxLock {
   std::lock_guard<std::mutex> lk;
-  explicit CtxLock(te_ctx* c, bool beside_prefetch = false) : lk(c->mu) {
-    if (!beside_prefetch) finish_prefetch_locked(c);
+  // beside_prefetch: the call may run while a prefetch is in flight -- unless it touches one of the layers the prefetch is
+  // writing (`touches`: bits TE_LAYER_*), in which case it joins it like every other call
+  explicit CtxLock(te_ctx* c, bool beside_prefetch = false, unsigned touches = 0) : lk(c->mu) {
+    if (!beside_prefetch || (touches & c->prefetch_mask)) finish_prefetch_locked(c);
   }
 };
+constexpr unsigned bit(int layer) { return (layer >= 0 && layer < 32) ? 1u << layer : 0u; }
+// layers TE_FILTER_* reads and writes (travgpu.h: TE_FILTER_* table)
+unsigned filter_layers(int filter) {
+  const unsigned normals = bit(TE_LAYER_NORMAL_X) | bit(TE_LAYER_NORMAL_Y) | bit(TE_LAYER_NORMAL_Z);
+  switch (filter) {
+    case TE_FILTER_SLOPE: return bit(TE_LAYER_NORMAL_Z) | bit(TE_LAYER_SLOPE);
+    case TE_FILTER_STEP: return bit(TE_LAYER_ELEVATION) | bit(TE_LAYER_STEP);
+    case TE_FILTER_ROUGHNESS: return bit(TE_LAYER_ELEVATION) | normals | bit(TE_LAYER_ROUGHNESS);
+    case TE_FILTER_COMBINE: return bit(TE_LAYER_SLOPE) | bit(TE_LAYER_STEP) | bit(TE_LAYER_ROUGHNESS) | bit(TE_LAYER_TRAVERSABILITY);
+    case TE_FILTER_NORMALS: return bit(TE_LAYER_ELEVATION) | normals | bit(TE_LAYER_SLOPE) | bit(TE_LAYER_ROUGHNESS);
+    default: return ~0u;
+  }
+}
 }  // namespace
 
 namespace {
@@ -690,6 +722,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
       }
     }
     if (slot >= 0) {
+      TraceRange tr("te_run_chain: graph replay (chain + footprint kernels)");
       HIP_TRY(hipGraphLaunch(c->graph_exec[slot], c->stream));
       c->trav_external = false;  // (as run_chain_locked: every cell of the combined layer now comes from the chain)
       c->chain_done = true;
@@ -1244,7 +1277,7 @@ int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int s
 static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
                                            int expect_rows, int expect_cols) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: NULL");
-  CtxLock lk(c, /*beside_prefetch*/ true);
+  CtxLock lk(c, /*beside_prefetch*/ true, bit(layer));
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer_circular: geometry not set");
   if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
     return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
@@ -1370,7 +1403,10 @@ int te_bag_write(const void* m, size_t msg_len, const char* topic, uint32_t stam
 
 int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_filter: NULL ctx");
-  CtxLock lk(c, /*beside_prefetch*/ true);
+  static const char* const kFilterRange[] = {"te_run_filter", "te_run_filter: slope", "te_run_filter: step", "te_run_filter: roughness",
+                                             "te_run_filter: combine", "te_run_filter: normals"};
+  TraceRange tr(kFilterRange[(filter >= 0 && filter < 6) ? filter : 0]);
+  CtxLock lk(c, /*beside_prefetch*/ true, filter_layers(filter));
   if (!c->have_geo || !c->have_params) return fail(TE_ERR_NOT_READY, "te_run_filter: set params and geometry first");
   if (!c->tables_ready) {
     int rc = rebuild_tables(c);
@@ -1400,6 +1436,7 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
 
 int te_run_chain(te_ctx* c, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain: NULL ctx");
+  TraceRange tr("te_run_chain");
   CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain: geometry not set");
   return run_whole_locked(c, flags);
@@ -1407,6 +1444,7 @@ int te_run_chain(te_ctx* c, unsigned flags) {
 
 int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, int h, int w) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_chain_region: NULL ctx");
+  TraceRange tr("te_run_chain_region");
   CtxLock lk(c);
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_run_chain_region: geometry not set");
   if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
@@ -1445,6 +1483,7 @@ int te_run_chain_region(te_ctx* c, unsigned flags, int map, int row0, int col0, 
 
 int te_run_footprint(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_footprint: NULL ctx");
+  TraceRange tr("te_run_footprint");
   CtxLock lk(c);
   return run_footprint_locked(c, TE_RUN_FOOTPRINT_MEMO);
 }
@@ -1851,7 +1890,7 @@ int te_sync(te_ctx* c) {
 
 int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
   if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer: NULL");
-  CtxLock lk(c, /*beside_prefetch*/ true);
+  CtxLock lk(c, /*beside_prefetch*/ true, bit(layer));
   if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer: geometry not set");
   float* p = layer_ptr(c, layer);
   if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer: bad layer %d", layer);
@@ -1877,6 +1916,7 @@ int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* 
   };
   std::vector<Job> jobs;
   bool elev = false;
+  unsigned mask = 0;
   for (int k = 0; k < n; ++k) {
     if (!hosts[k]) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: NULL host buffer");
     if (layers[k] != TE_LAYER_ELEVATION) {
@@ -1886,8 +1926,7 @@ int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* 
     if (!p) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: bad layer %d", layers[k]);
     jobs.push_back(Job{p, hosts[k]});
     elev = elev || layers[k] == TE_LAYER_ELEVATION;
-    if (layers[k] == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
-    if (layers[k] == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
+    mask |= bit(layers[k]);
   }
   HIP_TRY(hipSetDevice(c->device));
   if (!c->prefetch_order) HIP_TRY(hipStreamCreateWithFlags(&c->prefetch_order, hipStreamNonBlocking));
@@ -1907,6 +1946,7 @@ int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* 
     c->prefetch_rc.store(rc);
   };
   c->prefetch_elev = elev;
+  c->prefetch_mask = mask;
   if (!c->prefetch_thread.joinable()) {
     try {
       c->prefetch_thread = std::thread([c] {
@@ -1928,6 +1968,7 @@ int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* 
       });
     } catch (...) {  // no thread to be had: the uploads happen here and now
       work();
+      finish_prefetch_locked(c);
       return TE_OK;
     }
   }
