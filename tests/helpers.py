@@ -29,6 +29,22 @@ def assert_layers_match(got, want, layers=OUT_LAYERS, tol=TOL, ctx=""):
     return report
 
 
+def orient_horizontal_normals(layers, nz_ref):
+    """The SIGN of a horizontal normal is not defined by the filter: NormalVectorsFilter flips a normal only if its z
+    component is negative, so where nz is 0 -- three collinear points, the usual disc of a one-cell tie radius whose cells
+    across one axis were rejected -- the eigen-solver's rounding noise decides between n and -n (in the reference as in the
+    oracle; slope, roughness and every later layer are the same for both).  Returns copies of surface_normal_x / _y with the
+    horizontal normals (|nz_ref| <= 1e-6) turned so that their larger component is positive."""
+    nx = np.array(layers["surface_normal_x"], np.float32).reshape(-1)
+    ny = np.array(layers["surface_normal_y"], np.float32).reshape(-1)
+    flat = np.abs(np.asarray(nz_ref, np.float32).reshape(-1)) <= 1e-6
+    lead = np.where(np.abs(nx) >= np.abs(ny), nx, ny)
+    sgn = np.where(flat & (lead < 0), -1.0, 1.0).astype(np.float32)
+    out = dict(layers)
+    out["surface_normal_x"], out["surface_normal_y"] = nx * sgn, ny * sgn
+    return out
+
+
 def to_te_params(capi, op):
     """oracle Params -> te_params (same field names)."""
     p = capi.default_params()

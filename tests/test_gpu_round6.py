@@ -8,7 +8,7 @@ radius with the generic kernels (k_normals: 0.99 ms on 4096^2 against 0.09 ms fo
 import numpy as np
 import pytest
 
-from tests.helpers import OUT_LAYERS, assert_layers_match, to_te_params
+from tests.helpers import OUT_LAYERS, assert_layers_match, orient_horizontal_normals, to_te_params
 
 pytestmark = pytest.mark.gpu
 
@@ -50,6 +50,8 @@ def test_default_yaml_radii_on_maps_where_they_are_one_cell_ties(capi, oracle, r
         ctx.run_chain(capi.RUN_FOOTPRINT | (capi.RUN_KEEP_NORMALS if keep else 0))
         ctx.sync()
         got = {k: ctx.download(k) for k in layers}
+    if keep:  # (the sign of a horizontal normal is rounding noise in the reference itself: tests/helpers.py)
+        got, want = orient_horizontal_normals(got, want["surface_normal_z"]), orient_horizontal_normals(want, want["surface_normal_z"])
     assert_layers_match(got, want, layers=layers, ctx=f"default YAML at res {res}, origin {origin}")
 
 

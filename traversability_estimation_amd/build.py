@@ -12,13 +12,15 @@ The shipped libtravgpu.so never reads the environment; tools/ load the lab libra
 """
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip", "csrc/te_trace.hip"]
+SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_normals_small.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip", "csrc/te_trace.hip"]
+# (every header of csrc/ and the public one; an object's key covers the ones it includes, see _deps)
 HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")
@@ -47,7 +49,24 @@ def _read(rel):
         return f.read()
 
 
+_INCLUDE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+
+
+def _deps(rel, seen=None):
+    """The headers `rel` (a path relative to this directory) includes, transitively: csrc/ and ../include/."""
+    seen = set() if seen is None else seen
+    for name in _INCLUDE.findall(_read(rel).decode("utf-8", "replace")):
+        for cand in (os.path.join(os.path.dirname(rel), name), os.path.join("csrc", name), os.path.join("..", "include", name)):
+            cand = os.path.normpath(cand)
+            if cand not in seen and os.path.exists(os.path.join(_HERE, cand)):
+                seen.add(cand)
+                _deps(cand, seen)
+                break
+    return seen
+
+
 def _headers_digest():
+    """(kept for callers that want one digest of every header: the library key)"""
     h = hashlib.sha256()
     for rel in HEADERS:
         h.update(rel.encode() + b"\0" + _read(rel))
@@ -55,10 +74,12 @@ def _headers_digest():
 
 
 def _key(unit, lab, headers=None):
-    """Content key of one object: its source, every header, the flags and the part it is."""
+    """Content key of one object: its source, the headers IT includes (transitively), the flags and the part it is --
+    editing a header rebuilds the objects that see it, not the library."""
     src, part = unit
     h = hashlib.sha256()
-    h.update(headers if headers is not None else _headers_digest())
+    for rel in sorted(_deps(src)):
+        h.update(rel.encode() + b"\0" + _read(rel))
     h.update(_read(src))
     h.update(repr((CFLAGS, EXTRA_CFLAGS.get(src, []), PARTS.get(src), part, bool(lab))).encode())
     return h.hexdigest()

@@ -1275,7 +1275,7 @@ hipError_t launch_footprint(const Geo& g, const FootprintParams& p, const Layers
   // measured in round 3 with k_fp_slide4 (0.418 ms per launch against 0.385) and again in round 4 with k_fp_slide5 and
   // 2 / 3 / 4 / 6 bands on two streams (0.393 / 0.425 / 0.462 / 0.589 against 0.375, profiles/r04_experiments.json): the two
   // kernels slow each other down by more than they overlap, and every band pays the strips' 2R lead-in rows again.)
-  // (Round 5 what-ifs, recorded in profiles/r05_experiments.json and kept as tools/lab/attic/r05_whatif_footprint.patch:
+  // (Round 5 what-ifs, recorded in profiles/r05_experiments.json and kept in the tree of git tag round5-record as tools/lab/attic/r05_whatif_footprint.patch:
   // the sum kernel on the second stream BESIDE the mask kernel -- 2-3 % slower than behind it -- and ONE kernel that stages
   // elevation and the three scores itself: 264 us alone against 67 + 51.)
   {

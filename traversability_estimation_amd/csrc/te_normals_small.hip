@@ -1,0 +1,259 @@
+// te_normals_small.hip -- NormalVectorsFilter + SlopeFilter + RoughnessFilter for discs that reach at most TWO cells: one
+// cell per thread, the neighbourhood gathered directly.
+//
+//   NormalVectorsFilter (area method; un-vendored grid_map_filters, call site
+//                        traversability_estimation/config/robot_filter_parameter.yaml:3-9)
+//   SlopeFilter::update      traversability_estimation_filters/src/SlopeFilter.cpp:59-88
+//   RoughnessFilter::update  traversability_estimation_filters/src/RoughnessFilter.cpp:73-132
+//
+// Why a kernel of its own.  The reference's DEFAULT radius is 0.05 m (robot_filter_parameter.yaml:8, :28): on a 0.05 m map
+// that is a TIE radius of exactly one cell -- the runs of the disc hold the centre alone and the four edge neighbours lie
+// on the circle, kept or dropped centre by centre by the rounding of the cell positions (CircleIterator::isInside).  The
+// sliding kernels of te_normals3.hip exist to make a 253-point disc cost 38 cells per step; with at most 12 neighbours
+// there is nothing to slide, and their strips (a serial march per wavefront, a ring, strip starts, the map frame left to the
+// fix-up pass) are pure overhead: the TIES march took 0.47 ms for a 4096^2 map at one cell, 31 us for a 256^2 one.
+// Here every thread owns one cell (workgroups of 64 x 4, four to a 64 x 16 tile of the fix-up pass), reads its neighbours straight from the layer
+// (coalesced along i, the rows above and below come from L2 / the vector cache), decides its tie cells with the
+// reference's own position arithmetic, and runs the general tail of te_eig3.h.  Discs clipped by the map border and
+// invalid neighbours are just fewer points: no frame, no hole march.  Cells the tail does not resolve (a nearly
+// horizontal normal, an ambiguous middle eigenvalue) and scores within their error of the clip at 0 are left to
+// k_normals_fixup exactly like the sliding kernels leave them (te_internal.h: kExactNaNBits).
+//
+// Algorithmic bytes: 4 B read + 8 B written per cell (+ 12 B when the normals are kept).
+#include "te_eig.h"
+#include "te_eig3.h"
+#include "te_geom.h"
+#include "te_internal.h"
+#include "te_march.h"
+
+namespace te {
+namespace fast {
+
+namespace {
+
+constexpr int kSmallMaxOffsets = 12;  // the 13-point disc (reach 2) without its centre
+constexpr int kSmallRows = 16;        // rows of a tile (= the fix-up pass's 64 x 16 tile)
+constexpr int kSmallBY = 4;           // rows of a workgroup (64 x 4 threads, one cell each): four workgroups per fix-up tile
+
+struct SmallArgs {
+  const float* elev;
+  float* slope;
+  float* rough;
+  float* nx;
+  float* ny;
+  float* nz;
+  int* tile_flags;
+  int rows, cols;
+  long long map_cells;
+  int map;  // >= 0: this map only; < 0: blockIdx.z
+  int i_lo, i_hi, j_lo, j_hi;
+  double res, r2, ax, ay;
+  int n_off;
+  signed char di[kSmallMaxOffsets], dj[kSmallMaxOffsets];
+  unsigned tie_mask;  // bit k: offset k lies on the circle -- isInside decides it for every centre
+  float inv_slope_crit, inv_rough_crit, band_slope, band_rough;
+  int ntx, nty, fix_groups;
+};
+
+// The valid cells of a disc all lie on ONE grid line (with a one-cell tie radius: the centre and its two neighbours along
+// one axis, the pair across the other axis rejected by isInside -- on a 0.05 m map at the origin a third of all rows): the
+// covariance has the exact eigenvalue 0 with the horizontal unit vector across the line as eigenvector.  general_tail3
+// leaves a (nearly) horizontal normal unresolved, and in round 6's first measurement these cells -- a fifth of the map --
+// made the fix-up pass the longest kernel of the launch (0.35 of 0.48 ms on 4096^2).  They need no eigen-solver:
+//   * the normal is that horizontal vector if the middle eigenvalue -- the smaller one of the 2 x 2 (line coordinate, z)
+//     block -- is > 1e-8 (NormalVectorsFilter), else UnitZ; decided from the sign of (A - t)(F - t) - D^2, t = 1e-8 n^2;
+//   * horizontal: nz = 0, slope pi/2, n^T C n = 0, roughness 0 (the SIGN of such a normal is rounding noise in the
+//     reference itself, tests/helpers.py: orient_horizontal_normals); UnitZ: n^T C n = var(z).
+// Returns 0: done; 1: not this case's business after all (a diagonal line, the threshold within its rounding): unresolved.
+__device__ __forceinline__ int collinear_tail(double res, int n, long long Ai, long long Ci, int si, int sj, double Sz, double Siz, double Sjz, double Szz,
+                                              float& nx, float& ny, float& nz, double& q_scaled) {
+  const double dn = (double)n;
+  const double F = fma(dn, Szz, -(Sz * Sz));  // n^2 var(z)
+  const bool along_i = Ci == 0;               // every point in one map row j: the line runs along i (x)
+  if (!along_i && Ai != 0) return 1;          // a diagonal line (13-point discs with many invalid cells): the fix-up pass
+  const double Au = res * res * (double)(along_i ? Ai : Ci);
+  const double Du = -res * (along_i ? fma(dn, Siz, -((double)si * Sz)) : fma(dn, Sjz, -((double)sj * Sz)));
+  const double thr = 1e-8 * dn * dn;
+  const double P = fma(Au - thr, F - thr, -(Du * Du));
+  if (fabs(P) <= 1e-6 * Au * thr) return 1;
+  if (P > 0.0 && F > thr) {
+    nx = along_i ? 0.0f : 1.0f;
+    ny = along_i ? 1.0f : 0.0f;
+    nz = 0.0f;
+    q_scaled = 0.0;
+  } else {
+    nx = ny = 0.0f;
+    nz = 1.0f;
+    q_scaled = F > 0.0 ? F : 0.0;
+  }
+  return 0;
+}
+
+template <bool KEEP>
+__global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a) {
+  const int lane = (int)threadIdx.x, ty = (int)threadIdx.y;
+  const int mz = a.map >= 0 ? 0 : (int)blockIdx.z;
+  const size_t mo = (size_t)(a.map >= 0 ? a.map : mz) * (size_t)a.map_cells;
+  const int i = a.i_lo + (int)blockIdx.x * kLanes + lane;
+  const int j = a.j_lo + (int)blockIdx.y * kSmallBY + ty;
+  bool flagged = false;
+  if (i < a.i_hi && j < a.j_hi) {
+    const size_t o = mo + (size_t)j * a.rows + i;
+    const float zcf = a.elev[o];
+    // every neighbour's load is issued before the first is used (a loop over n_off waits for one load per turn: on a
+    // 256^2 map the kernel then took 18 us against 11 for the sliding kernel it replaces)
+    const double xi = a.ax + a.res * (double)(-i), yj = a.ay + a.res * (double)(-j);  // cell_x, cell_y (te_geom.h)
+    float zn[kSmallMaxOffsets];
+#pragma unroll
+    for (int k = 0; k < kSmallMaxOffsets; ++k) {
+      zn[k] = qnan();
+      if (k < a.n_off) {  // (uniform)
+        const int ii = i + a.di[k], jj = j + a.dj[k];
+        bool in = (unsigned)ii < (unsigned)a.rows && (unsigned)jj < (unsigned)a.cols;
+        if ((a.tie_mask >> k) & 1u) {  // CircleIterator::isInside with the reference's rounded positions
+          const double dx = (a.ax + a.res * (double)(-ii)) - xi, dy = (a.ay + a.res * (double)(-jj)) - yj;
+          in = in && (dx * dx + dy * dy <= a.r2);
+        }
+        if (in) zn[k] = a.elev[mo + (size_t)jj * a.rows + ii];
+      }
+    }
+    float o_slope = qnan(), o_rough = qnan(), fx = qnan(), fy = qnan(), fz = qnan();
+    if (__builtin_isfinite(zcf)) {  // normals only where the input layer is valid; slope / roughness follow (SlopeFilter.cpp:71, RoughnessFilter.cpp:84)
+      const double zc = (double)zcf;
+      // moments in centre-local coordinates (te_cell.h): the centre itself is (0, 0, 0)
+      int n = 1, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
+      double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
+#pragma unroll
+      for (int k = 0; k < kSmallMaxOffsets; ++k) {
+        if (k < a.n_off) {
+          const int di = a.di[k], dj = a.dj[k];
+          const bool v = __builtin_isfinite(zn[k]);
+          const double dz = v ? (double)zn[k] - zc : 0.0;
+          const int w = v ? 1 : 0;
+          n += w;
+          si += w * di;
+          sj += w * dj;
+          sii += w * di * di;
+          sij += w * di * dj;
+          sjj += w * dj * dj;
+          Sz += dz;
+          Siz = fma((double)di, dz, Siz);
+          Sjz = fma((double)dj, dz, Sjz);
+          Szz = fma(dz, dz, Szz);
+        }
+      }
+      double qs = 0.0;
+      int unresolved;
+      const long long Ai = (long long)n * sii - (long long)si * si, Bi = (long long)n * sij - (long long)si * sj, Ci = (long long)n * sjj - (long long)sj * sj;
+      if (n >= 3 && Ai * Ci - Bi * Bi == 0)
+        unresolved = collinear_tail(a.res, n, Ai, Ci, si, sj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+      else
+        unresolved = general_tail3(a.res, n, si, sj, sii, sij, sjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+      // slope = acos(float32 nz) (SlopeFilter.cpp:74); roughness^2 = q / (n (n - 1)) (RoughnessFilter.cpp:105-117)
+      const float sl = acosf_poly(fz);
+      const float rs = fmaf(-sl, a.inv_slope_crit, 1.0f);
+      o_slope = fmaxf(rs, 0.0f);
+      float rq = (float)(qs * rcp_fast((double)n * (double)(n > 1 ? n - 1 : 1)));
+      rq = rq > 0.0f ? rq : 0.0f;
+      const float rgh = __builtin_amdgcn_sqrtf(rq);
+      const float rr = fmaf(-rgh, a.inv_rough_crit, 1.0f);
+      o_rough = n > 1 ? fmaxf(rr, 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
+      const bool near = near_clip(rs, a.band_slope) || (n > 1 && near_clip(rr, a.band_rough));
+      if (unresolved != 0 || near) {  // the fix-up pass settles the cell with the generic arithmetic
+        const float qn = near ? exact_nanf() : qnan();
+        o_slope = o_rough = fx = fy = fz = qn;
+        flagged = true;
+      }
+    }
+    a.slope[o] = o_slope;
+    a.rough[o] = o_rough;
+    if (KEEP) {
+      a.nx[o] = fx;
+      a.ny[o] = fy;
+      a.nz[o] = fz;
+    }
+  }
+  if (__syncthreads_or(flagged ? 1 : 0) && lane == 0 && ty == 0) {  // the 64 x 16 tile of the fix-up pass this block lies in
+    const int t = mz * a.ntx * a.nty + ((int)blockIdx.y * kSmallBY / kSmallRows) * a.ntx + (int)blockIdx.x;
+    a.tile_flags[(t % a.fix_groups) * kFixTiles + t / a.fix_groups] = 1;
+  }
+}
+
+}  // namespace
+
+// Discs that reach at most two cells, tie radii included: the one-cell tie radius of the default parameters on a 0.05 m
+// map first of all.  Tie-free discs of that size only on small launches (the sliding kernels are faster from about 2^18
+// cells on: 4096^2 at 1.67 cells 0.09 ms).  False: not taken.
+bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* flags, FastGrid* fg,
+                   hipStream_t s) {
+  const Disc& d = p.normals;
+  static const bool off = lab_flag("TE_NO_SMALL");  // measurement aid
+  static const int max_cells_env = lab_int("TE_SMALL_MAX_CELLS", 0);
+  if (off || d.reach < 1 || d.reach > 2 || !flags) return false;
+  if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
+  const long long cells = (long long)(r.i1 - r.i0) * (r.j1 - r.j0) * (r.map >= 0 ? 1 : g.batch);
+  const long long small_launch = max_cells_env > 0 ? max_cells_env : (1ll << 18);
+  if (d.n_ties == 0 && cells > small_launch) return false;
+  SmallArgs a;
+  a.n_off = 0;
+  a.tie_mask = 0;
+  // the generic order: the runs row by row, then the circle cells (the sums are order-dependent only below the tolerance)
+  for (int dj = -d.R; dj <= d.R; ++dj) {
+    const int hw = d.hw[dj < 0 ? -dj : dj];
+    for (int di = -hw; di <= hw; ++di) {
+      if (di == 0 && dj == 0) continue;
+      if (a.n_off >= kSmallMaxOffsets) return false;
+      a.di[a.n_off] = (signed char)di;
+      a.dj[a.n_off] = (signed char)dj;
+      ++a.n_off;
+    }
+  }
+  for (int t = 0; t < d.n_ties; ++t) {
+    if (a.n_off >= kSmallMaxOffsets) return false;
+    a.di[a.n_off] = d.tie_di[t];
+    a.dj[a.n_off] = d.tie_dj[t];
+    a.tie_mask |= 1u << a.n_off;
+    ++a.n_off;
+  }
+  if (a.n_off < 2) return false;  // fewer than three points in every disc: UnitZ everywhere, the generic kernel's business
+  for (int k = a.n_off; k < kSmallMaxOffsets; ++k) a.di[k] = a.dj[k] = 0;
+  a.elev = L.elev;
+  a.slope = L.slope;
+  a.rough = L.rough;
+  a.nx = L.nx;
+  a.ny = L.ny;
+  a.nz = L.nz;
+  a.tile_flags = flags;
+  a.rows = g.rows;
+  a.cols = g.cols;
+  a.map_cells = (long long)g.rows * g.cols;
+  a.map = r.map;
+  a.i_lo = r.i0;
+  a.i_hi = r.i1;
+  a.j_lo = r.j0;
+  a.j_hi = r.j1;
+  a.res = g.res;
+  a.r2 = d.r2;
+  a.ax = g.ax;
+  a.ay = g.ay;
+  a.inv_slope_crit = (float)(1.0 / p.slope_crit);
+  a.inv_rough_crit = (float)(1.0 / p.rough_crit);
+  a.band_slope = clip_band_slope(p.slope_crit);
+  a.band_rough = clip_band_rough(p.rough_crit);
+  fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
+  fg->nty = (r.j1 - r.j0 + kSmallRows - 1) / kSmallRows;
+  fg->nbz = r.map >= 0 ? 1 : g.batch;
+  fg->frame = 0;
+  a.ntx = fg->ntx;
+  a.nty = fg->nty;
+  a.fix_groups = fix_groups(fg->ntx * fg->nty * fg->nbz);
+  const dim3 grid((unsigned)fg->ntx, (unsigned)((r.j1 - r.j0 + kSmallBY - 1) / kSmallBY), (unsigned)fg->nbz);
+  if (keep_normals)
+    hipLaunchKernelGGL(k_normals_small<true>, grid, dim3(kLanes, kSmallBY), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_normals_small<false>, grid, dim3(kLanes, kSmallBY), 0, s, a);
+  return true;
+}
+
+}  // namespace fast
+}  // namespace te

@@ -529,6 +529,10 @@ void launch_r(const Geo& g, SlideArgs a, const Layers& L, bool keep, const Regio
 bool normals_fast(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, bool combine,
                   const Region& r, int* flags, const int* gtab, FastGrid* fg, hipStream_t s, bool* combined) {
   const Disc& d = p.normals;
+  if (normals_small(g, p, L, keep_normals, r, flags, fg, s)) {  // discs of at most 13 cells: one cell per thread
+    *combined = false;
+    return true;
+  }
   if (d.n_ties != 0) {  // a tie radius: k_normals3's TIES march or nothing
     static const bool no_n3_ties = lab_flag("TE_NO_N3");
     if (no_n3_ties || !gtab || g.rows < 2 * d.reach + 1 || g.cols < 2 * d.reach + 1) return false;
