@@ -2,28 +2,13 @@
 //
 // Owns the device-resident elevation/output layers of a batch of maps and launches the HIP chain.
 // No CPU fallback of any kind: without a gfx950 device te_create() fails with TE_ERR_NO_DEVICE.
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <condition_variable>
-#include <dlfcn.h>
-#include <functional>
-#include <chrono>
-#include <mutex>
-#include <new>
-#include <thread>
-#include <vector>
-
-#include <cstdlib>
-#include "te_internal.h"
-#include "te_msg.h"
+#include "te_ctx.h"
 
 using namespace te;
+using namespace te::shim;
 
-namespace {
+namespace te {
+namespace shim {
 
 thread_local char g_err[512] = "";
 
@@ -34,15 +19,6 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
-
-#define HIP_TRY(expr)                                                                            \
-  do {                                                                                           \
-    hipError_t e__ = (expr);                                                                     \
-    if (e__ != hipSuccess) {                                                                     \
-      (void)hipGetLastError(); /* the runtime's last-error slot is sticky: later launches check it */ \
-      return fail(TE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));                          \
-    }                                                                                            \
-  } while (0)
 
 // Build the row-run table of the disc {di^2+dj^2 <= (radius/res)^2}.  Offsets whose squared norm
 // equals (radius/res)^2 to within 1e-9 relative are "ties": the reference decides them per cell
@@ -113,7 +89,9 @@ bool same_disc(const Disc& a, const Disc& b) {
   return true;
 }
 
-}  // namespace
+}  // namespace shim
+}  // namespace te
+
 
 // Invalid (non-finite) cells of a layer: one pass at upload time.  out[0]: their number; out[1]: the number of RUNS of them
 // in memory order (an invalid cell whose predecessor is valid, or that is the layer's first).  The two pick the march
@@ -136,91 +114,9 @@ __global__ void k_count_invalid(const float* __restrict__ v, size_t n, unsigned 
   }
 }
 
-struct te_ctx {
-  std::mutex mu;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  te_params params;
-  bool have_params = false, have_geo = false, have_elev = false, chain_done = false, footprint_done = false;
-  float* poly_x = nullptr;  // traversability_x / traversability_rot (one allocation, made by the first te_run_polygon_footprint)
-  float* poly_rot = nullptr;
-  float* robot_slope = nullptr;  // layer robot_slope (checkInclination); allocated by its first upload, NaN until written
-  bool have_robot_slope = false, check_inclination = false;  // footprint/check_robot_inclination (:114)
-  unsigned* poly_stream = nullptr;        // offset tables of the two footprint polygons (device copy)
-  size_t poly_stream_cap = 0;             // in words
-  std::vector<unsigned> poly_stream_host;  // stays alive until the asynchronous upload has been consumed
-  Geo geo;
-  ChainParams cp;
-  FootprintParams fp;
-  Layers L;
-  size_t layer_elems = 0;
-  void* slab = nullptr;
-  int16_t* d_spiral = nullptr;
-  int* clip_table = nullptr;
-  int* fp_clip_table = nullptr;
-  bool combine_deferred = false;
-  // the traversability layer was written from outside (upload, device pointer, a per-plugin combine of uploaded scores):
-  // its values are then not bounded by the weights, and the fixed-point footprint kernel must not be used
-  bool trav_external = false;
-  // te_device_ptr handed out the traversability layer: the caller may write it at any time from then on, so only a
-  // footprint pass that runs right behind a chain that rewrote EVERY cell (te_run_chain with the footprint flag) may
-  // still assume the bound; te_run_footprint and region runs take the double kernel.  Reset with the layers.
-  bool trav_ptr_out = false;
-  // te_set_option: choices between kernels that give identical results (tests reach both; never read from the environment)
-  int opt_fb_walk = 0, opt_fb_blocks_per_cu = 0, opt_polygon_per_cell = 0;
-  // invalid cells of the elevation layer as of the last whole upload (-1: unknown -- tiles, device pointer): see sparse_holes()
-  long long invalid_cells = -1;
-  long long invalid_runs = -1;  // runs of invalid cells in memory order (k_count_invalid); meaningful with invalid_cells >= 0
-  unsigned long long* d_count = nullptr;
-  char* hole_queue = nullptr;  // scratch of k_normals3's sparse-hole march (allocated when a launch first picks it)
-  float* tie_scratch = nullptr;  // one float per cell: the step filter at a tie radius (allocated when a launch first needs it, freed with the layers)
-  bool tables_ready = false;
-  // the circular-footprint tables are built separately: a footprint this build cannot handle (more than 20 cells) must
-  // not stop the filter chain or the per-plugin entry points, which never use them (the reference has no such coupling)
-  bool fp_tables_ready = false;
-  int fp_tables_rc = TE_OK;
-  char fp_tables_err[256] = "";
-  // the launch sequence of a whole-map run, captured once per (flags, parameters, geometry) and replayed
-  static constexpr int kGraphs = 4;  // one per flag combination in use
-  hipGraphExec_t graph_exec[kGraphs] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned graph_flags[kGraphs] = {0, 0, 0, 0};
-  int graph_next = 0;
-  bool graph_ok = true;  // cleared after a failed capture: direct launches from then on
-  // streaming tiles (te_upload_tile_async / te_download_tile_async): copy streams, two device staging slots each way
-  struct TileSlot {
-    float* buf = nullptr;
-    size_t cap = 0;                              // in floats
-    hipEvent_t ready = nullptr, freed = nullptr;  // filled / consumed
-    bool used = false;
-  };
-  hipStream_t in_stream = nullptr, out_stream = nullptr;
-  TileSlot in_slot[2], out_slot[2];
-  int in_next = 0, out_next = 0;
-  bool tiles_pending = false;  // te_sync has copy streams to wait for
-  HostStager stager;           // whole-layer transfers through pageable host buffers (te_stage.hip)
-  // te_prefetch_layers: whole-layer uploads on a thread of their own, through a second staging ring and the second copy
-  // pool, beside whatever the caller does meanwhile (a filter on other layers, the download of its output)
-  HostStager prefetcher;
-  hipStream_t prefetch_order = nullptr;  // stands in for the compute stream of HostStager::upload
-  // (one worker per context, started by the first prefetch and kept: a new thread's first HIP call pays the runtime's
-  // per-thread set-up, milliseconds that a 3 ms transfer cannot afford)
-  std::thread prefetch_thread;
-  std::mutex pf_mu;
-  std::condition_variable pf_cv;
-  std::function<void()> pf_job;
-  bool pf_quit = false;
-  bool prefetch_running = false, prefetch_elev = false;  // (prefetch_running: a job is queued or being worked on; under pf_mu)
-  // bit TE_LAYER_* of every layer the prefetch in flight is writing (under mu): a call that runs beside a prefetch joins
-  // it first if it reads or writes one of them (te_run_filter, te_download_layer*)
-  unsigned prefetch_mask = 0;
-  std::atomic<int> prefetch_rc{TE_OK};
-};
 
-namespace {
-int count_invalid_elevation(te_ctx* c);
+namespace te {
+namespace shim {
 // joins a running prefetch (caller holds c->mu); its result stays in c->prefetch_rc until te_wait_prefetch reports it
 void finish_prefetch_locked(te_ctx* c) {
   {
@@ -255,17 +151,6 @@ void finish_prefetch_locked(te_ctx* c) {
     if (mask & (1u << TE_LAYER_TRAVERSABILITY)) c->trav_external = c->trav_ptr_out = true;
   }
 }
-// Every entry point takes the context's mutex through this: a prefetch that is still running is finished first -- except
-// in the calls that are meant to run beside one (te_run_filter, te_download_layer*, the parameter calls).
-struct CtxLock {
-  std::lock_guard<std::mutex> lk;
-  // beside_prefetch: the call may run while a prefetch is in flight -- unless it touches one of the layers the prefetch is
-  // writing (`touches`: bits TE_LAYER_*), in which case it joins it like every other call
-  explicit CtxLock(te_ctx* c, bool beside_prefetch = false, unsigned touches = 0) : lk(c->mu) {
-    if (!beside_prefetch || (touches & c->prefetch_mask)) finish_prefetch_locked(c);
-  }
-};
-constexpr unsigned bit(int layer) { return (layer >= 0 && layer < 32) ? 1u << layer : 0u; }
 // layers TE_FILTER_* reads and writes (travgpu.h: TE_FILTER_* table)
 unsigned filter_layers(int filter) {
   const unsigned normals = bit(TE_LAYER_NORMAL_X) | bit(TE_LAYER_NORMAL_Y) | bit(TE_LAYER_NORMAL_Z);
@@ -278,9 +163,11 @@ unsigned filter_layers(int filter) {
     default: return ~0u;
   }
 }
-}  // namespace
+}  // namespace shim
+}  // namespace te
 
-namespace {
+namespace te {
+namespace shim {
 
 // counts the invalid cells of the whole elevation layer on the context's stream and waits for the result
 int count_invalid_elevation(te_ctx* c) {
@@ -736,7 +623,16 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
   return rc;
 }
 
-}  // namespace
+int sync_tiles(te_ctx* c) {  // the copy streams of the streaming-tile calls
+  if (!c->tiles_pending) return TE_OK;
+  if (c->in_stream) HIP_TRY(hipStreamSynchronize(c->in_stream));
+  if (c->out_stream) HIP_TRY(hipStreamSynchronize(c->out_stream));
+  c->tiles_pending = false;
+  return TE_OK;
+}
+
+}  // namespace shim
+}  // namespace te
 
 extern "C" {
 
@@ -1021,386 +917,6 @@ int te_set_geometry(te_ctx* c, int rows, int cols, int batch, double res, double
   return rebuild_tables(c);
 }
 
-int te_upload_elevation(te_ctx* c, const float* host, int map0, int nmaps) {
-  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: NULL");
-  CtxLock lk(c);
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_elevation: geometry not set");
-  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
-    return fail(TE_ERR_INVALID_ARG, "te_upload_elevation: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(c->stager.upload(c->L.elev + per * map0, host, per * nmaps * sizeof(float), c->stream));
-  // (the count also waits for the copy: the host buffer may be reused as soon as we return)
-  if (const int rc = count_invalid_elevation(c)) return rc;
-  c->have_elev = true;
-  c->chain_done = false;
-  c->footprint_done = false;
-  return TE_OK;
-}
-
-int te_upload_tile(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
-  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile: NULL");
-  CtxLock lk(c);
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_tile: geometry not set");
-  if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows ||
-      col0 + w > c->geo.cols)
-    return fail(TE_ERR_INVALID_ARG, "te_upload_tile: tile (%d,%d)+(%d,%d) outside %dx%d", row0, col0, h, w,
-                c->geo.rows, c->geo.cols);
-  HIP_TRY(hipSetDevice(c->device));
-  float* dst = c->L.elev + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
-  // column-major: w columns of h contiguous rows each
-  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->geo.rows * sizeof(float), host_tile, (size_t)h * sizeof(float),
-                           (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->have_elev = true;
-  c->invalid_cells = -1;  // tiles are not counted: the count of the last whole upload says nothing about them (dense march)
-  return TE_OK;
-}
-
-namespace {
-
-int check_tile(te_ctx* c, const char* who, int map, int row0, int col0, int h, int w) {
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "%s: geometry not set", who);
-  if (map < 0 || map >= c->geo.batch || row0 < 0 || col0 < 0 || h <= 0 || w <= 0 || row0 + h > c->geo.rows || col0 + w > c->geo.cols)
-    return fail(TE_ERR_INVALID_ARG, "%s: tile (%d,%d)+(%d,%d) outside %dx%d", who, row0, col0, h, w, c->geo.rows, c->geo.cols);
-  return TE_OK;
-}
-
-// a staging slot of at least n floats with its two events; growing one waits for whatever still uses it
-int prepare_slot(te_ctx* c, te_ctx::TileSlot& sl, size_t n) {
-  if (!sl.ready) HIP_TRY(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
-  if (!sl.freed) HIP_TRY(hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
-  if (sl.cap < n) {
-    if (sl.buf) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(sl.buf));
-      sl.buf = nullptr;
-      sl.cap = 0;
-      sl.used = false;
-    }
-    HIP_TRY(hipMalloc((void**)&sl.buf, n * sizeof(float)));
-    sl.cap = n;
-  }
-  return TE_OK;
-}
-
-int tile_streams(te_ctx* c) {
-  if (!c->in_stream) HIP_TRY(hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
-  if (!c->out_stream) HIP_TRY(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
-  return TE_OK;
-}
-
-}  // namespace
-
-int te_download_tile(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
-  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile: NULL");
-  CtxLock lk(c);
-  if (const int rc = check_tile(c, "te_download_tile", map, row0, col0, h, w)) return rc;
-  const float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile: bad layer %d", layer);
-  HIP_TRY(hipSetDevice(c->device));
-  const float* src = p + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
-  HIP_TRY(hipMemcpy2DAsync(host_tile, (size_t)h * sizeof(float), src, (size_t)c->geo.rows * sizeof(float), (size_t)h * sizeof(float),
-                           (size_t)w, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return TE_OK;
-}
-
-int te_upload_tile_async(te_ctx* c, const float* host_tile, int map, int row0, int col0, int h, int w) {
-  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_upload_tile_async: NULL");
-  CtxLock lk(c);
-  if (const int rc = check_tile(c, "te_upload_tile_async", map, row0, col0, h, w)) return rc;
-  HIP_TRY(hipSetDevice(c->device));
-  if (const int rc = tile_streams(c)) return rc;
-  te_ctx::TileSlot& sl = c->in_slot[c->in_next];
-  c->in_next ^= 1;
-  if (const int rc = prepare_slot(c, sl, (size_t)h * w)) return rc;
-  // PCIe into the slot on the copy-in stream, once the compute stream has consumed what the slot held before
-  if (sl.used) HIP_TRY(hipStreamWaitEvent(c->in_stream, sl.freed, 0));
-  HIP_TRY(hipMemcpyAsync(sl.buf, host_tile, (size_t)h * w * sizeof(float), hipMemcpyHostToDevice, c->in_stream));
-  HIP_TRY(hipEventRecord(sl.ready, c->in_stream));
-  // into the layer on the compute stream: ordered after every launch already queued there (they may still read the cells)
-  HIP_TRY(hipStreamWaitEvent(c->stream, sl.ready, 0));
-  float* dst = c->L.elev + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
-  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->geo.rows * sizeof(float), sl.buf, (size_t)h * sizeof(float), (size_t)h * sizeof(float),
-                           (size_t)w, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipEventRecord(sl.freed, c->stream));
-  sl.used = true;
-  c->tiles_pending = true;
-  c->have_elev = true;
-  c->invalid_cells = -1;  // (as te_upload_tile)
-  return TE_OK;
-}
-
-int te_download_tile_async(te_ctx* c, int layer, int map, int row0, int col0, int h, int w, float* host_tile) {
-  if (!c || !host_tile) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: NULL");
-  CtxLock lk(c);
-  if (const int rc = check_tile(c, "te_download_tile_async", map, row0, col0, h, w)) return rc;
-  const float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_tile_async: bad layer %d", layer);
-  HIP_TRY(hipSetDevice(c->device));
-  if (const int rc = tile_streams(c)) return rc;
-  te_ctx::TileSlot& sl = c->out_slot[c->out_next];
-  c->out_next ^= 1;
-  if (const int rc = prepare_slot(c, sl, (size_t)h * w)) return rc;
-  // the rectangle as the launches queued so far leave it, copied aside on the compute stream (the next tick may
-  // overwrite it), once the slot's previous content has crossed PCIe
-  if (sl.used) HIP_TRY(hipStreamWaitEvent(c->stream, sl.freed, 0));
-  const float* src = p + (size_t)map * c->geo.rows * c->geo.cols + (size_t)col0 * c->geo.rows + row0;
-  HIP_TRY(hipMemcpy2DAsync(sl.buf, (size_t)h * sizeof(float), src, (size_t)c->geo.rows * sizeof(float), (size_t)h * sizeof(float),
-                           (size_t)w, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(hipEventRecord(sl.ready, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->out_stream, sl.ready, 0));
-  HIP_TRY(hipMemcpyAsync(host_tile, sl.buf, (size_t)h * w * sizeof(float), hipMemcpyDeviceToHost, c->out_stream));
-  HIP_TRY(hipEventRecord(sl.freed, c->out_stream));
-  sl.used = true;
-  c->tiles_pending = true;
-  return TE_OK;
-}
-
-int te_device_ptr(te_ctx* c, int layer, void** dptr, size_t* bytes) {
-  if (!c || !dptr) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: NULL");
-  CtxLock lk(c);
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_device_ptr: geometry not set");
-  if (const int rc = ensure_input_layer(c, layer)) return rc;
-  // (robot_slope: handing out the pointer does not make the layer present -- the buffer is all NaN until the caller
-  // has filled it and says so with te_set_layer_present)
-  float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_device_ptr: bad layer %d", layer);
-  *dptr = p;
-  if (bytes) *bytes = c->layer_elems * sizeof(float);
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
-  if (layer == TE_LAYER_ELEVATION) {  // caller fills the elevation in place (zero-copy producer)
-    c->invalid_cells = -1;
-    c->have_elev = true;
-    c->chain_done = false;
-    c->footprint_done = false;
-  }
-  return TE_OK;
-}
-
-int te_set_layer_present(te_ctx* c, int layer, int present) {
-  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: NULL ctx");
-  CtxLock lk(c);
-  if (layer != TE_LAYER_ROBOT_SLOPE) return fail(TE_ERR_INVALID_ARG, "te_set_layer_present: only the optional input layer robot_slope can be declared present / absent");
-  if (present && !c->robot_slope) return fail(TE_ERR_NOT_READY, "te_set_layer_present: robot_slope was never uploaded nor handed out (te_device_ptr)");
-  c->have_robot_slope = present != 0;
-  return TE_OK;
-}
-
-int te_upload_layer(te_ctx* c, int layer, const float* host, int map0, int nmaps) {
-  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: NULL");
-  if (layer == TE_LAYER_ELEVATION) return te_upload_elevation(c, host, map0, nmaps);
-  CtxLock lk(c);
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer: geometry not set");
-  if (const int rc = ensure_input_layer(c, layer)) return rc;
-  float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer: bad layer %d", layer);
-  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
-    return fail(TE_ERR_INVALID_ARG, "te_upload_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(c->stager.upload(p + per * map0, host, per * nmaps * sizeof(float), c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
-  return TE_OK;
-}
-
-namespace {
-// GridMap layers are circular buffers: logical cell (i, j) is stored at ((i + si) % rows, (j + sj) % cols)
-// (grid_map_core getBufferIndexFromIndex, (si, sj) = GridMap::getStartIndex()).  The device layers are in
-// logical order, so a layer in buffer order moves as (up to) four rectangles.
-// `host` may be unaligned (a payload inside a serialised message).
-hipError_t copy_circular(te_ctx* c, float* dev, void* host, int si, int sj, bool to_device) {
-  const int rows = c->geo.rows, cols = c->geo.cols;
-  const size_t pitch = (size_t)rows * sizeof(float);
-  const int i_split[3] = {0, rows - si, rows}, j_split[3] = {0, cols - sj, cols};
-  for (int bj = 0; bj < 2; ++bj)
-    for (int bi = 0; bi < 2; ++bi) {
-      const int li = i_split[bi], lj = j_split[bj];                  // logical origin of the rectangle
-      const int h = i_split[bi + 1] - li, w = j_split[bj + 1] - lj;  // rows x cols
-      if (h <= 0 || w <= 0) continue;
-      const int ri = (li + si) % rows, rj = (lj + sj) % cols;        // its origin in the buffer
-      float* d = dev + (size_t)lj * rows + li;
-      char* b = (char*)host + ((size_t)rj * rows + ri) * sizeof(float);
-      const hipError_t e = to_device ? hipMemcpy2DAsync(d, pitch, b, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyHostToDevice, c->stream)
-                                     : hipMemcpy2DAsync(b, pitch, d, pitch, (size_t)h * sizeof(float), (size_t)w, hipMemcpyDeviceToHost, c->stream);
-      if (e != hipSuccess) return e;
-    }
-  return hipStreamSynchronize(c->stream);
-}
-}  // namespace
-
-// expect_rows / expect_cols > 0: the caller laid out its host buffer for that shape (the message entry points read the
-// geometry, drop the lock and come back here): fail instead of copying rows*cols cells of another shape
-static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col,
-                                         int expect_rows, int expect_cols);
-static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
-                                           int expect_rows, int expect_cols);
-
-int te_upload_layer_circular(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col) {
-  return upload_layer_circular_checked(c, layer, host, map, start_row, start_col, 0, 0);
-}
-
-static int upload_layer_circular_checked(te_ctx* c, int layer, const float* host, int map, int start_row, int start_col,
-                                         int expect_rows, int expect_cols) {
-  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: NULL");
-  CtxLock lk(c);
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_upload_layer_circular: geometry not set");
-  if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
-    return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
-                c->geo.cols, expect_rows, expect_cols);
-  if (const int rc = ensure_input_layer(c, layer)) return rc;
-  float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: bad layer %d", layer);
-  if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
-    return fail(TE_ERR_INVALID_ARG, "te_upload_layer_circular: map %d, start index (%d,%d) of a %dx%d map", map, start_row,
-                start_col, c->geo.rows, c->geo.cols);
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(copy_circular(c, p + (size_t)map * c->geo.rows * c->geo.cols, const_cast<float*>(host), start_row, start_col, true));
-  if (layer == TE_LAYER_ELEVATION) {
-    if (const int rc = count_invalid_elevation(c)) return rc;
-    c->have_elev = true;
-    c->chain_done = false;
-    c->footprint_done = false;
-  }
-  if (layer == TE_LAYER_ROBOT_SLOPE) c->have_robot_slope = true;
-  if (layer == TE_LAYER_TRAVERSABILITY) c->trav_external = c->trav_ptr_out = true;
-  return TE_OK;
-}
-
-int te_download_layer_circular(te_ctx* c, int layer, float* host, int map, int start_row, int start_col) {
-  return download_layer_circular_checked(c, layer, host, map, start_row, start_col, 0, 0);
-}
-
-static int download_layer_circular_checked(te_ctx* c, int layer, float* host, int map, int start_row, int start_col,
-                                           int expect_rows, int expect_cols) {
-  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: NULL");
-  CtxLock lk(c, /*beside_prefetch*/ true, bit(layer));
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer_circular: geometry not set");
-  if (expect_rows > 0 && (c->geo.rows != expect_rows || c->geo.cols != expect_cols))
-    return fail(TE_ERR_NOT_READY, "the geometry changed to %dx%d under a %dx%d message transfer (another thread)", c->geo.rows,
-                c->geo.cols, expect_rows, expect_cols);
-  float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: bad layer %d", layer);
-  if (map < 0 || map >= c->geo.batch || start_row < 0 || start_row >= c->geo.rows || start_col < 0 || start_col >= c->geo.cols)
-    return fail(TE_ERR_INVALID_ARG, "te_download_layer_circular: map %d, start index (%d,%d) of a %dx%d map", map, start_row,
-                start_col, c->geo.rows, c->geo.cols);
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(copy_circular(c, p + (size_t)map * c->geo.rows * c->geo.cols, host, start_row, start_col, false));
-  return TE_OK;
-}
-
-int te_msg_parse(const void* m, size_t len, te_msg_info* info) {
-  if (!m || !info) return fail(TE_ERR_INVALID_ARG, "te_msg_parse: NULL");
-  msg::View v;
-  std::string err;
-  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_parse: %s", err.c_str());
-  *info = v.info;
-  return TE_OK;
-}
-
-int te_msg_layer(const void* m, size_t len, int k, char* name, size_t* data_offset) {
-  if (!m || !name || !data_offset) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: NULL");
-  msg::View v;
-  std::string err;
-  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: %s", err.c_str());
-  if (k < 0 || k >= (int)v.layers.size()) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: layer %d of %zu", k, v.layers.size());
-  const msg::LayerView& l = v.layers[k];
-  if (l.name_len >= TE_MSG_MAX_NAME) return fail(TE_ERR_INVALID_ARG, "te_msg_layer: layer name longer than %d", TE_MSG_MAX_NAME - 1);
-  memcpy(name, l.name, l.name_len);
-  name[l.name_len] = 0;
-  *data_offset = l.data_off;
-  return TE_OK;
-}
-
-int te_msg_write(const te_msg_info* info, int n_layers, const char* const* names, const float* const* layer_data, int n_basic,
-                 const char* const* basic_names, void* out, size_t cap, size_t* written) {
-  if (!info || !written || (n_layers > 0 && (!names || !layer_data))) return fail(TE_ERR_INVALID_ARG, "te_msg_write: NULL");
-  const msg::Names ln = {n_layers, names}, bn = {n_basic, basic_names};
-  *written = msg::message_size(*info, ln, bn);
-  std::vector<size_t> off;
-  std::string err;
-  if (!msg::write_skeleton(*info, ln, bn, (uint8_t*)out, out ? cap : 0, off, err)) return fail(TE_ERR_INVALID_ARG, "te_msg_write: %s", err.c_str());
-  for (int k = 0; k < n_layers; ++k) {
-    if (!layer_data[k]) return fail(TE_ERR_INVALID_ARG, "te_msg_write: NULL layer data");
-    memcpy((uint8_t*)out + off[k], layer_data[k], (size_t)info->rows * info->cols * sizeof(float));
-  }
-  return TE_OK;
-}
-
-int te_upload_msg(te_ctx* c, const void* m, size_t len, const char* layer_name, int layer, te_msg_info* info) {
-  if (!c || !m || !layer_name) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: NULL");
-  msg::View v;
-  std::string err;
-  if (!msg::parse((const uint8_t*)m, len, v, err)) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: %s", err.c_str());
-  const msg::LayerView* l = nullptr;
-  for (const msg::LayerView& k : v.layers)
-    if (k.name_len == strlen(layer_name) && memcmp(k.name, layer_name, k.name_len) == 0) l = &k;
-  // setElevationMap refuses a message without the elevation layers (TraversabilityMap.cpp:135-154)
-  if (!l) return fail(TE_ERR_INVALID_ARG, "te_upload_msg: the message has no layer '%s'", layer_name);
-  const te_msg_info& mi = v.info;
-  bool same;
-  {
-    CtxLock lk(c);
-    same = c->have_geo && c->geo.rows == mi.rows && c->geo.cols == mi.cols && c->geo.batch == 1 && c->geo.res == mi.resolution &&
-           c->geo.pos_x == mi.pose[0] && c->geo.pos_y == mi.pose[1];
-  }
-  if (!same) {
-    const int rc = te_set_geometry(c, mi.rows, mi.cols, 1, mi.resolution, mi.pose[0], mi.pose[1]);
-    if (rc != TE_OK) return rc;
-  }
-  if (info) *info = mi;
-  // the payload may be unaligned: it is only ever handed to the copy engine
-  return upload_layer_circular_checked(c, layer, reinterpret_cast<const float*>((const uint8_t*)m + l->data_off), 0, mi.start_row,
-                                       mi.start_col, mi.rows, mi.cols);
-}
-
-int te_download_msg(te_ctx* c, const te_msg_info* info, int n_layers, const int* layers, const char* const* names, int n_basic,
-                    const char* const* basic_names, void* out, size_t cap, size_t* written) {
-  if (!c || !info || !written || (n_layers > 0 && (!layers || !names))) return fail(TE_ERR_INVALID_ARG, "te_download_msg: NULL");
-  te_msg_info mi = *info;
-  {
-    CtxLock lk(c);
-    if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_msg: geometry not set");
-    mi.rows = c->geo.rows;
-    mi.cols = c->geo.cols;
-    mi.resolution = c->geo.res;
-    mi.length_x = c->geo.len_x;
-    mi.length_y = c->geo.len_y;
-    mi.pose[0] = c->geo.pos_x;
-    mi.pose[1] = c->geo.pos_y;
-  }
-  const msg::Names ln = {n_layers, names}, bn = {n_basic, basic_names};
-  *written = msg::message_size(mi, ln, bn);
-  std::vector<size_t> off;
-  std::string err;
-  if (!msg::write_skeleton(mi, ln, bn, (uint8_t*)out, out ? cap : 0, off, err)) return fail(TE_ERR_INVALID_ARG, "te_download_msg: %s", err.c_str());
-  for (int k = 0; k < n_layers; ++k) {
-    const int rc = download_layer_circular_checked(c, layers[k], reinterpret_cast<float*>((uint8_t*)out + off[k]), 0, mi.start_row, mi.start_col,
-                                                   mi.rows, mi.cols);
-    if (rc != TE_OK) return rc;
-  }
-  return TE_OK;
-}
-
-int te_bag_find_message(const void* bag, size_t len, const char* topic, size_t* msg_offset, size_t* msg_len) {
-  if (!bag || !topic || !msg_offset || !msg_len) return fail(TE_ERR_INVALID_ARG, "te_bag_find_message: NULL");
-  std::string err;
-  if (!msg::bag_find((const uint8_t*)bag, len, topic, *msg_offset, *msg_len, err)) return fail(TE_ERR_INVALID_ARG, "te_bag_find_message: %s", err.c_str());
-  return TE_OK;
-}
-
-int te_bag_write(const void* m, size_t msg_len, const char* topic, uint32_t stamp_sec, uint32_t stamp_nsec, void* out, size_t cap,
-                 size_t* written) {
-  if (!m || !topic || !written) return fail(TE_ERR_INVALID_ARG, "te_bag_write: NULL");
-  std::string err;
-  if (!msg::bag_write((const uint8_t*)m, msg_len, topic, stamp_sec, stamp_nsec, (uint8_t*)out, out ? cap : 0, *written, err))
-    return fail(TE_ERR_INVALID_ARG, "te_bag_write: %s", err.c_str());
-  return TE_OK;
-}
-
 int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_run_filter: NULL ctx");
   static const char* const kFilterRange[] = {"te_run_filter", "te_run_filter: slope", "te_run_filter: step", "te_run_filter: roughness",
@@ -1488,385 +1004,6 @@ int te_run_footprint(te_ctx* c) {
   return run_footprint_locked(c, TE_RUN_FOOTPRINT_MEMO);
 }
 
-int te_check_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_offset, const double* pose_xy,
-                             unsigned char* is_safe, double* traversability, int* status) {
-  if (!c || n_paths < 0 || (n_paths > 0 && (!pose_offset || !pose_xy || !is_safe || !traversability || !status)))
-    return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: NULL argument");
-  CtxLock lk(c);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: run the chain with the footprint pass first");
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: map %d of %d", map, c->geo.batch);
-  if (c->check_inclination && !c->have_robot_slope)
-    return fail(TE_ERR_NOT_READY, "te_check_footprint_paths: check_robot_inclination is set but the layer robot_slope was never uploaded");
-  if (n_paths == 0) return TE_OK;
-  const int n_poses = pose_offset[n_paths];
-  if (pose_offset[0] != 0 || n_poses < 0) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: bad pose offsets");
-  for (int k = 0; k < n_paths; ++k)
-    if (pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_check_footprint_paths: bad pose offsets");
-  HIP_TRY(hipSetDevice(c->device));
-  // staging buffers for this call (paths are small: a few KB .. MB)
-  const size_t b_off = (size_t)(n_paths + 1) * sizeof(int), b_xy = (size_t)2 * (n_poses > 0 ? n_poses : 1) * sizeof(double);
-  const size_t b_safe = (size_t)n_paths, b_trav = (size_t)n_paths * sizeof(double), b_st = (size_t)n_paths * sizeof(int);
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  char* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, up(b_off) + up(b_xy) + up(b_trav) + up(b_st) + up(b_safe)));
-  int* d_off = (int*)d;
-  double* d_xy = (double*)(d + up(b_off));
-  double* d_trav = (double*)(d + up(b_off) + up(b_xy));
-  int* d_st = (int*)(d + up(b_off) + up(b_xy) + up(b_trav));
-  unsigned char* d_safe = (unsigned char*)(d + up(b_off) + up(b_xy) + up(b_trav) + up(b_st));
-  hipError_t e = hipMemcpyAsync(d_off, pose_offset, b_off, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess && n_poses > 0) e = hipMemcpyAsync(d_xy, pose_xy, (size_t)2 * n_poses * sizeof(double), hipMemcpyHostToDevice, c->stream);
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  if (e == hipSuccess)
-    e = launch_check_circular_paths(c->geo, c->L.footprint + per * map, c->params.fp_default,
-                                    c->check_inclination ? c->robot_slope + per * map : nullptr, n_paths, d_off, d_xy, d_safe,
-                                    d_trav, d_st, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(is_safe, d_safe, b_safe, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, b_st, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_check_footprint_paths: %s", hipGetErrorString(e));
-  return TE_OK;
-}
-
-int te_set_check_robot_inclination(te_ctx* c, int enabled) {
-  if (!c) return fail(TE_ERR_INVALID_ARG, "te_set_check_robot_inclination: NULL");
-  CtxLock lk(c);
-  c->check_inclination = enabled != 0;
-  return TE_OK;
-}
-
-namespace {
-// batched checkInclination on the resident robot_slope layer of map `map`; c->mu held
-int check_inclination_locked(te_ctx* c, int map, int n, const double* start_end_xy, unsigned char* ok, int* status,
-                             const char* who) {
-  if (!c->have_geo || !c->have_robot_slope) return fail(TE_ERR_NOT_READY, "%s: upload the layer robot_slope first", who);
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "%s: map %d of %d", who, map, c->geo.batch);
-  if (n == 0) return TE_OK;
-  HIP_TRY(hipSetDevice(c->device));
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t b_seg = (size_t)4 * n * sizeof(double), b_ok = (size_t)n, b_st = (size_t)n * sizeof(int);
-  char* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, up(b_seg) + up(b_st) + up(b_ok)));
-  double* d_seg = (double*)d;
-  int* d_st = (int*)(d + up(b_seg));
-  unsigned char* d_ok = (unsigned char*)(d + up(b_seg) + up(b_st));
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  hipError_t e = hipMemcpyAsync(d_seg, start_end_xy, b_seg, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = launch_check_inclination(c->geo, c->robot_slope + per * map, n, d_seg, d_ok, d_st, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(ok, d_ok, b_ok, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(status, d_st, b_st, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
-  return TE_OK;
-}
-}  // namespace
-
-int te_check_inclination(te_ctx* c, int map, int n_segments, const double* start_end_xy, unsigned char* ok, int* status) {
-  if (!c || n_segments < 0 || (n_segments > 0 && (!start_end_xy || !ok || !status)))
-    return fail(TE_ERR_INVALID_ARG, "te_check_inclination: NULL argument");
-  CtxLock lk(c);
-  return check_inclination_locked(c, map, n_segments, start_end_xy, ok, status, "te_check_inclination");
-}
-
-int te_run_polygon_footprint(te_ctx* c, int n_points, const double* points_xy, double yaw) {
-  if (!c || !points_xy) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: NULL");
-  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
-    return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
-  if (!isfinite(yaw)) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: yaw is not finite");
-  for (int k = 0; k < 2 * n_points; ++k)
-    if (!isfinite(points_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_run_polygon_footprint: footprint point %d is not finite", k / 2);
-  CtxLock lk(c);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_run_polygon_footprint: run the chain with the footprint pass first (it marks the untraversable cells)");
-  if (c->geo.cols > 65535) return fail(TE_ERR_UNSUPPORTED, "te_run_polygon_footprint: more than 65535 columns");
-  HIP_TRY(hipSetDevice(c->device));
-  if (!c->poly_x) {
-    const size_t lb = (c->layer_elems * sizeof(float) + 255) & ~(size_t)255;
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, 2 * lb);
-    if (e != hipSuccess) return fail(TE_ERR_HIP, "te_run_polygon_footprint: hipMalloc(%zu bytes): %s", 2 * lb, hipGetErrorString(e));
-    c->poly_x = (float*)p;
-    c->poly_rot = (float*)((char*)p + lb);
-  }
-  PolygonArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = n_points;
-  a.def = c->params.fp_default;
-  rotate_footprint(n_points, points_xy, 0.0, a.off[0]);
-  rotate_footprint(n_points, points_xy, yaw, a.off[1]);
-  // offset tables (te_polygon.hip); polygons that do not fit the table format, or te_set_option(TE_OPT_POLYGON_PER_CELL) (a debugging
-  // aid: both kernels give identical layers), take the kernel that evaluates every cell of every bounding box
-  PolygonTables tabs;
-  HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's table upload has been consumed
-  c->poly_stream_host.clear();
-  bool table = !c->opt_polygon_per_cell;
-  for (int w = 0; w < 2 && table; ++w) table = build_polygon_table(c->geo, n_points, a.off[w], c->poly_stream_host, tabs.t[w]);
-  if (!table) {
-    HIP_TRY(launch_polygon_footprint(c->geo, a, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot, c->stream));
-    return TE_OK;
-  }
-  if (c->poly_stream_host.empty()) c->poly_stream_host.push_back(0);
-  if (c->poly_stream_host.size() > c->poly_stream_cap) {
-    if (c->poly_stream) (void)hipFree(c->poly_stream);
-    c->poly_stream = nullptr;
-    c->poly_stream_cap = 0;
-    const size_t cap = c->poly_stream_host.size() + 1024;
-    hipError_t e = hipMalloc((void**)&c->poly_stream, cap * sizeof(unsigned));
-    if (e != hipSuccess) return fail(TE_ERR_HIP, "te_run_polygon_footprint: hipMalloc: %s", hipGetErrorString(e));
-    c->poly_stream_cap = cap;
-  }
-  HIP_TRY(hipMemcpyAsync(c->poly_stream, c->poly_stream_host.data(), c->poly_stream_host.size() * sizeof(unsigned),
-                         hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(launch_polygon_footprint_table(c->geo, a, tabs, c->poly_stream, c->L.trav, c->L.untrav, c->poly_x, c->poly_rot,
-                                         c->stream));
-  return TE_OK;
-}
-
-namespace {
-// isTraversable(polygon) for a batch of validated polygons; context locked, mask present
-int polygons_traversable_locked(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
-                                unsigned char* is_traversable, double* traversability, const char* who) {
-  if (n_polygons == 0) return TE_OK;
-  const int n_vert = vertex_offset[n_polygons];
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t b_off = (size_t)(n_polygons + 1) * sizeof(int), b_xy = (size_t)2 * n_vert * sizeof(double);
-  const size_t b_ok = (size_t)n_polygons, b_trav = (size_t)n_polygons * sizeof(double);
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  char* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, up(b_off) + up(b_xy) + up(b_trav) + up(b_ok)));
-  int* d_off = (int*)d;
-  double* d_xy = (double*)(d + up(b_off));
-  double* d_trav = (double*)(d + up(b_off) + up(b_xy));
-  unsigned char* d_ok = (unsigned char*)(d + up(b_off) + up(b_xy) + up(b_trav));
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  hipError_t e = hipMemcpyAsync(d_off, vertex_offset, b_off, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_xy, vertex_xy, b_xy, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess)
-    e = launch_polygons_traversable(c->geo, c->params.fp_default, n_polygons, d_off, d_xy, c->L.trav + per * map,
-                                    c->L.untrav + per * map, d_ok, d_trav, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(is_traversable, d_ok, b_ok, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(traversability, d_trav, b_trav, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return fail(TE_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
-  return TE_OK;
-}
-}  // namespace
-
-int te_polygons_traversable(te_ctx* c, int map, int n_polygons, const int* vertex_offset, const double* vertex_xy,
-                            unsigned char* is_traversable, double* traversability) {
-  if (!c || n_polygons < 0 || (n_polygons > 0 && (!vertex_offset || !vertex_xy || !is_traversable || !traversability)))
-    return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: NULL argument");
-  CtxLock lk(c);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_polygons_traversable: run the chain with the footprint pass first (it marks the untraversable cells)");
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: map %d of %d", map, c->geo.batch);
-  if (n_polygons == 0) return TE_OK;
-  if (vertex_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: bad vertex offsets");
-  for (int k = 0; k < n_polygons; ++k)
-    if (vertex_offset[k + 1] <= vertex_offset[k])
-      return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: polygon %d has no vertices (or the offsets decrease)", k);
-  const int n_vert = vertex_offset[n_polygons];
-  for (long k = 0; k < 2L * n_vert; ++k)
-    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygons_traversable: vertex %ld is not finite", k / 2);
-  return polygons_traversable_locked(c, map, n_polygons, vertex_offset, vertex_xy, is_traversable, traversability,
-                                     "te_polygons_traversable");
-}
-
-int te_polygon_untraversable_hull(te_ctx* c, int map, int n_vertices, const double* vertex_xy, unsigned char* is_traversable,
-                                  double* traversability, int cap_vertices, int* n_hull, double* hull_xy) {
-  if (!c || !vertex_xy || !is_traversable || !traversability || !n_hull || cap_vertices < 0 || (cap_vertices > 0 && !hull_xy))
-    return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: NULL argument");
-  if (n_vertices < 1) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: a polygon needs at least one vertex");
-  for (long k = 0; k < 2L * n_vertices; ++k)
-    if (!isfinite(vertex_xy[k])) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: vertex %ld is not finite", k / 2);
-  CtxLock lk(c);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_polygon_untraversable_hull: run the chain with the footprint pass first (it marks the untraversable cells)");
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: map %d of %d", map, c->geo.batch);
-  *n_hull = 0;
-  const int off[2] = {0, n_vertices};
-  const int rc = polygons_traversable_locked(c, map, 1, off, vertex_xy, is_traversable, traversability, "te_polygon_untraversable_hull");
-  if (rc != TE_OK || *is_traversable) return rc;  // :635-636 traversable: the empty polygon
-  // untraversable: the rows of the bounding box that hold untraversable cells, then the hull on the host
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t b_xy = (size_t)2 * n_vertices * sizeof(double), b_rows = (size_t)5 * c->geo.rows * sizeof(double);
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  char* d = nullptr;
-  HIP_TRY(hipMalloc((void**)&d, up(b_xy) + b_rows));
-  double* d_xy = (double*)d;
-  double* d_rows = (double*)(d + up(b_xy));
-  std::vector<double> rows5((size_t)5 * c->geo.rows);
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  hipError_t e = hipMemcpyAsync(d_xy, vertex_xy, b_xy, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = launch_polygon_untraversable_rows(c->geo, n_vertices, d_xy, c->L.untrav + per * map, d_rows, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(rows5.data(), d_rows, b_rows, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return fail(TE_ERR_HIP, "te_polygon_untraversable_hull: %s", hipGetErrorString(e));
-  std::vector<double> hull;
-  untraversable_hull_from_rows(c->geo.rows, rows5.data(), hull);
-  *n_hull = (int)(hull.size() / 2);
-  if (*n_hull > cap_vertices)
-    return fail(TE_ERR_INVALID_ARG, "te_polygon_untraversable_hull: the hull has %d vertices, room for %d", *n_hull, cap_vertices);
-  if (!hull.empty()) memcpy(hull_xy, hull.data(), hull.size() * sizeof(double));
-  return TE_OK;
-}
-
-int te_check_polygon_footprint_paths(te_ctx* c, int map, int n_paths, const int* pose_offset, const double* poses, int n_points,
-                                     const double* points_xyz, const unsigned char* conservative, unsigned char* is_safe,
-                                     double* traversability, double* area, int* status) {
-  if (!c || n_paths < 0 || !points_xyz ||
-      (n_paths > 0 && (!pose_offset || !poses || !is_safe || !traversability || !area || !status)))
-    return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: NULL argument");
-  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
-    return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
-  for (int k = 0; k < 3 * n_points; ++k)
-    if (!isfinite(points_xyz[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: footprint point %d is not finite", k / 3);
-  CtxLock lk(c);
-  if (!c->have_geo || !c->footprint_done)
-    return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: run the chain with the footprint pass first (it marks the untraversable cells)");
-  if (map < 0 || map >= c->geo.batch) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: map %d of %d", map, c->geo.batch);
-  if (c->check_inclination && !c->have_robot_slope)
-    return fail(TE_ERR_NOT_READY, "te_check_polygon_footprint_paths: check_robot_inclination is set but the layer robot_slope was never uploaded");
-  if (n_paths == 0) return TE_OK;
-  if (pose_offset[0] != 0) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
-  for (int k = 0; k < n_paths; ++k)
-    if (pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: bad pose offsets");
-  for (long k = 0; k < 7L * pose_offset[n_paths]; ++k)
-    if (!isfinite(poses[k])) return fail(TE_ERR_INVALID_ARG, "te_check_polygon_footprint_paths: pose %ld is not finite", k / 7);
-  // the polygons of all paths: built on the host (hulls, areas), in chunks on a few threads for large requests
-  const int n_chunks = n_paths >= 4096 ? std::min<int>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  std::vector<PathPolygons> chunk(n_chunks);
-  auto first_of = [&](int q) { return (int)((long)n_paths * q / n_chunks); };
-  {
-    std::vector<std::thread> workers;
-    for (int q = 1; q < n_chunks; ++q)
-      workers.emplace_back([&, q]() {
-        const int k0 = first_of(q);
-        build_path_polygons(first_of(q + 1) - k0, pose_offset + k0, poses, n_points, points_xyz,
-                            conservative ? conservative + k0 : nullptr, chunk[q]);
-      });
-    build_path_polygons(first_of(1), pose_offset, poses, n_points, points_xyz, conservative, chunk[0]);
-    for (std::thread& w : workers) w.join();
-  }
-  // checkRobotInclination_ (:526-528, :553-557): one checkInclination per pose of a one-pose path / per segment
-  // otherwise, all of them in one launch; incl_first[k] = index of path k's first test
-  std::vector<unsigned char> incl_ok;
-  std::vector<int> incl_st, incl_first;
-  if (c->check_inclination) {
-    incl_first.assign((size_t)n_paths + 1, 0);
-    std::vector<double> seg;
-    for (int k = 0; k < n_paths; ++k) {
-      const int n = pose_offset[k + 1] - pose_offset[k];
-      const double* q = poses + 7 * (size_t)pose_offset[k];
-      if (n == 1) {
-        seg.insert(seg.end(), {q[0], q[1], q[0], q[1]});
-      } else {
-        for (int i = 1; i < n; ++i) seg.insert(seg.end(), {q[7 * (i - 1)], q[7 * (i - 1) + 1], q[7 * i], q[7 * i + 1]});
-      }
-      incl_first[k + 1] = (int)(seg.size() / 4);
-    }
-    const int n_seg = incl_first[n_paths];
-    incl_ok.assign(n_seg > 0 ? n_seg : 1, 0);
-    incl_st.assign(n_seg > 0 ? n_seg : 1, 0);
-    const int rc = check_inclination_locked(c, map, n_seg, seg.data(), incl_ok.data(), incl_st.data(),
-                                            "te_check_polygon_footprint_paths");
-    if (rc != TE_OK) return rc;
-  }
-  std::vector<unsigned char> ok;
-  std::vector<double> val;
-  for (int q = 0; q < n_chunks; ++q) {
-    const PathPolygons& pp = chunk[q];
-    const int k0 = first_of(q), nk = first_of(q + 1) - k0;
-    const int n_poly = (int)pp.area.size();
-    ok.assign(n_poly > 0 ? n_poly : 1, 0);
-    val.assign(n_poly > 0 ? n_poly : 1, 0.0);
-    const int rc = polygons_traversable_locked(c, map, n_poly, pp.vertex_offset.data(), pp.vertex_xy.data(), ok.data(),
-                                               val.data(), "te_check_polygon_footprint_paths");
-    if (rc != TE_OK) return rc;
-    // the loop of :480-580 over the precomputed polygons; a path stops at its first untraversable polygon and keeps
-    // the partial traversability / area, like `result` in the reference
-    for (int kk = 0; kk < nk; ++kk) {
-      const int k = k0 + kk;
-      is_safe[k] = 0;
-      traversability[k] = 0.0;
-      area[k] = 0.0;
-      status[k] = pp.status[kk];
-      if (pp.status[kk] == 2) continue;
-      const int n = pose_offset[k + 1] - pose_offset[k];
-      bool good = true;
-      for (int s = 0; s < pp.count[kk] && good; ++s) {
-        const int g = pp.first[kk] + s;
-        if (c->check_inclination && !incl_ok[incl_first[k] + s]) {  // before isTraversable (:553-557); the partial result stays
-          status[k] = incl_st[incl_first[k] + s];
-          good = false;
-          break;
-        }
-        if (!ok[g]) {
-          good = false;
-          break;
-        }
-        if (n == 1 || s == 0) {  // :543-544, :576-577
-          area[k] = pp.area[g];
-          traversability[k] = val[g];
-        } else {  // :570-575
-          const double area_previous = area[k];
-          const double area_polygon = pp.area[g] - pp.area_previous[g];
-          area[k] += area_polygon;
-          traversability[k] = (area_polygon * val[g] + area_previous * traversability[k]) / area[k];
-        }
-      }
-      if (good && pp.status[kk] == 0) is_safe[k] = 1;
-    }
-  }
-  return TE_OK;
-}
-
-int te_path_polygons(int n_paths, const int* pose_offset, const double* poses, int n_points, const double* points_xyz,
-                     const unsigned char* conservative, int cap_polygons, int cap_vertices, int* n_polygons, int* n_vertices,
-                     int* polygon_first, int* vertex_offset, double* vertex_xy, double* area) {
-  if (n_paths < 0 || !n_polygons || !n_vertices || !points_xyz || (n_paths > 0 && (!pose_offset || !poses)))
-    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL argument");
-  if (n_points < 1 || n_points > TE_MAX_POLYGON_VERTICES)
-    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d footprint points (1..%d)", n_points, TE_MAX_POLYGON_VERTICES);
-  for (int k = 0; k < n_paths; ++k)
-    if (pose_offset[0] != 0 || pose_offset[k + 1] < pose_offset[k]) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: bad pose offsets");
-  // the same input checks as te_check_polygon_footprint_paths: a NaN pose would otherwise come back as a degenerate hull
-  for (int k = 0; k < 3 * n_points; ++k)
-    if (!isfinite(points_xyz[k])) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: footprint point %d is not finite", k / 3);
-  for (long k = 0; n_paths > 0 && k < 7L * pose_offset[n_paths]; ++k)
-    if (!isfinite(poses[k])) return fail(TE_ERR_INVALID_ARG, "te_path_polygons: pose %ld is not finite", k / 7);
-  PathPolygons pp;
-  build_path_polygons(n_paths, pose_offset, poses, n_points, points_xyz, conservative, pp);
-  *n_polygons = (int)pp.area.size();
-  *n_vertices = pp.vertex_offset.back();
-  if (*n_polygons > cap_polygons || *n_vertices > cap_vertices)
-    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: %d polygons / %d vertices do not fit the buffers (%d / %d)", *n_polygons,
-                *n_vertices, cap_polygons, cap_vertices);
-  // (nothing to write: a sizing call, or paths without poses -- the buffers may be NULL then)
-  if (!polygon_first || !vertex_offset || (*n_vertices && !vertex_xy) || (*n_polygons && !area))
-    return fail(TE_ERR_INVALID_ARG, "te_path_polygons: NULL output");
-  for (int k = 0; k < n_paths; ++k) polygon_first[k] = pp.first[k];
-  polygon_first[n_paths] = *n_polygons;
-  memcpy(vertex_offset, pp.vertex_offset.data(), pp.vertex_offset.size() * sizeof(int));
-  if (*n_vertices) memcpy(vertex_xy, pp.vertex_xy.data(), pp.vertex_xy.size() * sizeof(double));
-  if (*n_polygons) memcpy(area, pp.area.data(), pp.area.size() * sizeof(double));
-  return TE_OK;
-}
-
-static int sync_tiles(te_ctx* c) {  // the copy streams of the streaming-tile calls
-  if (!c->tiles_pending) return TE_OK;
-  if (c->in_stream) HIP_TRY(hipStreamSynchronize(c->in_stream));
-  if (c->out_stream) HIP_TRY(hipStreamSynchronize(c->out_stream));
-  c->tiles_pending = false;
-  return TE_OK;
-}
-
 int te_sync(te_ctx* c) {
   if (!c) return fail(TE_ERR_INVALID_ARG, "te_sync: NULL ctx");
   CtxLock lk(c);
@@ -1886,241 +1023,6 @@ int te_sync(te_ctx* c) {
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return sync_tiles(c);
-}
-
-int te_download_layer(te_ctx* c, int layer, float* host, int map0, int nmaps) {
-  if (!c || !host) return fail(TE_ERR_INVALID_ARG, "te_download_layer: NULL");
-  CtxLock lk(c, /*beside_prefetch*/ true, bit(layer));
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_download_layer: geometry not set");
-  float* p = layer_ptr(c, layer);
-  if (!p) return fail(TE_ERR_INVALID_ARG, "te_download_layer: bad layer %d", layer);
-  if (map0 < 0 || nmaps <= 0 || map0 + nmaps > c->geo.batch)
-    return fail(TE_ERR_INVALID_ARG, "te_download_layer: maps [%d,%d) of batch %d", map0, map0 + nmaps, c->geo.batch);
-  HIP_TRY(hipSetDevice(c->device));
-  const size_t per = (size_t)c->geo.rows * c->geo.cols;
-  HIP_TRY(c->stager.download(host, p + per * map0, per * nmaps * sizeof(float), c->stream));
-  return TE_OK;
-}
-
-// Whole-layer uploads that run BESIDE the calls that follow (see travgpu.h).  The reference's chain hands every plugin the
-// whole map (SlopeFilter.cpp:62-63, StepFilter.cpp:105-107, RoughnessFilter.cpp:76-77), so a plugin knows the layers its
-// successors will read: their upload can cross PCIe host -> device while its own output crosses device -> host.
-int te_prefetch_layers(te_ctx* c, int n, const int* layers, const float* const* hosts) {
-  if (!c || n <= 0 || n > 8 || !layers || !hosts) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: bad argument");
-  CtxLock lk(c);  // (an earlier prefetch is finished first)
-  if (!c->have_geo) return fail(TE_ERR_NOT_READY, "te_prefetch_layers: geometry not set");
-  if (c->prefetch_rc.load() != TE_OK) return fail(TE_ERR_HIP, "te_prefetch_layers: an earlier prefetch failed (te_wait_prefetch reports it)");
-  struct Job {
-    float* dev;
-    const float* host;
-  };
-  std::vector<Job> jobs;
-  bool elev = false;
-  unsigned mask = 0;
-  for (int k = 0; k < n; ++k) {
-    if (!hosts[k]) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: NULL host buffer");
-    if (layers[k] != TE_LAYER_ELEVATION) {
-      if (const int rc = ensure_input_layer(c, layers[k])) return rc;
-    }
-    float* p = layer_ptr(c, layers[k]);
-    if (!p) return fail(TE_ERR_INVALID_ARG, "te_prefetch_layers: bad layer %d", layers[k]);
-    jobs.push_back(Job{p, hosts[k]});
-    elev = elev || layers[k] == TE_LAYER_ELEVATION;
-    mask |= bit(layers[k]);
-  }
-  HIP_TRY(hipSetDevice(c->device));
-  if (!c->prefetch_order) HIP_TRY(hipStreamCreateWithFlags(&c->prefetch_order, hipStreamNonBlocking));
-  // what the compute stream has queued so far may still read these layers
-  HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->prefetch_order, c->ev0, 0));
-  c->prefetcher.pool = 1;
-  const size_t bytes = c->layer_elems * sizeof(float);
-  const int device = c->device;
-  auto work = [c, jobs, bytes, device] {
-    int rc = TE_OK;
-    if (hipSetDevice(device) != hipSuccess) rc = TE_ERR_HIP;
-    for (size_t k = 0; k < jobs.size() && rc == TE_OK; ++k)
-      if (c->prefetcher.upload(jobs[k].dev, jobs[k].host, bytes, c->prefetch_order) != hipSuccess) rc = TE_ERR_HIP;
-    if (rc == TE_OK && hipStreamSynchronize(c->prefetch_order) != hipSuccess) rc = TE_ERR_HIP;
-    if (rc != TE_OK) (void)hipGetLastError();
-    c->prefetch_rc.store(rc);
-  };
-  c->prefetch_elev = elev;
-  c->prefetch_mask = mask;
-  if (!c->prefetch_thread.joinable()) {
-    try {
-      c->prefetch_thread = std::thread([c] {
-        for (;;) {
-          std::function<void()> job;
-          {
-            std::unique_lock<std::mutex> pl(c->pf_mu);
-            c->pf_cv.wait(pl, [c] { return c->pf_quit || (bool)c->pf_job; });
-            if (c->pf_quit) return;
-            job.swap(c->pf_job);
-          }
-          job();
-          {
-            std::lock_guard<std::mutex> pl(c->pf_mu);
-            c->prefetch_running = false;
-          }
-          c->pf_cv.notify_all();
-        }
-      });
-    } catch (...) {  // no thread to be had: the uploads happen here and now
-      work();
-      finish_prefetch_locked(c);
-      return TE_OK;
-    }
-  }
-  {
-    std::lock_guard<std::mutex> pl(c->pf_mu);
-    c->pf_job = work;
-    c->prefetch_running = true;
-  }
-  c->pf_cv.notify_all();
-  return TE_OK;
-}
-
-int te_wait_prefetch(te_ctx* c) {
-  if (!c) return fail(TE_ERR_INVALID_ARG, "te_wait_prefetch: NULL ctx");
-  CtxLock lk(c);  // (joins the prefetch)
-  const int rc = c->prefetch_rc.exchange(TE_OK);
-  if (rc != TE_OK) return fail(rc, "te_prefetch_layers: a transfer failed");
-  return TE_OK;
-}
-
-int te_pin_host(void* host, size_t bytes) {
-  if (!host || !bytes) return fail(TE_ERR_INVALID_ARG, "te_pin_host: NULL or empty buffer");
-  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
-  return TE_OK;
-}
-
-int te_unpin_host(void* host) {
-  if (!host) return fail(TE_ERR_INVALID_ARG, "te_unpin_host: NULL");
-  HIP_TRY(hipHostUnregister(host));
-  return TE_OK;
-}
-
-int te_shard_range(int batch, int n_shards, int k, int* first, int* count) {
-  if (!first || !count || batch < 0 || n_shards <= 0 || k < 0 || k >= n_shards)
-    return fail(TE_ERR_INVALID_ARG, "te_shard_range: batch=%d n_shards=%d k=%d", batch, n_shards, k);
-  const int base = batch / n_shards, extra = batch % n_shards;
-  *first = k * base + (k < extra ? k : extra);
-  *count = base + (k < extra ? 1 : 0);
-  return TE_OK;
-}
-
-namespace {
-// the few RCCL entry points the parameter broadcast needs, resolved at run time (no link-time dependency: a single-GPU
-// host never loads the library)
-struct Rccl {
-  typedef void* comm_t;
-  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
-  int (*CommDestroy)(comm_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  int (*Broadcast)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
-  bool ok = false;
-  Rccl() {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return;
-    CommInitAll = (int (*)(comm_t*, int, const int*))dlsym(h, "ncclCommInitAll");
-    CommDestroy = (int (*)(comm_t))dlsym(h, "ncclCommDestroy");
-    GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
-    GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
-    Broadcast = (int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t))dlsym(h, "ncclBroadcast");
-    ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast;
-  }
-};
-}  // namespace
-
-int te_bcast_params(te_ctx** ctxs, int n, int root) {
-  if (!ctxs || n <= 0 || root < 0 || root >= n) return fail(TE_ERR_INVALID_ARG, "te_bcast_params: n=%d root=%d", n, root);
-  for (int k = 0; k < n; ++k)
-    if (!ctxs[k]) return fail(TE_ERR_INVALID_ARG, "te_bcast_params: NULL context %d", k);
-  te_params p;
-  int rc = te_get_params(ctxs[root], &p);
-  if (rc) return rc;
-  // one representative context per device (the root for its own); the others on a device are served from the host copy
-  std::vector<int> devs, rep;
-  devs.push_back(ctxs[root]->device);
-  rep.push_back(root);
-  for (int k = 0; k < n; ++k) {
-    bool seen = false;
-    for (int d : devs) seen = seen || d == ctxs[k]->device;
-    if (!seen) {
-      devs.push_back(ctxs[k]->device);
-      rep.push_back(k);
-    }
-  }
-  std::vector<te_params> got(devs.size(), p);
-  if (devs.size() > 1) {
-    static Rccl rccl;
-    if (!rccl.ok) return fail(TE_ERR_UNSUPPORTED, "te_bcast_params: %zu devices but librccl could not be loaded", devs.size());
-    const int nd = (int)devs.size();
-    std::vector<Rccl::comm_t> comms(nd, nullptr);
-    std::vector<void*> buf(nd, nullptr);
-    // streams of this call's own: the contexts' streams belong to their mutexes, and this is configure-time
-    std::vector<hipStream_t> st(nd, nullptr);
-    int e = rccl.CommInitAll(comms.data(), nd, devs.data());
-    if (e) return fail(TE_ERR_HIP, "te_bcast_params: ncclCommInitAll failed (%d)", e);
-    bool bad = false;
-    for (int d = 0; d < nd && !bad; ++d) {
-      bad = hipSetDevice(devs[d]) != hipSuccess || hipMalloc(&buf[d], sizeof(te_params)) != hipSuccess ||
-            hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking) != hipSuccess;
-      if (!bad && d == 0) bad = hipMemcpy(buf[0], &p, sizeof(te_params), hipMemcpyHostToDevice) != hipSuccess;
-    }
-    if (!bad) {
-      rccl.GroupStart();
-      for (int d = 0; d < nd; ++d) {  // rank 0 is the root's device; ncclChar == 0
-        (void)hipSetDevice(devs[d]);
-        e = e ? e : rccl.Broadcast(buf[d], buf[d], sizeof(te_params), 0, 0, comms[d], st[d]);
-      }
-      e = rccl.GroupEnd() || e;
-      for (int d = 0; d < nd && !e; ++d) {
-        (void)hipSetDevice(devs[d]);
-        bad = bad || hipStreamSynchronize(st[d]) != hipSuccess ||
-              hipMemcpy(&got[d], buf[d], sizeof(te_params), hipMemcpyDeviceToHost) != hipSuccess;
-      }
-    }
-    for (int d = 0; d < nd; ++d) {
-      (void)hipSetDevice(devs[d]);
-      if (buf[d]) (void)hipFree(buf[d]);
-      if (st[d]) (void)hipStreamDestroy(st[d]);
-      if (comms[d]) rccl.CommDestroy(comms[d]);
-    }
-    if (bad || e) {
-      (void)hipGetLastError();
-      return fail(TE_ERR_HIP, "te_bcast_params: RCCL broadcast failed (%d)", e);
-    }
-  }
-  for (int k = 0; k < n; ++k) {
-    if (k == root) continue;
-    size_t d = 0;
-    while (d < devs.size() && devs[d] != ctxs[k]->device) ++d;
-    rc = te_set_params(ctxs[k], &got[d]);
-    if (rc) return rc;
-  }
-  return TE_OK;
-}
-
-int te_run_chain_multi(te_ctx** ctxs, int n, unsigned flags) {
-  if (!ctxs || n <= 0) return fail(TE_ERR_INVALID_ARG, "te_run_chain_multi: n=%d", n);
-  for (int k = 0; k < n; ++k) {
-    const int rc = te_run_chain(ctxs[k], flags);
-    if (rc) return rc;
-  }
-  return TE_OK;
-}
-
-int te_sync_multi(te_ctx** ctxs, int n) {
-  if (!ctxs || n <= 0) return fail(TE_ERR_INVALID_ARG, "te_sync_multi: n=%d", n);
-  for (int k = 0; k < n; ++k) {
-    const int rc = te_sync(ctxs[k]);
-    if (rc) return rc;
-  }
-  return TE_OK;
 }
 
 int te_time_chain(te_ctx* c, unsigned flags, int warmup, int iters, float* ms_per_iter) {
