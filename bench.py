@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
-VALU_CYCLES_PER_INST, N_SIMDS, CLOCK_HZ = 4.2, 1024, 2.4e9  # measured issue rate of fp64 / 3-operand instructions per SIMD (profiles/r01_valu_rates.txt)
+N_SIMDS, CLOCK_HZ = 1024, 2.4e9
 FP64_LANE_OPS_PEAK = 39.3e12  # 78.6 TFLOP/s vector fp64 = 39.3e12 fused multiply-adds (lane operations) per second
 # double-precision lane operations per cell of one launch: the sliding moments of k_normals3 (6 per disc
 # column and edge + 1 per distinct run length: 118 at R = 9, scaled with 2R+1 for other radii) and its tail (31)
@@ -624,30 +624,33 @@ def main():
             else:
                 out["roofline"]["traffic_unit"] = f"not reported: profiles/{os.path.basename(tpaths[0])} was taken with other kernel sources"
         # What this FORMULATION can reach at most: the launch is bound by vector-instruction issue, so
-        # the sum of the kernels' VALU floors -- executed vector instructions (SQ_INSTS_VALU of the committed counter
-        # profile) x 4.2 cycles per wavefront instruction / (1024 SIMDs x 2.4 GHz) -- is a lower bound of its time,
-        # whatever the overlap.  `frac` is to be read against this ceiling, not against 1.
-        spaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), reverse=True)
-        if spaths and is_cfg3:
+        # the sum of the kernels' issue floors is a lower bound of its time, whatever the overlap.  Round 6 prices the
+        # executed VALU instructions BY CLASS (tools/valu_classes.py -> profiles/rNN_valu_classes.json: fp64 as counted by
+        # SQ_INSTS_VALU_*_F64 at 4.2 cycles per SIMD, the rest split by each kernel's loop mix into the 4.2-cycle class --
+        # 3-operand, min / max, compare, select, convert --, the 2.2-cycle class -- plain float32 / integer -- and float32
+        # transcendentals at 8.2); round 5 priced all of them at 4.2, which flattered the efficiency.  `frac` is to be read
+        # against this ceiling, not against 1.
+        vpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_classes.json")), reverse=True)
+        if vpaths and is_cfg3:
             try:
-                sq = json.load(open(spaths[0]))
-                floors = {}
-                for kname, rec in sq.items():
-                    if kname.startswith("k_combine") or kname.startswith("k_count_invalid") or kname == "kernel_sources_sha16":
-                        continue  # (the sequential profile's separate combine: inside k_fp_mask in the timed launch; upload-time count)
-                    v = rec.get("counters", {}).get("SQ_INSTS_VALU")
-                    if v:
-                        floors[kname] = v * VALU_CYCLES_PER_INST / (N_SIMDS * CLOCK_HZ) * 1e6
-                floor_us = sum(floors.values())
-                if floor_us > 0:
-                    ceiling = cells_timed * bytes_per_cell / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                vc = json.load(open(vpaths[0]))
+                if vc.get("kernel_sources_sha16") != kernel_sources_sha16():
+                    out["roofline"]["formulation_ceiling_error"] = f"profiles/{os.path.basename(vpaths[0])} was taken with other kernel sources"
+                else:
+                    floor_cls, floor_all = vc["sum_issue_floor_us_by_class"], vc["sum_issue_floor_us_all_at_4.2"]
+                    ceiling = cells_timed * bytes_per_cell / (floor_cls * 1e-6) / 1e9 / HBM_PEAK_GBS
                     out["roofline"]["formulation_ceiling"] = ceiling
                     out["roofline"]["frac_of_ceiling"] = out["roofline"]["frac"] / ceiling
                     out["roofline"]["formulation_ceiling_what"] = {
-                        "valu_floor_us": {k: round(v, 1) for k, v in sorted(floors.items())}, "valu_floor_us_sum": round(floor_us, 1),
-                        "model": f"SQ_INSTS_VALU x {VALU_CYCLES_PER_INST} cycles / ({N_SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz), every kernel of the launch; "
-                                 "fp64 and 3-operand instructions issue once per 4.2 cycles per SIMD (profiles/r01_valu_rates.txt)",
-                        "source": f"profiles/{os.path.basename(spaths[0])}",
+                        "issue_floor_us_by_class": {k: v.get("issue_floor_us_by_class") for k, v in vc["kernels"].items()},
+                        "issue_floor_us_sum_by_class": floor_cls,
+                        "issue_floor_us_sum_all_at_4.2": floor_all,
+                        "formulation_ceiling_all_at_4.2 (round 5's model)": cells_timed * bytes_per_cell / (floor_all * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "model": "executed VALU instructions per launch (SQ counters) priced by class: fp64 / 3-operand / min-max / compare / select / convert "
+                                 f"4.2 cycles per SIMD, plain float32 and 2-operand integer 2.2, float32 transcendental 8.2 (profiles/r01_valu_rates.txt), "
+                                 f"/ ({N_SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz); the 2.2-cycle rate needs >= 4 waves per SIMD, so the floor is a lower bound "
+                                 "of the time and the ceiling an upper bound of the formulation's reach",
+                        "source": f"profiles/{os.path.basename(vpaths[0])} ({vc.get('counters')})",
                         "note": "an fp64 sliding-disc formulation at R = 9 is bound by vector-instruction issue, not by HBM: "
                                 "the 50 % north-star presumes a bandwidth-bound stencil, which this is not (DESIGN.md 4)"}
             except (OSError, ValueError, KeyError) as e:

@@ -1,10 +1,30 @@
-"""Host logic of the hole routing (te_shim.hip: k_count_invalid, clustered_holes, sparse_holes, short_strips), restated in
-numpy on the maps the hole benches use: the upload counts the invalid cells and their RUNS in memory order; scattered cells
-(runs of one) take the sparse march up to 2 per mille and the dense march on long strips above, unobserved regions (runs of
-eight and more on average) the dense march on strips of 32 rows however few they are."""
-import numpy as np
+"""The hole routing on the maps the hole benches use, decided by the shim's OWN code: tests/cpu/hole_routing_check.cpp is
+compiled from traversability_estimation_amd/csrc/te_hole_routing.h, the header te_shim.hip routes with.  The upload counts
+the invalid cells and their RUNS in memory order (k_count_invalid; the definition is restated in count_invalid below and
+checked on the device by tests/test_gpu_round6.py); scattered cells (runs of one) take the sparse march up to 2 per mille and
+the dense march on long strips above, unobserved regions (runs of eight and more on average) the dense march on strips of
+32 rows however few they are."""
+import os
+import subprocess
 
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
 from traversability_estimation_amd import synth
+
+
+@pytest.fixture(scope="module")
+def router(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("route") / "hole_routing_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "traversability_estimation_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpu", "hole_routing_check.cpp"), "-o", str(exe)], check=True, timeout=300)
+
+    def route(elev):
+        n, runs = count_invalid(elev)
+        r = subprocess.run([str(exe), str(elev.size), str(n), str(runs)], capture_output=True, text=True, check=True, timeout=60)
+        return r.stdout.strip().replace(", clean attempt skipped", "")
+    return route
 
 
 def count_invalid(elev):
@@ -12,14 +32,6 @@ def count_invalid(elev):
     flat = ~np.isfinite(np.ascontiguousarray(elev).ravel())
     prev = np.concatenate([[False], flat[:-1]])
     return int(flat.sum()), int((flat & ~prev).sum())
-
-
-def route(elev):
-    n, runs = count_invalid(elev)
-    clustered = n > 0 and runs * 8 <= n                     # clustered_holes
-    sparse = n > 0 and n <= 0.002 * elev.size and not clustered   # sparse_holes
-    short = clustered and not sparse                        # short_strips
-    return "clean" if n == 0 else "sparse" if sparse else "dense, short strips" if short else "dense"
 
 
 def regions(n, fraction, seed=99):
@@ -34,7 +46,8 @@ def regions(n, fraction, seed=99):
     return e
 
 
-def test_routing_of_the_hole_bench_maps():
+def test_routing_of_the_hole_bench_maps(router):
+    route = router
     n = 1024
     base = synth.perlin_elevation(n, n, seed=3)
     assert route(base) == "clean"

@@ -50,6 +50,13 @@ def main():
             derived["mean_resident_waves_per_busy_sq_cycle"] = round(c["SQ_WAVE_CYCLES"] / c["SQ_BUSY_CYCLES"], 2)
         d["derived"] = derived
         out[k] = d
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:  # ties the counters to the kernel sources they were measured with (bench.py, tools/valu_classes.py check it)
+        import bench
+        out["kernel_sources_sha16"] = bench.kernel_sources_sha16()
+    except Exception:
+        pass
     json.dump(out, sys.stdout, indent=1)
     print()
 

@@ -103,12 +103,25 @@ def hottest_loop(body):
     return body[best[0]:best[1] + 1] if best else body
 
 
+def kernel_sources_sha16():
+    """As bench.py: identifies the kernel sources a profile belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "traversability_estimation_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     sq_path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))[-1]
     sq = json.load(open(sq_path))
     objdir = os.path.join(ROOT, "traversability_estimation_amd", "_build")
     out = {"what": __doc__.split("\n")[0], "cycles_per_instruction_per_simd": CYCLES, "fast32_opcodes": sorted(FAST32),
-           "counters": os.path.relpath(sq_path, ROOT), "kernels": {}}
+           "counters": os.path.relpath(sq_path, ROOT), "counters_kernel_sources_sha16": sq.get("kernel_sources_sha16"),
+           "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
     tot_all, tot_cls = 0.0, 0.0
     with tempfile.TemporaryDirectory() as tmp:
         cache = {}

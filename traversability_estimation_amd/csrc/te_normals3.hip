@@ -33,6 +33,7 @@
 // Cells whose disc meets an invalid cell are left NaN and their 64x16 tile is flagged for k_normals_fixup, as before.
 #include "te_internal.h"
 #include "te_march.h"
+#include "te_n3_plan.h"
 #include "te_eig.h"
 #include "te_eig3.h"
 
@@ -1088,35 +1089,11 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
   return jend;
 }
 
-// Which strip a block works on (uniform): blocks [0, nb_fast) are the interior columns x interior rows, then come the edge
-// block columns over all rows, then the top and the bottom frame rows of the interior columns.  false: nothing to do.
+// Which strip a block works on: te_n3_plan.h (the same code runs in the CPU test harness)
 __device__ __forceinline__ bool n3_block(const N3Args& a, int& i0, int& own_lo, int& js, int& jend, bool& general) {
-  int b = (int)blockIdx.x, bx;
-  general = true;
-  const int nb_fast = a.n_int * a.s_int, ne = a.edge0 + a.edge1;
-  if (b < nb_fast) {
-    general = false;
-    bx = a.edge0 + b % a.n_int;
-    js = a.jf_lo + (b / a.n_int) * a.rows_int;
-    jend = js + a.rows_int < a.jf_hi ? js + a.rows_int : a.jf_hi;
-  } else if ((b -= nb_fast) < ne * a.s_edge) {
-    const int q = b % ne;
-    bx = q < a.edge0 ? q : a.nbx - ne + q;
-    js = a.j_lo + (b / ne) * a.rows_edge;
-    jend = js + a.rows_edge < a.j_hi ? js + a.rows_edge : a.j_hi;
-  } else {
-    b -= ne * a.s_edge;
-    const bool bottom = b >= a.n_top;  // n_top = n_int if the region has top frame rows, else 0
-    bx = a.edge0 + (bottom ? b - a.n_top : b);
-    js = bottom ? a.jf_hi : a.j_lo;
-    jend = bottom ? a.j_hi : a.jf_lo;
-  }
-  own_lo = a.i_lo + bx * kLanes;
-  i0 = own_lo + kLanes > a.i_hi ? a.i_hi - kLanes : own_lo;  // the last block ends at the edge
-  return js < jend;
+  return n3_block_of(a, (int)blockIdx.x, i0, own_lo, js, jend, general);
 }
 
-constexpr int kN3ShortStripRows = 32;  // strip height of the dense march on maps with counted invalid cells (launch3)
 constexpr int kN3TieWaves = 3;  // the TIES march holds 168 registers and 170 bytes of scratch (local copies of the moments, the general
                                 // tail on every row); compiled for 2 waves the compiler takes all 256 and spills 500 bytes on top
 template <int Q, bool KEEP, int HM, bool TIES = false>
@@ -1236,72 +1213,19 @@ int resident_blocks(bool ties = false) {
 template <int Q>
 bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s) {
   N3Args a = a0;
-  const int H = a.j_hi - a.j_lo;
   // As many blocks as fill the resident wave slots in ONE round.  Edge block columns run the general tail on every row
   // (about 1.5x the time of an interior row): their strips are 1.5x shorter so that all blocks finish together.
   static const bool no_slim = lab_flag("TE_N3_NO_SLIM");  // measurement aid
   const bool slim = slim_shape<Q>() && a.no_holes && !keep && a.n_ties == 0 && !no_slim;
   const int resident = slim ? resident_blocks_slim<Q>() : keep ? resident_blocks<Q, true>(a.n_ties != 0) : resident_blocks<Q, false>(a.n_ties != 0);
-  const int capacity = resident / (maps > 0 ? maps : 1);
-  const double capacity_f = (double)resident / (double)(maps > 0 ? maps : 1);  // slots per map
-  const int ne = a.edge0 + a.edge1;
   constexpr int R = Shape<Q>::R;
-  a.n_int = a.nbx - ne;
-  a.jf_lo = a.j_lo > R ? a.j_lo : (R < a.j_hi ? R : a.j_hi);                          // first row below the top frame
-  a.jf_hi = a.j_hi < g.cols - R ? a.j_hi : (g.cols - R > a.jf_lo ? g.cols - R : a.jf_lo);  // one past the last above the bottom frame
-  a.n_top = a.jf_lo > a.j_lo ? a.n_int : 0;
-  const int n_bottom = a.j_hi > a.jf_hi ? a.n_int : 0;
-  const int Hf = a.jf_hi - a.jf_lo;
-  int rows_int = 512;
   static const int pct_env = lab_int("TE_N3_EDGE_PERCENT", 50);  // measurement aid: strip height of the edge columns in percent
-  const int pct = pct_env > 0 ? pct_env : 50;
-  auto edge_rows = [&](int h) { return (pct * h + 99) / 100; };
+  static const int rows_env = lab_int("TE_N3_STRIP_ROWS", 0);    // measurement aid
+  // strips of 32 rows only when the upload counted invalid cells and the dense march serves them (Layers::short_strips): a
+  // clean map would pay the extra strip starts for nothing (profiles/r05_experiments.json, exp13)
   bool fits = false;
-  for (int h = 8; h <= 512; ++h) {  // smallest strip height whose block count fits (small maps: short strips, low latency)
-    const int he = edge_rows(h);
-    const int blocks = a.n_int * ((Hf + h - 1) / h) + ne * ((H + he - 1) / he) + a.n_top + n_bottom;
-    if (blocks <= capacity) {
-      rows_int = h;
-      fits = true;
-      break;
-    }
-  }
-  if (!fits) {
-    // More blocks than resident slots whatever the strip height (a large batch -- 512 maps of 512^2: 22 blocks per map
-    // against 5.5 slots --, a very large map, a small device): the launch runs in waves of blocks and its last blocks run
-    // on a nearly empty device.  Shorter strips make that tail shorter and pay the strip start (staging 2R+2 rows and the
-    // direct sums of the first disc: about R + 6 row steps) more often; the height that minimises
-    //   (row steps of all blocks) / slots  +  half a block
-    // is taken (512 x 512^2 at R = 5: 512 -> 176 rows; normals pass 1.16 -> 0.97 ms).
-    const double c0 = (double)(R + 6);
-    double best = 0.0;
-    for (int h = 16; h <= 512; h += 8) {
-      const int he = edge_rows(h);
-      const double si = (double)((Hf + h - 1) / h), se = (double)((H + he - 1) / he);
-      const double work = (double)a.n_int * (si > 0 ? (double)Hf + si * c0 : 0.0) + 1.5 * (double)ne * ((double)H + se * c0) +
-                          (double)(a.n_top + n_bottom) * ((double)R + c0);
-      const double t = work / capacity_f + 0.5 * ((double)h + c0);
-      if (best == 0.0 || t < best) {
-        best = t;
-        rows_int = h;
-      }
-    }
-  }
-  // UNOBSERVED REGIONS.  A strip that runs along the edge of a region is in "holes" mode on every row -- 2.6x the time of a
-  // clean strip --, and with one strip per resident slot the pass lasts as long as its slowest strip: 0.34-0.41 ms against
-  // 0.16 with 5-20 % of the bench map unobserved, most of the device idle for the second half.  With strips of 32 rows there
-  // are three times as many blocks as slots, the hardware hands them out as slots free up, and the pass takes 0.23-0.30 ms
-  // (profiles/r05_experiments.json, exp13: 64 / 47 / 32 / 24 rows 0.274 / 0.247 / 0.232 / 0.229 ms at 5 %; scattered invalid
-  // cells -- 1 % speckle, every strip alike -- neither gain nor lose: 0.425 -> 0.428).  Only when the upload counted invalid
-  // cells and the dense march serves them (Layers::short_strips): a clean map would pay the extra strip starts for nothing.
-  if (a.short_strips && !slim && a.n_ties == 0 && fits && rows_int > kN3ShortStripRows) rows_int = kN3ShortStripRows;
-  static const int rows_env = lab_int("TE_N3_STRIP_ROWS", 0);  // measurement aid
-  if (rows_env > 0) rows_int = rows_env;
-  a.rows_int = rows_int;
-  a.rows_edge = edge_rows(rows_int);
-  a.s_int = (a.n_int > 0 && Hf > 0) ? (Hf + a.rows_int - 1) / a.rows_int : 0;
-  a.s_edge = ne > 0 ? (H + a.rows_edge - 1) / a.rows_edge : 0;
-  const int nblocks = a.n_int * a.s_int + ne * a.s_edge + a.n_top + n_bottom;
+  const int nblocks = n3_plan_strips(a, g.cols, R, resident, maps, a.short_strips && !slim && a.n_ties == 0, pct_env, rows_env, &fits);
+  (void)fits;
   if (nblocks <= 0) return true;
   const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
   constexpr unsigned kDyn = TE_N3_DYN_LDS ? (unsigned)((2 * R + 2) * (kLanes + 2 * R) * 8) : 0u;  // the ring, when the kernel declares it extern
@@ -1450,17 +1374,7 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.cols = g.cols;
   a.map_cells = (long long)g.rows * g.cols;
   a.map = r.map;
-  a.nbx = (a.i_hi - a.i_lo + kLanes - 1) / kLanes;
-  a.edge0 = a.edge1 = 0;
-  {
-    auto is_edge = [&](int bx) {
-      int i0 = a.i_lo + bx * kLanes;
-      i0 = i0 + kLanes > a.i_hi ? a.i_hi - kLanes : i0;
-      return i0 < R || i0 + kLanes - 1 > g.rows - 1 - R;
-    };
-    while (a.edge0 < a.nbx && is_edge(a.edge0) && (a.i_lo + a.edge0 * kLanes < R)) ++a.edge0;  // left: columns that reach i < R
-    while (a.edge1 < a.nbx - a.edge0 && is_edge(a.nbx - 1 - a.edge1)) ++a.edge1;
-  }
+  n3_plan_edges(a, g.rows, R);
   a.gtab = d.n_ties ? L.clip_table + kClipInts : L.clip_table;  // (ties: the table of the shape with its circle)
   a.n_ties = d.n_ties;
   a.n_gen = 0;

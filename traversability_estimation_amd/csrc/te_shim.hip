@@ -3,6 +3,7 @@
 // Owns the device-resident elevation/output layers of a batch of maps and launches the HIP chain.
 // No CPU fallback of any kind: without a gfx950 device te_create() fails with TE_ERR_NO_DEVICE.
 #include "te_ctx.h"
+#include "te_hole_routing.h"
 
 using namespace te;
 using namespace te::shim;
@@ -190,33 +191,21 @@ int count_invalid_elevation(te_ctx* c) {
 // at 1 % 1.4x slower; MI355X, 4096^2, R = 9).  Unknown counts take the dense march, whose cost does not depend on the map.
 // (A map without invalid cells takes the dense kernel too: its clean march is the same code, and a tile with invalid
 // cells uploaded later -- tiles are not counted -- is then in safe hands.)
-// Unobserved REGIONS rather than scattered cells: the invalid cells come in runs of eight and more on average (speckle: runs
-// of one; a region 100 cells wide: runs of 100).
-bool clustered_holes(const te_ctx* c) {
-  return c->invalid_cells > 0 && c->invalid_runs >= 0 && c->invalid_runs * 8 <= c->invalid_cells;
-}
+// Which march serves the invalid cells of the resident elevation layer: te_hole_routing.h (plain functions of the upload's
+// two counts, shared with the CPU test); the lab switches stay here.
+HoleCounts hole_counts(const te_ctx* c) { return HoleCounts{(long long)c->layer_elems, c->invalid_cells, c->invalid_runs}; }
+bool clustered_holes(const te_ctx* c) { return holes_clustered(hole_counts(c)); }
 bool sparse_holes(const te_ctx* c) {
   static const int force = lab_int("TE_N3_HOLES", 0);  // measurement aid: 1 sparse, 2 dense
   if (force == 1 || force == 2) return force == 1;
-  // (a region, however small: the sparse march walks every invalid cell of a disc -- 5x the dense march inside a region)
-  return c->invalid_cells > 0 && (double)c->invalid_cells <= 0.002 * (double)c->layer_elems && !clustered_holes(c);
+  return holes_sparse(hole_counts(c));
 }
-
-// Sparse holes, and so many of them that hardly a strip is free of them (a strip's window is some 8 000 cells: from three
-// expected invalid cells per window on): k_normals3's clean first attempt would be given up within its first rows on
-// nearly every strip (0.1 % speckle: 99.99 % of them) -- it is skipped.  (Unobserved regions take the dense march -- by
-// their run count, clustered_holes -- and keep the attempt: most of their strips ARE clean.)
 bool skip_clean_march(const te_ctx* c) {
 #ifdef TE_NO_SKIP_CLEAN  // (A/B builds only)
   return false;
 #endif
-  return sparse_holes(c) && (double)c->invalid_cells * 8000.0 >= 3.0 * (double)c->layer_elems;
+  return sparse_holes(c) && holes_skip_clean_march(hole_counts(c));
 }
-
-// Unobserved regions (counted at upload): the dense march on short strips (Layers::short_strips).  Scattered invalid cells
-// keep the long strips -- every strip costs alike there, and the extra strip starts and the second round of blocks cost
-// the launch 10 % (1 % speckle: 0.61 -> 0.69 ms) --, and so does an unknown count (tile uploads): a map without invalid
-// cells would pay for nothing.
 bool short_strips(const te_ctx* c) {
   static const int force = lab_int("TE_N3_SHORT_STRIPS", -1);  // measurement aid: 0 never, 1 whenever invalid cells were counted
   if (force >= 0) return force == 1 && c->invalid_cells > 0 && !sparse_holes(c);
@@ -568,7 +557,7 @@ int run_footprint_locked(te_ctx* c, unsigned flags, bool fresh = false) {
 int run_whole_locked(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   static const bool no_graph = lab_flag("TE_NO_GRAPH");
-  const bool large = (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23);
+  const bool large = c->opt_graph == 1 || (c->opt_graph == 0 && (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23));
   // (only the defined TE_RUN_* bits: the graph key below puts its own hints into the upper bits of the same word)
   flags &= TE_RUN_KEEP_NORMALS | TE_RUN_FOOTPRINT | TE_RUN_GENERIC_KERNELS | TE_RUN_FOOTPRINT_MEMO | TE_RUN_SEQUENTIAL | TE_RUN_NORMALS_ONLY;
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
@@ -827,6 +816,10 @@ int te_set_option(te_ctx* c, int option, int value) {
       break;
     case TE_OPT_POLYGON_PER_CELL:
       c->opt_polygon_per_cell = value != 0;
+      break;
+    case TE_OPT_GRAPH_REPLAY:
+      if (value < 0 || value > 2) return fail(TE_ERR_INVALID_ARG, "te_set_option: TE_OPT_GRAPH_REPLAY takes 0 (by size), 1 (always), 2 (never)");
+      c->opt_graph = value;
       break;
     default:
       return fail(TE_ERR_INVALID_ARG, "te_set_option: unknown option %d", option);
