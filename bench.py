@@ -94,7 +94,11 @@ def parse():
     ap.add_argument("--footprint-yaml", help="robot_footprint_parameter.yaml (circular_footprint_radius_inscribed / _offset, traversability_default, ...)")
     ap.add_argument("--robot-yaml", help="robot.yaml (max_gap_width)")
     ap.add_argument("--tile", type=int, default=256, help="cfg5: side of the dirty tile")
-    ap.add_argument("--in-flight", type=int, default=4, help="cfg5: ticks in flight on the copy streams before the host waits")
+    ap.add_argument("--in-flight", type=int, default=2, help="cfg5, streamed ticks: ticks in flight on the copy streams before the host waits "
+                    "(the context has two staging slots each way: more than 2 in flight wait for a slot -- 0.16 ms per tick at 1 - 2, 0.29 at 4 - 8)")
+    ap.add_argument("--tick-mode", choices=("auto", "sync", "stream"), default="auto",
+                    help="cfg5: sync = te_upload_tile + te_run_chain_region + te_download_tile, one blocking call after the other (lowest latency "
+                         "for small tiles); stream = the asynchronous pair on the copy streams (throughput for large tiles); auto: sync up to 512^2")
     ap.add_argument("--check", action="store_true", help="(default now; kept for old command lines)")
     return ap.parse_args()
 
@@ -364,7 +368,9 @@ def main():
         ctx.sync()
         tick = {"k": 0}
 
-        def step():
+        tick_mode = args.tick_mode if args.tick_mode != "auto" else ("sync" if T <= 512 else "stream")
+
+        def tick_stream():
             k = tick["k"]
             r0, c0 = origins[k % 16]
             ctx.upload_tile_async(tiles_in[k % 16], 0, r0, c0)
@@ -375,18 +381,23 @@ def main():
             if (k + 1) % max(1, args.in_flight) == 0:
                 ctx.sync()
 
-        # latency of ONE tick, host-timed (upload + region run + download + wait), median of 48
+        def tick_sync():
+            k = tick["k"]
+            r0, c0 = origins[k % 16]
+            ctx.upload_tile(tiles_in[k % 16], 0, r0, c0)
+            ctx.run_chain_region(0, r0, c0, T, T, flags=flags)
+            tick["last_out"] = ctx.download_tile(out_layer, 0, r0, c0, T, T)
+            host_map[c0:c0 + T, r0:r0 + T] = tiles_in[k % 16]
+            tick["k"] = k + 1
+
+        step = tick_sync if tick_mode == "sync" else tick_stream
+
+        # latency of ONE tick, host-timed (tile in, region run, tile out, wait), median of 48
         lat = []
         for _ in range(56):
             t0 = time.perf_counter()
-            k = tick["k"]
-            r0, c0 = origins[k % 16]
-            ctx.upload_tile_async(tiles_in[k % 16], 0, r0, c0)
-            ctx.run_chain_region(0, r0, c0, T, T, flags=flags)
-            ctx.download_tile_async(out_layer, 0, r0, c0, tiles_out[k % 8])
+            step()
             ctx.sync()
-            host_map[c0:c0 + T, r0:r0 + T] = tiles_in[k % 16]
-            tick["k"] = k + 1
             lat.append((time.perf_counter() - t0) * 1e3)
         chain_samples = np.array(lat[8:])
         n_samples = len(chain_samples)
@@ -435,6 +446,13 @@ def main():
         else:
             check = parity_check(args, ctx, elevs[0], p, with_fp, rows, cols, whole=(not args.check_crops) and cells <= 4096 * 4096, pos=pos)
     if tick is not None:
+        other = tick_stream if tick_mode == "sync" else tick_sync  # the other form, 128 ticks, for the record
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(128):
+            other()
+        ctx.sync()
+        tick["other_ms"] = (time.perf_counter() - t0) / 128 * 1e3
         for buf in tiles_in + tiles_out:
             capi.unpin_host(buf)
 
@@ -550,8 +568,8 @@ def main():
         is_cfg3 = args.config == "cfg3" and with_fp and n == 4096 and B == 1 and args.radius_cells == 9.0 and args.holes == 0.0 and not args.yaml
         what = {"cfg1": "the reference's bag map (TE/maps/elevation_map.bag), default robot_filter_parameter.yaml: ",
                 "cfg2": "", "cfg3": "", "cfg4": f"batch of {total_maps} maps cut over {world} rank(s), ",
-                "cfg5": f"8192x8192 resident map, one {args.tile}x{args.tile} dirty tile per step (tile H2D + region re-filter + tile D2H "
-                        f"on the copy streams, {args.in_flight} ticks in flight; value counts the dirty tile's cells): "}[args.config]
+                "cfg5": f"8192x8192 resident map, one {args.tile}x{args.tile} dirty tile per step (tile H2D + region re-filter + tile D2H; "
+                        f"value counts the dirty tile's cells; the two tick forms: tick_mode): "}[args.config]
         out = {
             "metric": "map cells/s through full filter chain",
             "value": cells_per_step * args.steps / dt,
@@ -597,6 +615,9 @@ def main():
         if tick is not None:
             out["ticks_per_s"] = args.steps / dt
             out["tick_latency_ms"] = ms_chain
+            out["tick_mode"] = {"timed": tick_mode, "what": "sync: te_upload_tile + te_run_chain_region + te_download_tile, blocking; stream: "
+                                f"te_upload_tile_async / te_run_chain_region / te_download_tile_async on the copy streams, {args.in_flight} ticks in flight",
+                                ("stream" if tick_mode == "sync" else "sync") + "_ms_per_tick": tick["other_ms"]}
             out["roofline"]["kernel"] = "one tick: tile H2D, region run of the chain (tile dilated by the reach), tile D2H -- latency-bound by construction"
         # second roofline: what actually bounds these kernels is instruction issue, most of it double precision
         ops = fp64_lane_ops_per_cell(args.radius_cells, with_fp) * cells_timed

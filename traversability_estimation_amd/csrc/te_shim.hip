@@ -550,14 +550,15 @@ int run_footprint_locked(te_ctx* c, unsigned flags, bool fresh = false) {
   return TE_OK;
 }
 
-// Whole-map chain (+ footprint): 6 kernels on two streams.  For large launches the sequence is captured into a
-// hipGraph the first time and replayed afterwards: measured on MI355X / ROCm 7.0 the replay saves ~17 us on a
-// 4096^2 map (0.534 vs 0.551 ms) but COSTS ~12 us on 1024^2 and 2048^2 maps, hence the size threshold.  Any
-// capture problem switches the context back to direct launches for good.
+// Whole-map chain (+ footprint): the launch sequence is captured once per (flags, hole hints) into a hipGraph and replayed
+// from 2^22 cells on (TE_OPT_GRAPH_REPLAY: always / never).  Measured on MI355X / ROCm 7.2, direct -> replayed, us per launch
+// (tools/lab/graph_small_ab.py, round 6): bag map 17 -> 23, 256^2 25 -> 31, 1024^2 45 -> 52 (the replay costs 6 us on a
+// launch that is a handful of short kernels on one stream), 2048^2 85 -> 79 and 121 -> 118 with the footprint pass, 4096^2
+// 17 us saved (round 1).  Any capture problem switches the context back to direct launches for good.
 int run_whole_locked(te_ctx* c, unsigned flags) {
   const Region r = {-1, 0, 0, c->geo.rows, c->geo.cols};
   static const bool no_graph = lab_flag("TE_NO_GRAPH");
-  const bool large = c->opt_graph == 1 || (c->opt_graph == 0 && (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 23));
+  const bool large = c->opt_graph == 1 || (c->opt_graph == 0 && (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 22));
   // (only the defined TE_RUN_* bits: the graph key below puts its own hints into the upper bits of the same word)
   flags &= TE_RUN_KEEP_NORMALS | TE_RUN_FOOTPRINT | TE_RUN_GENERIC_KERNELS | TE_RUN_FOOTPRINT_MEMO | TE_RUN_SEQUENTIAL | TE_RUN_NORMALS_ONLY;
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
