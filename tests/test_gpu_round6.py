@@ -34,7 +34,7 @@ def _map(synth, rows, cols, seed, boxes=8, holes=False):
                                                    (0.025, (0.0, 0.0), False, False)])
 def test_default_yaml_radii_on_maps_where_they_are_one_cell_ties(capi, oracle, res, origin, holes, keep):
     """Default parameters, map resolutions that make 0.05 m / 0.04 m exactly one cell (res 0.05: normals + roughness; res
-    0.04: the step windows; res 0.025: two cells; res 0.1: neither) -- k_normals3<1, .., TIES>, k_step_*_ties<CENTRE>."""
+    0.04: the step windows; res 0.025: two cells; res 0.1: neither) -- k_normals_small, k_step_small."""
     from traversability_estimation_amd import synth
     rows, cols = 330, 210
     elev = _map(synth, rows, cols, 900 + int(res * 1000), holes=holes)

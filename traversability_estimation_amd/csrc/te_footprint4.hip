@@ -697,7 +697,11 @@ size_t f4_list_slack(int rows, int cols, int batch) {
   const size_t nbx = (size_t)(rows + kLanes - 1) / kLanes, nb = (size_t)(batch > 0 ? batch : 1);
   const size_t one_round = (size_t)32 * (size_t)device_cus() + 2 * nbx * nb;  // (up to 8 waves per SIMD: k_fp_slide5 runs at 5)
   const size_t clamped = nbx * nb * ((size_t)(cols + 511) / 512 + 1);
-  return (size_t)kF4Chunk * (one_round > clamped ? one_round : clamped);
+  // k_fp_slide5 reserves 64 entries per row of EVERY block column, the shifted last one included (launch_f5's capacity test):
+  // a map whose rows are not a multiple of 64 needs the columns that block shares with its neighbour once more -- without them
+  // rows = 65 or 4033 failed the test and fell to the double kernel for no other reason (advisor, round 5)
+  const size_t shared = (nbx * (size_t)kLanes - (size_t)rows) * (size_t)cols * nb;
+  return (size_t)kF4Chunk * (one_round > clamped ? one_round : clamped) + shared;
 }
 
 // The second half of a footprint pass that used k_fp_slide4: the listed cells (see the header).

@@ -67,6 +67,18 @@ class DeviceMap {
   static const int kLayers = 16;
   LayerKey resident_[kLayers];  // what each device layer holds, as far as the plugins put it there
   bool prefetching_;
+  // prefetch() hashed this buffer: the upload() of the plugin that follows sees the same buffer under the same (non-zero)
+  // stamp and takes the hash from here instead of reading 64 MB again (one use; a foreign filter in between hands the next
+  // plugin the chain's OTHER buffer, which is hashed in full)
+  struct HashMemo {
+    const float* data;
+    uint64_t stamp, hash;
+    size_t n;
+  };
+  HashMemo memo_[kLayers];
+  // a prefetched layer that no upload() asked for before the next prefetch() of it: the chain has no plugin that reads it
+  // (SlopeFilter without a StepFilter behind it); after two such updates the layer is no longer prefetched
+  int unused_prefetches_[kLayers];
   void forget();                // after a geometry change or a launch that overwrites input layers
   unsigned long uploads_, uploads_skipped_;
   std::string error_;

@@ -12,11 +12,18 @@ DeviceMap& DeviceMap::instance() {
 
 DeviceMap::DeviceMap()
     : ctx_(nullptr), rows_(0), cols_(0), start_row_(0), start_col_(0), res_(0), px_(0), py_(0), uploads_(0), uploads_skipped_(0), prefetching_(false) {
+  for (int k = 0; k < kLayers; ++k) {
+    memo_[k] = HashMemo{nullptr, 0, 0, 0};
+    unused_prefetches_[k] = 0;
+  }
   forget();
 }
 
 void DeviceMap::forget() {
-  for (int k = 0; k < kLayers; ++k) resident_[k].valid = false;
+  for (int k = 0; k < kLayers; ++k) {
+    resident_[k].valid = false;
+    memo_[k].data = nullptr;
+  }
 }
 
 namespace {
@@ -111,13 +118,19 @@ bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, i
   const size_t n = (size_t)rows_ * cols_;
   LayerKey key = {true, (uint64_t)map.getTimestamp(), 0, n, start_row_, start_col_, false};
   if (cache_on && te_layer >= 0 && te_layer < kLayers) {
-    key.hash = hash_layer(data, n, hash_sampled());
+    HashMemo& mm = memo_[te_layer];
+    if (mm.data == data && mm.stamp == key.stamp && key.stamp != 0 && mm.n == n)
+      key.hash = mm.hash;  // the previous plugin's prefetch() read this very buffer
+    else
+      key.hash = hash_layer(data, n, hash_sampled());
+    mm.data = nullptr;
     const LayerKey& r = resident_[te_layer];
     // (a sampled hash only stands in for the content together with a real time stamp)
     if (r.valid && (!hash_sampled() || key.stamp != 0) && r.stamp == key.stamp && r.hash == key.hash && r.n == key.n && r.start_row == key.start_row && r.start_col == key.start_col) {
-      if (r.prefetched)
+      if (r.prefetched) {
         resident_[te_layer].prefetched = false;  // (counted as an upload when it was started)
-      else
+        unused_prefetches_[te_layer] = 0;
+      } else
         ++uploads_skipped_;
       return true;
     }
@@ -148,7 +161,12 @@ bool DeviceMap::prefetch(const grid_map::GridMap& map, const std::vector<std::pa
   for (const auto& l : layers) {
     if (m >= 8 || l.second < 0 || l.second >= kLayers || !map.exists(l.first)) continue;
     const float* data = map.get(l.first).data();
+    if (resident_[l.second].valid && resident_[l.second].prefetched) {  // the last prefetch of this layer found no reader
+      if (++unused_prefetches_[l.second] >= 2) continue;
+    }
+    if (unused_prefetches_[l.second] >= 2) continue;
     const LayerKey key = {true, (uint64_t)map.getTimestamp(), hash_layer(data, n, hash_sampled()), n, start_row_, start_col_, true};
+    memo_[l.second] = HashMemo{data, key.stamp, key.hash, n};
     const LayerKey& r = resident_[l.second];
     if (r.valid && (!hash_sampled() || key.stamp != 0) && r.stamp == key.stamp && r.hash == key.hash && r.n == key.n && r.start_row == key.start_row &&
         r.start_col == key.start_col)
