@@ -25,6 +25,10 @@
  * (bit-exact on step and combine, bit-exact on slope/roughness except the two exactly-planar
  * border cells documented in SURVEY.md F6).  The circular-footprint pass has NO golden vector in
  * the reference ("parity unpinned" for te_oracle_footprint).
+ * One output is undefined in the reference itself: the SIGN of a horizontal normal (nz == 0 up to the eigen-solver's
+ * rounding: collinear discs, the usual case at a one-cell tie radius).  NormalVectorsFilter flips only nz < 0, so rounding
+ * noise picks n or -n -- here the noise of Jacobi on absolute coordinates, in the reference that of Eigen's solver; slope,
+ * roughness and every later layer do not depend on it (tests/helpers.py: orient_horizontal_normals).
  *
  * Data contract: layers are float32, COLUMN-major like grid_map::Matrix (Eigen::MatrixXf):
  * element (row i, col j) at data[j * rows + i].  Invalid cell == non-finite value.
