@@ -84,6 +84,28 @@ def test_one_cell_tie_radius_on_a_batch_and_a_region(capi, oracle):
         assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx="region run after a dirty tile")
 
 
+@pytest.mark.parametrize("r1,r2", [(0.0, 0.0), (0.2, 0.0), (0.0, 0.15), (0.05, 0.05)])
+def test_step_windows_of_radius_zero(capi, oracle, r1, r2):
+    """A window radius of exactly 0: the disc is its centre, and the centre lies ON the circle (a tie cell that isInside always
+    accepts).  The random sweep of round 6 (seeds 20477 ...) caught k_step_small counting it twice."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 200, 150, 0.05
+    elev = _map(synth, rows, cols, 77, holes=True)
+    op = oracle.default_params(step_radius1=r1, step_radius2=r2, step_ncrit=3, step_critical=0.08)
+    g = oracle.geom(rows, cols, res, (0.3, -0.4))
+    want = oracle.chain(g, op, elev)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res, (0.3, -0.4))
+        ctx.upload_elevation(elev)
+        ctx.run_chain(0)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+    assert_layers_match(got, want, layers=list(OUT_LAYERS), ctx=f"step windows {r1} / {r2} m")
+    if r1 > 0.0:  # (a first window of one cell makes every step height 0; otherwise the case has cells whose count matters)
+        assert (np.asarray(want["traversability_step"]) < 1.0).sum() > 50
+
+
 def test_whole_1024_map_default_yaml_res_005_against_the_oracle(capi, oracle):
     """Every cell of a 1024^2 map at res 0.05 with the default parameters (one-cell tie normals, footprint radius 0.45 m = 9 cells)."""
     from traversability_estimation_amd import synth

@@ -170,8 +170,12 @@ bool small_window(int Q, const Disc* d, SmallWin* w) {
       for (int di = -hw; di <= hw; ++di)
         if ((di || dj) && !push(di, dj, false)) return false;
     }
-    for (int t = 0; t < d->n_ties; ++t)
+    for (int t = 0; t < d->n_ties; ++t) {
+      // (a radius of exactly 0: the circle IS the centre -- isInside accepts it, 0 <= 0 -- and the kernels count the centre
+      // themselves: listed again it was counted twice, nCells 2 instead of 1; the sweep's seeds 20477 ... 23804, round 6)
+      if (d->tie_di[t] == 0 && d->tie_dj[t] == 0) continue;
       if (!push(d->tie_di[t], d->tie_dj[t], true)) return false;
+    }
     return true;
   }
   // tie-free windows: the centre alone.  (A gather through the vector cache costs 5 us per neighbour and pass on a 4096^2
