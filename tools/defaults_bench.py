@@ -27,7 +27,8 @@ def main():
                 c.set_geometry(n, n, 1, res)
                 c.upload_elevation(e)
                 row = {}
-                for name, flags in (("chain", 0), ("chain+footprint", capi.RUN_FOOTPRINT), ("chain generic", capi.RUN_GENERIC_KERNELS),
+                seq = capi.RUN_SEQUENTIAL if "sequential" in sys.argv else 0  # (one stream: every kernel's own time under rocprofv3)
+                for name, flags in (("chain", seq), ("chain+footprint", capi.RUN_FOOTPRINT | seq), ("chain generic", capi.RUN_GENERIC_KERNELS),
                                     ("normals only", capi.RUN_NORMALS_ONLY), ("normals only generic", capi.RUN_NORMALS_ONLY | capi.RUN_GENERIC_KERNELS)):
                     if "profile" in sys.argv and "generic" in name:
                         continue
