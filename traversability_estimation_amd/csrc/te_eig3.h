@@ -47,6 +47,10 @@ __device__ __forceinline__ float nz_from_m(double m) {
 
 // Returns 0: done; 1: unresolved (nearly horizontal normal, ambiguous middle eigenvalue, no convergence, range):
 // the caller uses the cyclic Jacobi of te_cell.h.  q_scaled = n^T (n^2 C) n.
+// EARLY: the Newton iteration stops as soon as every lane of the wavefront has converged (its last step below 1e-15 of the
+// trace: the iteration is monotone and quadratic, on terrain three steps instead of six).  For kernels whose time IS this
+// tail (k_normals_small); the marching kernels keep the fixed count -- their register budgets were tuned around it.
+template <bool EARLY = false>
 __device__ __forceinline__ int general_tail3(double res, int n, int si, int sj, int sii, int sij, int sjj, double Sz, double Siz,
                                              double Sjz, double Szz, float& nx, float& ny, float& nz, double& q_scaled) {
   const double dn = (double)n;
@@ -83,6 +87,9 @@ __device__ __forceinline__ int general_tail3(double res, int n, int si, int sj, 
     const double dp = fma(lam, fma(-3.0, lam, tr2), -c1);  // < 0 left of the smallest root
     const double step = p * rcp_fast(dp);
     lam = lam - step;
+    if constexpr (EARLY) {
+      if (__all(!(fabs(step) > 1e-15 * tr))) break;  // (a lane outside the solver's range has step = NaN or tr <= 0: it does not hold the others up)
+    }
   }
   lam = lam > 0.0 ? lam : 0.0;  // det rounded below zero on an exactly planar patch
   const double a0 = A - lam, c0 = Cc - lam;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
       if (n >= 3 && Ai * Ci - Bi * Bi == 0)
         unresolved = collinear_tail(a.res, n, Ai, Ci, si, sj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
       else
-        unresolved = general_tail3(a.res, n, si, sj, sii, sij, sjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
+        unresolved = general_tail3<true>(a.res, n, si, sj, sii, sij, sjj, Sz, Siz, Sjz, Szz, fx, fy, fz, qs);
       // slope = acos(float32 nz) (SlopeFilter.cpp:74); roughness^2 = q / (n (n - 1)) (RoughnessFilter.cpp:105-117)
       const float sl = acosf_poly(fz);
       const float rs = fmaf(-sl, a.inv_slope_crit, 1.0f);
