@@ -128,3 +128,62 @@ def test_whole_1024_map_default_yaml_res_005_against_the_oracle(capi, oracle):
         ctx.sync()
         got = {k: ctx.download(k) for k in layers}
     assert_layers_match(got, want, layers=layers, ctx="1024^2, default YAML, res 0.05")
+
+
+def test_a_filter_beside_a_prefetch_of_its_own_input_joins_the_prefetch(capi, oracle):
+    """te_run_filter / te_download_layer may run BESIDE a prefetch -- unless they touch one of its layers: TE_FILTER_STEP right
+    behind an elevation prefetch must see the NEW elevation, whole (round 5's advisor: it read a half-written layer)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 1024, 768, 0.05
+    e1 = synth.perlin_elevation(rows, cols, seed=11)
+    e2 = synth.with_steps(synth.perlin_elevation(rows, cols, seed=12), 30, seed=13)
+    op = oracle.default_params(step_radius1=synth.benchmark_radius(3, res), step_radius2=synth.benchmark_radius(2, res))
+    g = oracle.geom(rows, cols, res)
+    oracle.set_threads(8)
+    try:
+        want = oracle.step(g, e2, op.step_critical, op.step_radius1, op.step_radius2, op.step_ncrit)
+    finally:
+        oracle.set_threads(1)
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, 1, res)
+        ctx.upload_elevation(e1)
+        ctx.run_filter("step")
+        ctx.sync()
+        for _ in range(3):  # (a race does not lose every time)
+            ctx.prefetch_layers({"elevation": e2})
+            ctx.run_filter("step")                       # reads elevation: joins the prefetch first
+            got = ctx.download("traversability_step")    # (a layer the prefetch does not write: runs beside nothing by now)
+            ctx.wait_prefetch()
+            assert_layers_match({"traversability_step": got}, {"traversability_step": want}, layers=["traversability_step"], ctx="step beside an elevation prefetch")
+            ctx.prefetch_layers({"elevation": e1})
+            e_back = ctx.download("elevation")           # a download of the prefetched layer itself joins it too
+            ctx.wait_prefetch()
+            assert np.array_equal(e_back.view(np.uint32), np.ascontiguousarray(e1, np.float32).reshape(-1).view(np.uint32))
+
+
+def test_graph_replay_option_gives_the_same_layers(capi):
+    """TE_OPT_GRAPH_REPLAY: always / never -- a choice between launch forms, bit-identical layers (small map: the default is direct)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res = 320, 256, 0.05
+    elev = _map(synth, rows, cols, 5, holes=True)
+    r = synth.benchmark_radius(4, res)
+    p = capi.default_params(normals_radius=r, rough_radius=r, step_radius1=r, step_radius2=r, fp_radius=synth.benchmark_radius(4, res),
+                            fp_offset=synth.benchmark_radius(2, res))
+    outs = []
+    for mode in (2, 1, 0):
+        with capi.Context(0) as ctx:
+            ctx.set_params(p)
+            ctx.set_geometry(rows, cols, 1, res)
+            ctx.set_option(capi.OPT_GRAPH_REPLAY, mode)
+            ctx.upload_elevation(elev)
+            for _ in range(3):  # (capture, then two replays)
+                ctx.run_chain(capi.RUN_FOOTPRINT)
+            ctx.sync()
+            outs.append({k: ctx.download(k) for k in list(OUT_LAYERS) + ["traversability_footprint"]})
+    for k in outs[0]:
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][k].view(np.uint32), o[k].view(np.uint32)), k
+    with capi.Context(0) as ctx:
+        with pytest.raises(capi.TeError):
+            ctx.set_option(capi.OPT_GRAPH_REPLAY, 3)
