@@ -341,8 +341,10 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
                    FastGrid* fg, hipStream_t s);
 // te_normals_small.hip: discs that reach at most two cells (the one-cell tie radius of the default parameters on a 0.05 m
 // map; small launches of the tie-free 5- to 13-point discs), one cell per thread; false: not taken
+// write_step: both step windows hold one cell -- the step score is 1 (valid) / NaN and this kernel writes the layer; combine:
+// ... and the weighted sum (the step layer must be complete, or written here)
 bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags, FastGrid* fg,
-                   hipStream_t s);
+                   hipStream_t s, bool write_step = false, bool combine = false);
 int normals_fast_max_blocks(const Geo& g);
 size_t normals_hole_queue_bytes();  // te_normals3.hip: scratch of the sparse-hole march for one device (any map, any batch)
 // te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)

@@ -53,6 +53,17 @@ struct SmallArgs {
   unsigned tie_mask;  // bit k: offset k lies on the circle -- isInside decides it for every centre
   float inv_slope_crit, inv_rough_crit, band_slope, band_rough;
   int ntx, nty, fix_groups;
+  // SINGLE-CELL STEP WINDOWS (both radii below one cell: the default 0.04 m on any map coarser than 0.04 m).  StepFilter then
+  // needs no neighbour: pass 1 gives max - min = 0 for a valid centre (StepFilter.cpp:113-143), pass 2 finds stepMax = 0 and
+  // nCells = 0 (0 > critical is false for any critical >= 0, :165), so step = 0 and the score is 1 - 0 / critical = 1
+  // (critical > 0; 0 otherwise, "0 < 0" fails at :172) -- and NaN where the elevation is invalid (no valid step height in the
+  // window, :161).  The kernel that holds the centre's elevation anyway writes the layer, and with it the weighted sum
+  // (MathExpressionFilter, float32, left to right): the chain of such a map is this kernel and its fix-up pass.
+  float* step;
+  float* trav;
+  int write_step, combine;
+  float step_valid;  // the step score of a valid cell: 1, or 0 for a critical value of 0
+  float w_scale, w_slope, w_step, w_rough;
 };
 
 // The valid cells of a disc all lie on ONE grid line (with a one-cell tie radius: the centre and its two neighbours along
@@ -167,6 +178,21 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
     }
     a.slope[o] = o_slope;
     a.rough[o] = o_rough;
+    if (a.write_step || a.combine) {  // (uniform)
+      float st;
+      if (a.write_step) {
+        st = __builtin_isfinite(zcf) ? a.step_valid : qnan();
+        a.step[o] = st;
+      } else {
+        st = a.step[o];
+      }
+      if (a.combine) {  // a cell left to the fix-up pass is NaN here and combined again there (NormalsArgs::combine)
+        const float ta = a.w_slope * o_slope, tb = a.w_step * st, tc = a.w_rough * o_rough;
+        const float tab = ta + tb;
+        const float tabc = tab + tc;
+        a.trav[o] = a.w_scale * tabc;
+      }
+    }
     if (KEEP) {
       a.nx[o] = fx;
       a.ny[o] = fy;
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
 // map first of all.  Tie-free discs of that size only on small launches (the sliding kernels are faster from about 2^18
 // cells on: 4096^2 at 1.67 cells 0.09 ms).  False: not taken.
 bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* flags, FastGrid* fg,
-                   hipStream_t s) {
+                   hipStream_t s, bool write_step, bool combine) {
   const Disc& d = p.normals;
   static const bool off = lab_flag("TE_NO_SMALL");  // measurement aid
   static const int max_cells_env = lab_int("TE_SMALL_MAX_CELLS", 0);
@@ -240,6 +266,15 @@ bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.inv_rough_crit = (float)(1.0 / p.rough_crit);
   a.band_slope = clip_band_slope(p.slope_crit);
   a.band_rough = clip_band_rough(p.rough_crit);
+  a.step = L.step;
+  a.trav = L.trav;
+  a.write_step = write_step ? 1 : 0;
+  a.combine = combine ? 1 : 0;
+  a.step_valid = 0.0 < p.step_crit ? 1.0f : 0.0f;
+  a.w_scale = p.w_scale;
+  a.w_slope = p.w_slope;
+  a.w_step = p.w_step;
+  a.w_rough = p.w_rough;
   fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
   fg->nty = (r.j1 - r.j0 + kSmallRows - 1) / kSmallRows;
   fg->nbz = r.map >= 0 ? 1 : g.batch;
