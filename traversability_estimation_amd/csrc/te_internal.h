@@ -213,7 +213,8 @@ inline int fix_groups(int ntiles) { return ntiles <= 2048 ? ntiles : (ntiles + k
 struct FastGrid {  // fix-up flag grid of the last sliding-disc normals launch: 64x16 tiles of the region
   int ntx, nty, nbz;
   int frame;  // > 0: the fix-up pass also owns every cell within `frame` cells of the map border (k_normals3 computes
-              // only discs that lie inside the map), whatever the flags and the slope layer say
+              // only discs that lie inside the map), whatever the flags and the slope layer say;
+              // < 0: the kernel settled every cell itself (k_normals_small): no fix-up pass at all
 };
 
 // te_stage.hip: whole-layer transfers through pageable caller buffers -- a ring of page-locked slots per context, chunked,

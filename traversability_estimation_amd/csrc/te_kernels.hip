@@ -581,34 +581,15 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   const bool normals_only = (flags & TE_RUN_NORMALS_ONLY) != 0;  // measurement aid: the dominant kernel alone
   // SINGLE-CELL STEP WINDOWS and a normals disc k_normals_small takes (the reference's defaults on a map coarser than
   // 0.04 m): the step score needs no neighbour -- 1 where the elevation is valid, NaN elsewhere (te_normals_small.hip) --, so
-  // that kernel writes the step layer and the weighted sum as well: the whole chain is one kernel and its fix-up pass
-  // (4096^2, default parameters at res 0.05: 0.34 -> 0.24 ms; 256^2: 17 -> 12 us).  Whole-map runs only: a region run
+  // that kernel writes the step layer and the weighted sum as well: the whole chain is ONE kernel
+  // (4096^2, default parameters at res 0.05: 0.34 -> 0.24 ms; 256^2: 17 -> 5 us).  Whole-map runs only: a region run
   // re-filters dilated regions stage by stage as before.
   if (whole && use_fast && !normals_only && p.same_rough_disc && p.axis == 2 && p.step1.n_ties == 0 && p.step1.Q == 0 && p.step2.n_ties == 0 &&
       p.step2.Q == 0) {
     const bool comb = !(flags & kDeferCombine);
     FastGrid fg;
-    TraceRange tr("chain: normals + slope + roughness + single-cell step windows + combine (+ fix-up)");
+    TraceRange tr("chain: normals + slope + roughness + single-cell step windows + combine (one kernel)");
     if (fast::normals_small(g, p, L, (flags & TE_RUN_KEEP_NORMALS) != 0, r, L.block_flags, &fg, stream, /*write_step*/ true, comb)) {
-      NormalsArgs na;
-      na.dn = p.normals;
-      na.dr = p.rough;
-      na.same_disc = p.same_rough_disc;
-      na.axis = p.axis;
-      na.slope_crit = p.slope_crit;
-      na.rough_crit = p.rough_crit;
-      na.w_scale = p.w_scale;
-      na.w_slope = p.w_slope;
-      na.w_step = p.w_step;
-      na.w_rough = p.w_rough;
-      na.given_normals = 0;
-      na.band_slope = clip_band_slope(p.slope_crit);
-      na.band_rough = clip_band_rough(p.rough_crit);
-      na.combine = comb ? 1 : 0;
-      const bool keep = (flags & TE_RUN_KEEP_NORMALS) != 0;
-      const int Kn = p.normals.reach > p.rough.reach ? p.normals.reach : p.rough.reach;
-      hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
-                         L.rough, L.trav, keep ? L.nx : nullptr, keep ? L.ny : nullptr, keep ? L.nz : nullptr, L.block_flags, fg, r);
       return hipGetLastError();
     }
   }
@@ -659,7 +640,8 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   if (use_fast && p.same_rough_disc && p.axis == 2 &&
       fast::normals_fast(g, p, L, keep, fused_combine, rn, L.block_flags, L.clip_table, &fg, stream, &combined)) {
     na.combine = combined ? 1 : 0;
-    hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
+    if (fg.frame >= 0)  // (k_normals_small settles every cell itself)
+      hipLaunchKernelGGL(k_normals_fixup, dim3((unsigned)fix_groups(fg.ntx * fg.nty * fg.nbz)), blk, tile_bytes(Kn), stream, g, na, L.elev, L.step, L.slope,
                        L.rough, L.trav, knx, kny, knz, L.block_flags, fg, rn);
   } else {
     combined = na.combine != 0;

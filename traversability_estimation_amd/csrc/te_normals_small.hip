@@ -12,14 +12,15 @@
 // sliding kernels of te_normals3.hip exist to make a 253-point disc cost 38 cells per step; with at most 12 neighbours
 // there is nothing to slide, and their strips (a serial march per wavefront, a ring, strip starts, the map frame left to the
 // fix-up pass) are pure overhead: the TIES march took 0.47 ms for a 4096^2 map at one cell, 31 us for a 256^2 one.
-// Here every thread owns one cell (workgroups of 64 x 4, four to a 64 x 16 tile of the fix-up pass), reads its neighbours straight from the layer
+// Here every thread owns one cell (workgroups of 64 x 4), reads its neighbours straight from the layer
 // (coalesced along i, the rows above and below come from L2 / the vector cache), decides its tie cells with the
 // reference's own position arithmetic, and runs the general tail of te_eig3.h.  Discs clipped by the map border and
-// invalid neighbours are just fewer points: no frame, no hole march.  Cells the tail does not resolve (a nearly
-// horizontal normal, an ambiguous middle eigenvalue) and scores within their error of the clip at 0 are left to
-// k_normals_fixup exactly like the sliding kernels leave them (te_internal.h: kExactNaNBits).
+// invalid neighbours are just fewer points: no frame, no hole march.  Cells the fast tail does not resolve (a nearly
+// horizontal normal, an ambiguous middle eigenvalue) and scores within their error of the clip at 0 (te_internal.h) take the
+// generic arithmetic in place: no fix-up pass behind this kernel.
 //
 // Algorithmic bytes: 4 B read + 8 B written per cell (+ 12 B when the normals are kept).
+#include "te_cell.h"
 #include "te_eig.h"
 #include "te_eig3.h"
 #include "te_geom.h"
@@ -32,8 +33,7 @@ namespace fast {
 namespace {
 
 constexpr int kSmallMaxOffsets = 12;  // the 13-point disc (reach 2) without its centre
-constexpr int kSmallRows = 16;        // rows of a tile (= the fix-up pass's 64 x 16 tile)
-constexpr int kSmallBY = 4;           // rows of a workgroup (64 x 4 threads, one cell each): four workgroups per fix-up tile
+constexpr int kSmallBY = 4;           // rows of a workgroup (64 x 4 threads, one cell each)
 
 struct SmallArgs {
   const float* elev;
@@ -42,7 +42,6 @@ struct SmallArgs {
   float* nx;
   float* ny;
   float* nz;
-  int* tile_flags;
   int rows, cols;
   long long map_cells;
   int map;  // >= 0: this map only; < 0: blockIdx.z
@@ -52,7 +51,6 @@ struct SmallArgs {
   signed char di[kSmallMaxOffsets], dj[kSmallMaxOffsets];
   unsigned tie_mask;  // bit k: offset k lies on the circle -- isInside decides it for every centre
   float inv_slope_crit, inv_rough_crit, band_slope, band_rough;
-  int ntx, nty, fix_groups;
   // SINGLE-CELL STEP WINDOWS (both radii below one cell: the default 0.04 m on any map coarser than 0.04 m).  StepFilter then
   // needs no neighbour: pass 1 gives max - min = 0 for a valid centre (StepFilter.cpp:113-143), pass 2 finds stepMax = 0 and
   // nCells = 0 (0 > critical is false for any critical >= 0, :165), so step = 0 and the score is 1 - 0 / critical = 1
@@ -62,6 +60,7 @@ struct SmallArgs {
   float* step;
   float* trav;
   int write_step, combine;
+  double slope_crit, rough_crit;  // (the exact tail of the cells the fast one does not settle)
   float step_valid;  // the step score of a valid cell: 1, or 0 for a critical value of 0
   float w_scale, w_slope, w_step, w_rough;
 };
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
   const size_t mo = (size_t)(a.map >= 0 ? a.map : mz) * (size_t)a.map_cells;
   const int i = a.i_lo + (int)blockIdx.x * kLanes + lane;
   const int j = a.j_lo + (int)blockIdx.y * kSmallBY + ty;
-  bool flagged = false;
   if (i < a.i_hi && j < a.j_hi) {
     const size_t o = mo + (size_t)j * a.rows + i;
     const float zcf = a.elev[o];
@@ -170,10 +168,24 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
       const float rr = fmaf(-rgh, a.inv_rough_crit, 1.0f);
       o_rough = n > 1 ? fmaxf(rr, 0.0f) : 0.0f;  // n == 1: 0/0 -> "roughness < crit" false -> 0
       const bool near = near_clip(rs, a.band_slope) || (n > 1 && near_clip(rr, a.band_rough));
-      if (unresolved != 0 || near) {  // the fix-up pass settles the cell with the generic arithmetic
-        const float qn = near ? exact_nanf() : qnan();
-        o_slope = o_rough = fx = fy = fz = qn;
-        flagged = true;
+      if (unresolved != 0 || near) {
+        // What the fast tail does not settle -- a nearly horizontal normal, an ambiguous middle eigenvalue, a score within its
+        // error of the clip at 0 -- is settled HERE with the generic arithmetic (te_cell.h: cyclic Jacobi, double acos and
+        // square root, as k_normals_fixup would): the moments are at hand, the cells are rare (a handful per map on terrain,
+        // box edges on maps with steps), and the fix-up pass -- 4 us of launch, flag scan and drain, half of the chain on the
+        // maps the reference's node actually filters (4 m x 4 m: 80 x 80 cells) -- is not launched behind this kernel at all.
+        Mom m;
+        m.n = n; m.si = si; m.sj = sj; m.sii = sii; m.sij = sij; m.sjj = sjj;
+        m.sz = Sz; m.siz = Siz; m.sjz = Sjz; m.szz = Szz;
+        double cov[6];
+        float nf[3];
+        covariance(m, a.res, cov);
+        normal_from_cov(m, cov, 2, nf);
+        o_slope = slope_score(nf[2], a.slope_crit);
+        o_rough = roughness_score(m, cov, nf, a.rough_crit);
+        fx = nf[0];
+        fy = nf[1];
+        fz = nf[2];
       }
     }
     a.slope[o] = o_slope;
@@ -199,10 +211,6 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
       a.nz[o] = fz;
     }
   }
-  if (__syncthreads_or(flagged ? 1 : 0) && lane == 0 && ty == 0) {  // the 64 x 16 tile of the fix-up pass this block lies in
-    const int t = mz * a.ntx * a.nty + ((int)blockIdx.y * kSmallBY / kSmallRows) * a.ntx + (int)blockIdx.x;
-    a.tile_flags[(t % a.fix_groups) * kFixTiles + t / a.fix_groups] = 1;
-  }
 }
 
 }  // namespace
@@ -215,7 +223,8 @@ bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   const Disc& d = p.normals;
   static const bool off = lab_flag("TE_NO_SMALL");  // measurement aid
   static const int max_cells_env = lab_int("TE_SMALL_MAX_CELLS", 0);
-  if (off || d.reach < 1 || d.reach > 2 || !flags) return false;
+  (void)flags;  // (no cell is left to the fix-up pass)
+  if (off || d.reach < 1 || d.reach > 2) return false;
   if ((double)g.rows * (double)g.cols * 4.0 >= 4294967296.0) return false;
   const long long cells = (long long)(r.i1 - r.i0) * (r.j1 - r.j0) * (r.map >= 0 ? 1 : g.batch);
   const long long small_launch = max_cells_env > 0 ? max_cells_env : (1ll << 18);
@@ -249,7 +258,6 @@ bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.nx = L.nx;
   a.ny = L.ny;
   a.nz = L.nz;
-  a.tile_flags = flags;
   a.rows = g.rows;
   a.cols = g.cols;
   a.map_cells = (long long)g.rows * g.cols;
@@ -271,17 +279,16 @@ bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   a.write_step = write_step ? 1 : 0;
   a.combine = combine ? 1 : 0;
   a.step_valid = 0.0 < p.step_crit ? 1.0f : 0.0f;
+  a.slope_crit = p.slope_crit;
+  a.rough_crit = p.rough_crit;
   a.w_scale = p.w_scale;
   a.w_slope = p.w_slope;
   a.w_step = p.w_step;
   a.w_rough = p.w_rough;
   fg->ntx = (r.i1 - r.i0 + kLanes - 1) / kLanes;
-  fg->nty = (r.j1 - r.j0 + kSmallRows - 1) / kSmallRows;
+  fg->nty = (r.j1 - r.j0 + 15) / 16;
   fg->nbz = r.map >= 0 ? 1 : g.batch;
-  fg->frame = 0;
-  a.ntx = fg->ntx;
-  a.nty = fg->nty;
-  a.fix_groups = fix_groups(fg->ntx * fg->nty * fg->nbz);
+  fg->frame = -1;  // nothing is left to the fix-up pass: the caller does not launch it
   const dim3 grid((unsigned)fg->ntx, (unsigned)((r.j1 - r.j0 + kSmallBY - 1) / kSmallBY), (unsigned)fg->nbz);
   if (keep_normals)
     hipLaunchKernelGGL(k_normals_small<true>, grid, dim3(kLanes, kSmallBY), 0, s, a);
