@@ -219,3 +219,38 @@ def test_single_cell_step_windows_fused_into_the_normals_kernel(capi, oracle, st
             assert_layers_match(got, want, layers=layers, ctx=f"fused single-cell steps, map {b}")
             st = np.asarray(want["traversability_step"])
             assert set(np.unique(st[~np.isnan(st)])) <= {np.float32(1.0 if step_crit > 0 else 0.0)}
+
+
+@pytest.mark.parametrize("nc,s1,s2,keep,fp", [(1.67, 1.33, 1.33, False, True),     # the bag map's shapes: 9-point disc, 5-point windows
+                                               (1.0, 1.42, 1.2, True, False),      # one-cell tie radius; 3 x 3 first window, 5-point second
+                                               (2.0, 0.5, 1.42, False, False),     # two-cell tie radius; single-cell first window
+                                               (2.24, 1.2, 0.4, False, True),      # 21-point disc; single-cell second window
+                                               (2.9, 1.45, 1.45, True, False),     # the whole 5 x 5 window; 3 x 3 windows
+                                               (1.5, 1.0, 1.3, False, False)])     # a TIE first window: not this kernel's (the stage-by-stage path)
+def test_the_whole_chain_of_a_small_map_in_one_kernel(capi, oracle, nc, s1, s2, keep, fp):
+    """k_chain_window: small launches whose normals disc reaches at most two cells and whose step windows fit 3 x 3 -- normals,
+    slope, roughness, both step passes and the weighted sum from the 5 x 5 window of elevations one thread holds.  Borders on
+    all sides, holes, +inf, steps, a batch; against the oracle (and the last row: a shape the kernel must leave alone)."""
+    from traversability_estimation_amd import synth
+    rows, cols, res, B = 150, 131, 0.04, 2
+    elevs = np.stack([_map(synth, rows, cols, 300 + b, boxes=10, holes=True) for b in range(B)])
+    elevs[0][10:12, 30:60] = np.inf
+    op = oracle.default_params(normals_radius=nc * res, rough_radius=nc * res, step_radius1=s1 * res, step_radius2=s2 * res, step_ncrit=3, step_critical=0.05,
+                               fp_radius=synth.benchmark_radius(3, res), fp_offset=synth.benchmark_radius(2, res))
+    g = oracle.geom(rows, cols, res, (-1.3, 2.2))
+    layers = list(OUT_LAYERS) + (["traversability_footprint"] if fp else []) + (["surface_normal_x", "surface_normal_y", "surface_normal_z"] if keep else [])
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(rows, cols, B, res, (-1.3, 2.2))
+        ctx.upload_elevation(elevs)
+        ctx.run_chain((capi.RUN_FOOTPRINT if fp else 0) | (capi.RUN_KEEP_NORMALS if keep else 0))
+        ctx.sync()
+        per = rows * cols
+        for b in range(B):
+            want = oracle.chain(g, op, elevs[b], want_normals=keep)
+            if fp:
+                want["traversability_footprint"] = oracle.footprint(g, op, elevs[b], want)
+            got = {k: ctx.download(k)[b * per:(b + 1) * per] for k in layers}
+            if keep:
+                got, want = orient_horizontal_normals(got, want["surface_normal_z"]), orient_horizontal_normals(want, want["surface_normal_z"])
+            assert_layers_match(got, want, layers=layers, ctx=f"one-kernel chain, normals {nc} / windows {s1}, {s2} cells, map {b}")

@@ -346,6 +346,9 @@ bool normals_fast3(const Geo& g, const ChainParams& p, const Layers& L, bool kee
 // ... and the weighted sum (the step layer must be complete, or written here)
 bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, int* block_flags, FastGrid* fg,
                    hipStream_t s, bool write_step = false, bool combine = false);
+// ... and the whole chain of a small whole-map launch (at most 2^18 cells, a disc of at most 13 cells, step windows of at most 3 x 3
+// cells) in one kernel: normals, slope, roughness, both step passes, the weighted sum; false: not taken
+bool chain_window(const Geo& g, const ChainParams& p, const Layers& L, bool keep_normals, const Region& r, bool combine, hipStream_t s);
 int normals_fast_max_blocks(const Geo& g);
 size_t normals_hole_queue_bytes();  // te_normals3.hip: scratch of the sparse-hole march for one device (any map, any batch)
 // te_footprint3.hip: the sliding-sum kernel of the circular footprint pass (false: shape / map not taken)

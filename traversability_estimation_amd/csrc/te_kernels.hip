@@ -584,6 +584,10 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   // that kernel writes the step layer and the weighted sum as well: the whole chain is ONE kernel
   // (4096^2, default parameters at res 0.05: 0.34 -> 0.24 ms; 256^2: 17 -> 5 us).  Whole-map runs only: a region run
   // re-filters dilated regions stage by stage as before.
+  if (whole && use_fast && !normals_only && p.same_rough_disc && p.axis == 2) {  // a small launch: the whole chain in one kernel
+    TraceRange tr("chain: one kernel (k_chain_window)");
+    if (fast::chain_window(g, p, L, (flags & TE_RUN_KEEP_NORMALS) != 0, r, !(flags & kDeferCombine), stream)) return hipGetLastError();
+  }
   if (whole && use_fast && !normals_only && p.same_rough_disc && p.axis == 2 && p.step1.n_ties == 0 && p.step1.Q == 0 && p.step2.n_ties == 0 &&
       p.step2.Q == 0) {
     const bool comb = !(flags & kDeferCombine);
