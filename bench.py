@@ -608,8 +608,8 @@ def main():
         }
         if ms_normals is not None:
             out["roofline"]["dominant_kernel"] = {
-                "name": "the normals pass (k_normals3s or k_normals3, + k_normals_fixup), alone on the GPU (TE_RUN_NORMALS_ONLY; rocprofv3 "
-                        "lists the two kernels separately, profiles/)",
+                "name": "the normals / slope / roughness pass alone on the GPU (TE_RUN_NORMALS_ONLY: k_normals3s or k_normals3 + k_normals_fixup on the "
+                        "headline map -- rocprofv3 lists the two separately, profiles/ --, k_normals_small on discs of at most 13 cells)",
                 "ms": ms_normals, "algorithmic_bytes_per_cell": 12, "achieved": cells_timed * 12 / (ms_normals * 1e-3) / 1e9,
                 "frac": cells_timed * 12 / (ms_normals * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if tick is not None:
