@@ -227,8 +227,8 @@ float largest_float_below(double crit) {  // largest float <= crit: "h > crit" i
   return lo;
 }
 
-// the shapes a whole-cell radius of 2 .. 10 cells leaves without its circle (te_march.h has them all): only these exist as RAW kernels
-constexpr bool tie_free_part(int Q) { return Q == 2 || Q == 8 || Q == 13 || Q == 20 || Q == 34 || Q == 45 || Q == 61 || Q == 80 || Q == 98; }
+// the shapes a whole-cell radius of 3 .. 10 cells leaves without its circle (2 cells: k_step_small) (te_march.h has them all): only these exist as RAW kernels
+constexpr bool tie_free_part(int Q) { return Q == 8 || Q == 13 || Q == 20 || Q == 34 || Q == 45 || Q == 61 || Q == 80 || Q == 98; }
 
 // the shape of a tie disc without its circle (largest norm in its runs), its ties as kernel arguments; false: not a
 // whole-cell radius this file serves

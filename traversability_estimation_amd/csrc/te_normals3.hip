@@ -1230,7 +1230,7 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   const dim3 grid((unsigned)nblocks, 1, (unsigned)maps);
   constexpr unsigned kDyn = TE_N3_DYN_LDS ? (unsigned)((2 * R + 2) * (kLanes + 2 * R) * 8) : 0u;  // the ring, when the kernel declares it extern
   if (a.n_ties != 0) {  // tie radius: the whole-cell shapes only
-    if constexpr (R * R == Q) {
+    if constexpr (R * R == Q && R >= 3) {  // (tie radii of one and two cells: k_normals_small, te_normals_small.hip)
       if (keep)
         hipLaunchKernelGGL((k_normals3<Q, true, 2, true>), grid, dim3(kLanes), kDyn, s, a);
       else

@@ -331,8 +331,8 @@ long wave_slots5(int waves) {
   return 4L * device_cus() * (ov > 0 ? ov : waves);
 }
 
-// the shapes a whole-cell radius of 2 .. 10 cells leaves without its circle (te_march.h has them all): only these exist as RAW kernels
-constexpr bool tie_free_part5(int Q) { return Q == 2 || Q == 8 || Q == 13 || Q == 20 || Q == 34 || Q == 45 || Q == 61 || Q == 80 || Q == 98; }
+// the shapes a whole-cell radius of 3 .. 10 cells leaves without its circle (2 cells: k_step_small) (te_march.h has them all): only these exist as RAW kernels
+constexpr bool tie_free_part5(int Q) { return Q == 8 || Q == 13 || Q == 20 || Q == 34 || Q == 45 || Q == 61 || Q == 80 || Q == 98; }
 
 template <int Q>
 bool launch_step5(bool score, const Geo& g, Step5Args a, const Region& r, hipStream_t s) {
