@@ -32,3 +32,20 @@ def test_plan_and_routing_harnesses_under_asan_ubsan(tmp_path):
         _run(["g++"] + SAN + ["-Wall", "-Werror", "-I", CSRC, os.path.join(ROOT, "tests", "cpu", src), "-o", exe])
         out = _run([exe] + (["1048576", "1000", "1000"] if "routing" in src else []))
         assert ("0 failed checks" in out) if "plan" in src else out.startswith("sparse")
+
+
+def test_polygon_tables_host_side_under_asan_ubsan(tmp_path):
+    """te_polygon.hip's host side (build_path_polygons, build_polygon_table) on degenerate input, and the offset table against
+    the per-cell crossing-number expression on 1.3e8 cell tests (tools/check_polygon_host.cpp) -- hipcc builds the host half
+    of the translation unit with the sanitizers (-Xarch_host)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    o1, o2, exe = str(tmp_path / "te_polygon_host.o"), str(tmp_path / "check_polygon_host.o"), str(tmp_path / "check_polygon_host")
+    _run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host",
+          "-fno-sanitize-recover=all"] + inc + ["-c", os.path.join(CSRC, "te_polygon.hip"), "-o", o1])
+    _run([hipcc, "--cuda-host-only", "-x", "hip", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] + inc +
+         ["-c", os.path.join(ROOT, "tools", "check_polygon_host.cpp"), "-o", o2])
+    _run([hipcc, "-fsanitize=address,undefined", o2, o1, "-o", exe])
+    out = _run([exe])
+    assert "cell tests=" in out and "path polygons=" in out, out[-500:]
