@@ -4,7 +4,8 @@ SlopeFilter / RoughnessFilter clip their scores at 0 (SlopeFilter.cpp:77-81, Rou
 footprint checks memoise only cells whose score IS 0 (TraversabilityMap.cpp:869-871, :897): a score that is 0 on one
 side of the comparison and 1e-7 on the other agrees within 1e-5 and still changes the NaN pattern of slope_footprint /
 roughness_footprint.  The fast tails therefore leave every cell whose raw score lies within their own error of the clip
-to the fix-up pass, which settles it with the generic (oracle-identical) arithmetic.  These tests put cells exactly there:
+to the fix-up pass, which settles it with the generic (oracle-identical) arithmetic (round 6's k_normals_small and
+k_chain_window run that arithmetic in place: no pass behind them).  These tests put cells exactly there:
 the critical values are taken from the oracle's own normal / roughness of chosen cells, so that those cells sit ON the
 clip (score exactly 0 in the oracle, neighbours in slope within 1e-7 of it), for every march of the normals kernels."""
 import os
@@ -58,14 +59,31 @@ def _case(kind):
         rows, cols, cells = 200, 150, 12
         elev = synth.perlin_elevation(rows, cols, seed=507, amplitude=1.5)
         return rows, cols, res, elev, synth.benchmark_radius(cells, res)
+    if kind == "one_cell_tie":  # the default 0.05 m radius on a 0.05 m map: k_normals_small's tie folds (round 6)
+        rows, cols = 600, 500
+        elev = synth.perlin_elevation(rows, cols, seed=508, amplitude=2.5)
+        return rows, cols, res, elev, res
+    if kind == "one_cell_holes":  # the same with 2 % speckle: discs of three and four cells beside the collinear ones
+        rows, cols = 600, 500
+        elev = synth.with_holes(synth.perlin_elevation(rows, cols, seed=509, amplitude=2.5), 0.02, seed=11)
+        return rows, cols, res, elev, res
+    if kind == "window":  # a small launch, discs of reach 1, single-cell step windows: k_chain_window (round 6)
+        rows, cols = 300, 200
+        elev = synth.perlin_elevation(rows, cols, seed=510, amplitude=2.5)
+        return rows, cols, res, elev, 1.2 * res
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["slim", "clean", "sparse", "dense", "ties", "narrow", "wide"])
+#: step windows of the cases that are not the file's usual two-cell ones
+_STEP_RADIUS = {"window": 0.04}
+
+
+@pytest.mark.parametrize("kind", ["slim", "clean", "sparse", "dense", "ties", "narrow", "wide", "one_cell_tie", "one_cell_holes", "window"])
 def test_scores_at_their_clip(capi, oracle, kind):
     rows, cols, res, elev, radius = _case(kind)
     g = oracle.geom(rows, cols, res, (2.0, -3.0))
-    base = dict(normals_radius=radius, rough_radius=radius, step_radius1=2 * res * 1.000001, step_radius2=2 * res * 1.000001,
+    step = _STEP_RADIUS.get(kind, 2 * res * 1.000001)
+    base = dict(normals_radius=radius, rough_radius=radius, step_radius1=step, step_radius2=step,
                 fp_radius=0.1, fp_offset=0.05, fp_check_roughness=1)
     op0 = oracle.default_params(slope_critical=1.0, rough_critical=0.05, **base)
     ref = oracle.chain(g, op0, elev, want_normals=True)
