@@ -265,9 +265,7 @@ def main():
                  "(TE_DIST_BACKEND=gloo lets the ranks share a device to exercise the code path; it is not a scaling figure)")
     rank, world, local_rank = tdist.init_process_group(backend_req)
     local_rank %= max(1, n_dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  "(or without a launcher: bench.py starts its own ranks)")
@@ -690,7 +688,7 @@ def main():
             ctx.close()
             sys.exit(1)
     ctx.close()
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         barrier()  # rank 0 is still timing the CPU baseline: leave the group together
         dist.destroy_process_group()
 

@@ -113,3 +113,32 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "one device per rank" in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_single_rank_can_be_made_to_run_its_collectives():
+    """TE_DIST_WORLD1_COLLECTIVES=1: world 1 initialises a process group and every helper runs its collective instead of the
+    shortcut (here over gloo; tests/test_gpu_multi.py runs the same switch over RCCL on the GPU box)."""
+    from traversability_estimation_amd import dist as tdist
+    code = ("import numpy as np\n"
+            "from traversability_estimation_amd import dist as d\n"
+            "assert d.init_process_group('gloo') == (0, 1, 0)\n"
+            "import torch.distributed as td\n"
+            "assert td.is_initialized() and td.get_world_size() == 1\n"
+            "assert d.ranks_report(3) == {'world': 1, 'backend': 'gloo', 'devices': [3]}\n"
+            "assert d.max_over_ranks(2.5) == 2.5 and d.broadcast_blob(b'xyz') == b'xyz'\n"
+            "d.barrier()\n"
+            "assert d.gather_shards(np.ones((2, 3), np.float32), 2).shape == (2, 3)\n"
+            "td.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(TE_DIST_WORLD1_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(tdist.free_port()), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # without the switch a single rank never touches torch.distributed
+    code2 = ("from traversability_estimation_amd import dist as d\n"
+             "assert d.init_process_group('gloo') == (0, 1, 0)\n"
+             "import torch.distributed as td\n"
+             "assert not td.is_initialized()\n"
+             "assert d.ranks_report(0) == {'world': 1, 'backend': None, 'devices': [0]}\n")
+    env.pop("TE_DIST_WORLD1_COLLECTIVES")
+    r = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -163,3 +163,25 @@ def test_bench_gpus_2_without_a_launcher_runs_two_ranks(capi):
     assert line["scaling"] == "weak" and line["parity_check"]["ok"]
     # two maps of 4096^2 went through the chain per step
     assert abs(line["value"] - 2 * 4096 * 4096 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-6 * line["value"]
+
+
+def test_bench_under_the_drivers_launcher_over_rccl_with_one_rank(capi):
+    """The driver's N > 1 form -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- with N = 1, the
+    only world a one-GPU box admits over RCCL, and TE_DIST_WORLD1_COLLECTIVES=1 so that the rank does not take the
+    world-of-one shortcuts: backend "nccl" initialises on its device, the barrier, the MAX over ranks, the gather of the
+    device indices and the parameter broadcast all go through RCCL on device tensors, and the line says so."""
+    import json
+    from traversability_estimation_amd import dist as tdist
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TE_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TE_DIST_WORLD1_COLLECTIVES"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(tdist.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--check-crops", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks"] == {"world": 1, "backend": "nccl", "devices": [0]}
+    assert line["parity_check"]["ok"]

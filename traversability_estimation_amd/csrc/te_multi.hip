@@ -62,8 +62,13 @@ int te_bcast_params(te_ctx** ctxs, int n, int root) {
       rep.push_back(k);
     }
   }
-  std::vector<te_params> got(devs.size(), p);
-  if (devs.size() > 1) {
+  // (the receivers' copies start out zeroed: what a context is given below has been through the broadcast)
+  std::vector<te_params> got(devs.size());
+  for (auto& q : got) memset(&q, 0, sizeof(q));
+  got[0] = p;
+  // TE_OPT_BCAST_RCCL on the root: a communicator of ONE rank when every context shares the root's device -- the same
+  // calls, so that a one-GPU host exercises this branch (the root's device then receives its own block back)
+  if (devs.size() > 1 || ctxs[root]->opt_bcast_rccl) {
     static Rccl rccl;
     if (!rccl.ok) return fail(TE_ERR_UNSUPPORTED, "te_bcast_params: %zu devices but librccl could not be loaded", devs.size());
     const int nd = (int)devs.size();

@@ -822,6 +822,9 @@ int te_set_option(te_ctx* c, int option, int value) {
       if (value < 0 || value > 2) return fail(TE_ERR_INVALID_ARG, "te_set_option: TE_OPT_GRAPH_REPLAY takes 0 (by size), 1 (always), 2 (never)");
       c->opt_graph = value;
       break;
+    case TE_OPT_BCAST_RCCL:
+      c->opt_bcast_rccl = value != 0;
+      return TE_OK;  // (no launch depends on it)
     default:
       return fail(TE_ERR_INVALID_ARG, "te_set_option: unknown option %d", option);
   }

@@ -13,14 +13,27 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def _world1_collectives():
+    """TE_DIST_WORLD1_COLLECTIVES=1: a single rank initialises its process group too and every helper below runs its
+    collective instead of the world-of-one shortcut -- how a one-GPU box exercises the RCCL branch of each of them."""
+    return os.environ.get("TE_DIST_WORLD1_COLLECTIVES") == "1"
+
+
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _world1_collectives())
+
+
 def init_process_group(backend=None):
-    """Returns (rank, world, local_rank).  No-op for world == 1."""
+    """Returns (rank, world, local_rank).  No-op for world == 1 (but see _world1_collectives)."""
     rank, world, local_rank = env_world()
-    if world > 1:
+    if world > 1 or _world1_collectives():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", str(rank))  # (a single rank without a launcher: _world1_collectives)
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if not dist.is_initialized():
@@ -56,7 +69,7 @@ def ranks_report(device_index):
     """{"world", "backend", "devices": [device index of every rank, gathered]} -- what the bench line carries so that a
     reader can see how many ranks ran and where."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return {"world": 1, "backend": None, "devices": [int(device_index)]}
     got = [None] * dist.get_world_size()
     dist.all_gather_object(got, int(device_index))
@@ -75,7 +88,7 @@ def broadcast_blob(blob, src=0):
     """Broadcast a bytes object of identical length on every rank (the te_params struct)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return bytes(blob)
     t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(_device())
     if dist.get_rank() != src:
@@ -99,7 +112,7 @@ def shard_range(n_maps, rank, world):
 def max_over_ranks(value):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -108,7 +121,7 @@ def max_over_ranks(value):
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -116,7 +129,7 @@ def gather_shards(local, n_maps):
     """all_gather of per-rank [n_local, cells] float32 arrays back into the full batch (tests only)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return np.asarray(local)
     world = dist.get_world_size()
     cells = local.shape[1]
