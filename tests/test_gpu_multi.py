@@ -142,6 +142,33 @@ def test_bcast_params_across_devices_over_rccl(capi):
             c.close()
 
 
+def test_bcast_params_over_rccl_on_one_device(capi):
+    """TE_OPT_BCAST_RCCL on the root: te_bcast_params takes its RCCL branch although every context shares one device --
+    librccl is found at run time, a communicator of one rank is created, the 144-byte block goes host -> device -> grouped
+    ncclBroadcast -> host, and the other contexts are given what came back.  (Between devices the same calls run with one
+    rank per device: test_bcast_params_across_devices_over_rccl, which needs two GPUs.)"""
+    ctxs = [capi.Context(0) for _ in range(3)]
+    try:
+        p = capi.default_params(slope_critical=0.65, step_ncrit=9, fp_radius=0.23, w_rough=0.25)
+        ctxs[1].set_params(p)
+        ctxs[1].set_option(capi.OPT_BCAST_RCCL, 1)
+        for _ in range(2):  # (a communicator per call: the second call builds another)
+            capi.bcast_params(ctxs, root=1)
+        want = bytes(memoryview(ctxs[1].get_params()))
+        assert want == bytes(memoryview(p))
+        for c in ctxs:
+            assert bytes(memoryview(c.get_params())) == want
+        # the default takes the host copy between contexts of one device: same result
+        ctxs[1].set_option(capi.OPT_BCAST_RCCL, 0)
+        ctxs[1].set_params(capi.default_params(rough_critical=0.07))
+        capi.bcast_params(ctxs, root=1)
+        for c in ctxs:
+            assert bytes(memoryview(c.get_params())) == bytes(memoryview(ctxs[1].get_params()))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_bench_gpus_2_without_a_launcher_runs_two_ranks(capi):
     """`python bench.py --gpus 2` with no torchrun around it (the driver's plain form) must start two ranks itself and say so
     in the line; on a one-GPU box the two gloo ranks share device 0 (TE_DIST_BACKEND=gloo), on a node with >= 2 GPUs the
