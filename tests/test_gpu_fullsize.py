@@ -3,6 +3,8 @@ needs minutes at these sizes, so the full maps are checked with (a) the shape-ge
 independent device implementation that IS checked against the oracle cell by cell in test_gpu_chain.py,
 (b) crops against the oracle at the corners, an edge and the centre, (c) determinism / idempotence of the
 dirty-region path, (d) the combine identity."""
+import os
+
 import numpy as np
 import pytest
 
@@ -403,3 +405,32 @@ def test_batch_with_sparse_holes(capi, oracle):
             assert_layers_match({k: fast[k][b * per:(b + 1) * per] for k in OUT_LAYERS}, want, ctx=f"sparse holes, map {b}")
     finally:
         oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("n", [16384, 32768])
+def test_maps_of_2_28_and_2_30_cells(n):
+    """Maximum sizes: ONE map of 16384^2 (layers of 1 GiB: the marching kernels, byte offsets up to 2^30) and of 32768^2
+    (layers of 4 GiB, a 62 GiB slab: byte offsets cross 2^31 and reach 2^32 -- the marching kernels address a map with
+    32-bit byte offsets and hand such a map to the double kernels, te_normals3.hip / te_footprint5.hip: `>= 4294967296.0`).
+    Chain + footprint pass at the bench radii; crops of 192 x 192 cells against the oracle at the corners, in the middle
+    and around the columns whose byte offsets cross 2^30 / 2^31 / 2^32 (tools/dbg/large_map.py, its own process: the host
+    arrays are 1 and 4 GiB)."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "large_map.py"), str(n)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "mismatching cells: 0" in r.stdout
+    assert r.stdout.count(": checked") >= 4
+
+
+def test_batch_whose_layers_exceed_4_gib():
+    """The batch axis sized for the device's memory: 4200 maps of 512 x 512 in one launch (4.4 GB per layer, a 63 GB slab).
+    Map offsets are 64-bit, offsets within a map 32-bit: the maps on both sides of the 2^31- and 2^32-byte marks, the first
+    and the last against the oracle (chain + footprint), one map in two slots bit-equal (tools/dbg/large_batch.py)."""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "large_batch.py"), "4200"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("checked") == 7 and r.stdout.strip().endswith("ok")
