@@ -407,9 +407,10 @@ def test_batch_with_sparse_holes(capi, oracle):
         oracle.set_threads(1)
 
 
-@pytest.mark.parametrize("n", [16384, 32768])
+@pytest.mark.parametrize("n", [16384, 28672, 32768])
 def test_maps_of_2_28_and_2_30_cells(n):
-    """Maximum sizes: ONE map of 16384^2 (layers of 1 GiB: the marching kernels, byte offsets up to 2^30) and of 32768^2
+    """Maximum sizes: ONE map of 16384^2 (layers of 1 GiB: the marching kernels, byte offsets up to 2^30), of 28672^2 (3.3 GB:
+    the marching kernels beyond 2^31 bytes -- they re-base their 32-bit offsets strip by strip) and of 32768^2
     (layers of 4 GiB, a 62 GiB slab: byte offsets cross 2^31 and reach 2^32 -- the marching kernels address a map with
     32-bit byte offsets and hand such a map to the double kernels, te_normals3.hip / te_footprint5.hip: `>= 4294967296.0`).
     Chain + footprint pass at the bench radii; crops of 192 x 192 cells against the oracle at the corners, in the middle
