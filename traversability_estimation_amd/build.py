@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SOURCES = ["csrc/te_kernels.hip", "csrc/te_shim.hip", "csrc/te_transfer.hip", "csrc/te_paths_api.hip", "csrc/te_multi.hip", "csrc/te_stage.hip", "csrc/te_fast_step.hip", "csrc/te_step5.hip", "csrc/te_slide_normals.hip", "csrc/te_normals3.hip", "csrc/te_normals_small.hip", "csrc/te_footprint.hip", "csrc/te_footprint3.hip", "csrc/te_footprint4.hip", "csrc/te_footprint5.hip", "csrc/te_paths.hip", "csrc/te_gridmap_msg.hip", "csrc/te_polygon.hip", "csrc/te_trace.hip"]
 # (every header of csrc/ and the public one; an object's key covers the ones it includes, see _deps)
-HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "csrc/te_ctx.h", "csrc/te_n3_plan.h", "csrc/te_hole_routing.h", "../include/travgpu.h"]
+HEADERS = ["csrc/te_internal.h", "csrc/te_march.h", "csrc/te_march5.h", "csrc/te_cell.h", "csrc/te_eig.h", "csrc/te_eig3.h", "csrc/te_geom.h", "csrc/te_msg.h", "csrc/te_ctx.h", "csrc/te_n3_plan.h", "csrc/te_hole_routing.h", "csrc/te_tie_triple.h", "../include/travgpu.h"]
 LIB = os.path.join(_HERE, "libtravgpu.so")
 LAB_LIB = os.path.join(_HERE, "libtravgpu_lab.so")
 OBJDIR = os.path.join(_HERE, "_build")

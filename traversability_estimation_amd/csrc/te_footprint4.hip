@@ -29,11 +29,13 @@
 // the circle belong to a disc or not as SpiralIterator::isInside() decides from rounded positions, per centre.  The
 // kernel (TIES = true, instantiated for the whole-cell shapes Q = R^2) slides the full shape, circle included, and every
 // row takes the rejected circle cells of its centre out again: one ring read and the reference's own test per cell
-// on the circle (12 at 15 cells).  k_fp_blocked applies the same test to the table entries that carry the tie flag.
+// on the circle (12 at 15 cells: the four axis cells and the eight of the triple 9-12-15, known from R at compile time;
+// the test's dx * dx is a lane's constant and its dy * dy a row's -- round 6: 401 -> see DESIGN.md us at 15 cells).  k_fp_blocked applies the same test to the table entries that carry the tie flag.
 // Used when the host can bound the traversability values (layer written by the chain with non-negative weights);
 // otherwise, and for radii whose k would drop below 17, k_fp_slide3 serves.
 #include "te_internal.h"
 #include "te_march.h"
+#include "te_tie_triple.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -123,6 +125,20 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
     const double dxp = (a.ax + a.res * (double)(-(icol + R))) - xi, dxm = (a.ax + a.res * (double)(-(icol - R))) - xi;
     xfail_p = __ballot(!(dxp * dxp + 0.0 <= a.r2) && icol + R < a.rows);
     xfail_m = __ballot(!(dxm * dxm + 0.0 <= a.r2) && icol - R >= 0);
+  }
+  // TIES, the triple's cells: isInside() tests dx * dx + dy * dy <= r2 with dx a function of the lane and dy of the row --
+  // dx * dx once per lane (here), dy * dy once per row (tail); a cell outside the map is never taken out: -inf passes the test
+  constexpr int TA = TIES ? tie_triple_a(R) : 0, TB = TIES ? tie_triple_b(R) : 0;
+  static_assert(!TIES || tie_triples(R) <= 1, "one Pythagorean triple per radius (whole-cell radii up to 16 cells)");
+  double dxsq[4] = {0.0, 0.0, 0.0, 0.0};  // di = -TB, -TA, +TA, +TB
+  if constexpr (TA != 0) {
+    const double xi = a.ax + a.res * (double)(-icol);
+    constexpr int di4[4] = {-TB, -TA, TA, TB};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double dx = (a.ax + a.res * (double)(-(icol + di4[q]))) - xi;
+      dxsq[q] = (unsigned)(icol + di4[q]) < (unsigned)a.rows ? dx * dx : -__builtin_inf();
+    }
   }
 
   // rows are loaded C steps before they are staged (a queue slot per unrolled position): with one step of lead the
@@ -235,16 +251,33 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
         }
       }
       // the others (3-4-5 radii: 5, 10, 13, 15 cells): the reference's test per cell
-      if (a.n_gen != 0) {
-        const double xi = a.ax + a.res * (double)(-icol);
-#pragma unroll 1
-        for (int t = 0; t < a.n_gen; ++t) {
-          const int e = a.gen_tab[t];
-          const int di = (int)(signed char)(e & 0xff), dj = (int)(signed char)((e >> 8) & 0xff);
-          const double dx = (a.ax + a.res * (double)(-(icol + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
-          const bool fail = !(dx * dx + dy * dy <= a.r2) && (unsigned)(icol + di) < (unsigned)a.rows && (unsigned)(j + dj) < (unsigned)a.cols;
-          take_out(fail, ring[wrap(slot0 + dj + R) * W + lane + R + di]);
+      if constexpr (TA != 0) {
+        constexpr int d4[4] = {-TB, -TA, TA, TB};
+        double dysq[4];
+        const unsigned* rrow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = j + d4[q];
+          const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+          dysq[q] = (unsigned)jj < (unsigned)a.cols ? dy * dy : -__builtin_inf();
+          rrow[q] = ring + wrap(slot0 + d4[q] + R) * W + lane + R;
         }
+        // (di, dj) = (+-TA, +-TB) and (+-TB, +-TA): index q of d4 pairs with 3 - q' ... spelled out: |di| = TA <-> |dj| = TB
+        unsigned sub = 0;  // packed sum of the cells taken out (eight cells: neither field overflows)
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+          constexpr int lo_hi[4][2] = {{1, 2}, {0, 3}, {0, 3}, {1, 2}};  // |d4[qi]| = TB: dj = -+TA (slots 1, 2); = TA: dj = -+TB (slots 0, 3)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int qj = lo_hi[qi][s2];
+            const bool fail = !(dxsq[qi] + dysq[qj] <= a.r2);
+            const unsigned wd = rrow[qj][d4[qi]];
+            sub += fail ? wd : 0u;
+            nfail += fail ? 1 : 0;
+          }
+        }
+        Xc -= sub;
+        NUc -= sub >> 24;
       }
       if (__builtin_expect(__any(nfail != 0), 0)) rn = nfail ? (float)(a.inv_scale / (double)(nt - nfail)) : rn;
     }
@@ -367,6 +400,8 @@ bool launch_f4(const F4Args& a0, int batch, hipStream_t s) {
   constexpr int R = Shape<Q>::R;
   static_assert(R * R == Q, "instantiated for the shapes a tie radius can have: its circle passes through (R, 0)");
   if (a.n_ties == 0) return false;  // (tie-free discs: k_fp_slide5, or the double kernel -- footprint_slide4 does not ask)
+  // the kernel knows the circle's cells from R (axis cells + one Pythagorean triple): the disc's own table must say the same
+  if (a.n_gen != tie_triple_cells(R) || a.n_ties != 4 + a.n_gen) return false;
   constexpr int lds = (2 * R + 2) * (kLanes + 2 * R) * 4;
   int per_cu = (160 * 1024) / (((lds + 2047) / 2048) * 2048);  // see te_normals3.hip (resident_blocks)
   if (per_cu > kF4Waves * 4) per_cu = kF4Waves * 4;

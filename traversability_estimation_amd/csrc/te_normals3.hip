@@ -34,6 +34,7 @@
 #include "te_internal.h"
 #include "te_march.h"
 #include "te_n3_plan.h"
+#include "te_tie_triple.h"
 #include "te_eig.h"
 #include "te_eig3.h"
 
@@ -473,6 +474,20 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
       n0 = gt[0]; si0 = gt[1]; sj0 = gt[2]; sii0 = gt[3]; sij0 = gt[4]; sjj0 = gt[5];
     }
   }
+  // the circle's other cells (te_tie_triple.h: the eight of a Pythagorean triple, radii of 5 and 10 cells here): dx * dx of
+  // isInside()'s test per lane, -inf for a cell outside the map (it passes the test: never taken out)
+  constexpr int TA = TIES ? tie_triple_a(R) : 0, TB = TIES ? tie_triple_b(R) : 0;
+  static_assert(!TIES || tie_triples(R) <= 1, "one Pythagorean triple per radius");
+  double dxsq[4] = {0.0, 0.0, 0.0, 0.0};  // di = -TB, -TA, +TA, +TB
+  if constexpr (TA != 0) {
+    const double xi = a.ax + a.res * (double)(-icol);
+    constexpr int d4[4] = {-TB, -TA, TA, TB};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double dx = (a.ax + a.res * (double)(-(icol + d4[q]))) - xi;
+      dxsq[q] = (unsigned)(icol + d4[q]) < (unsigned)a.rows ? dx * dx : -__builtin_inf();
+    }
+  }
   auto tail_ties = [&](int j, int ky, auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
     constexpr int pc = u + R;  // ring position of map row j
@@ -532,30 +547,36 @@ __device__ __forceinline__ int march3(const N3Args& a, double* ring, unsigned lo
         }
       }
     }
-    if (a.n_gen != 0) {  // the other circle cells (3-4-5 radii): both coordinates decide, cell by cell
-      const int slot0 = (int)(__builtin_amdgcn_readfirstlane(vb[0]) / (unsigned)RB) + u;  // ring slot of map row j - R
-      const double xi = a.ax + a.res * (double)(-icol);
-#pragma unroll 1
-      for (int t = 0; t < a.n_gen; ++t) {
-        const int e = a.gen_tab[t];
-        const int di = (int)(signed char)(e & 0xff), dj = (int)(signed char)((e >> 8) & 0xff);
-        const double dx = (a.ax + a.res * (double)(-(icol + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
-        const bool fail = !(dx * dx + dy * dy <= a.r2) && (unsigned)(icol + di) < (unsigned)a.rows && (unsigned)(j + dj) < (unsigned)a.cols;
-        int sl = slot0 + dj + R;
-        sl = sl >= NR ? sl - NR : sl;
-        sl = sl >= NR ? sl - NR : sl;
-        const double zz = fail ? ring[sl * W + lane + R + di] : 0.0;
-        n -= fail ? 1 : 0;
-        si -= fail ? di : 0;
-        sj -= fail ? dj : 0;
-        sii -= fail ? di * di : 0;
-        sij -= fail ? di * dj : 0;
-        sjj -= fail ? dj * dj : 0;
-        lSz -= zz;
-        lSiz = fma(-(double)di, zz, lSiz);
-        lSjz = fma(-(double)dj, zz, lSjz);
-        lSzz = fma(-zz, zz, lSzz);
+    if constexpr (TA != 0) {  // the other circle cells: both coordinates decide -- dx * dx from the lane, dy * dy from the row
+      constexpr int d4[4] = {-TB, -TA, TA, TB};
+      double dysq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = j + d4[q];
+        const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+        dysq[q] = (unsigned)jj < (unsigned)a.cols ? dy * dy : -__builtin_inf();
       }
+      static_for<4>([&](auto qic) __attribute__((always_inline)) {
+        constexpr int qi = decltype(qic)::value;
+        constexpr int di = d4[qi];
+        static_for<2>([&](auto sc) __attribute__((always_inline)) {
+          constexpr int qj = (qi == 0 || qi == 3) ? (decltype(sc)::value == 0 ? 1 : 2) : (decltype(sc)::value == 0 ? 0 : 3);  // |di| = TB: dj = -+TA; |di| = TA: dj = -+TB
+          constexpr int dj = d4[qj];
+          const bool fail = !(dxsq[qi] + dysq[qj] <= a.r2);
+          const double zc = cell(std::integral_constant<int, pc + dj>{}, std::integral_constant<int, di>{});
+          const double zz = fail ? zc : 0.0;
+          n -= fail ? 1 : 0;
+          si -= fail ? di : 0;
+          sj -= fail ? dj : 0;
+          sii -= fail ? di * di : 0;
+          sij -= fail ? di * dj : 0;
+          sjj -= fail ? dj * dj : 0;
+          lSz -= zz;
+          lSiz = fma(-(double)di, zz, lSiz);
+          lSjz = fma(-(double)dj, zz, lSjz);
+          lSzz = fma(-zz, zz, lSzz);
+        });
+      });
     }
     double qs = 0.0;
     const int unresolved = general_tail3(a.res, n, si, sj, sii, sij, sjj, lSz, lSiz, lSjz, lSzz, fx, fy, fz, qs);
@@ -1231,6 +1252,8 @@ bool launch3(const Geo& g, const N3Args& a0, bool keep, int maps, hipStream_t s)
   constexpr unsigned kDyn = TE_N3_DYN_LDS ? (unsigned)((2 * R + 2) * (kLanes + 2 * R) * 8) : 0u;  // the ring, when the kernel declares it extern
   if (a.n_ties != 0) {  // tie radius: the whole-cell shapes only
     if constexpr (R * R == Q && R >= 3) {  // (tie radii of one and two cells: k_normals_small, te_normals_small.hip)
+      // the kernel knows the circle's cells from R (te_tie_triple.h): the disc's own table must say the same
+      if (a.n_gen != tie_triple_cells(R) || a.n_ties != 4 + a.n_gen) return false;
       if (keep)
         hipLaunchKernelGGL((k_normals3<Q, true, 2, true>), grid, dim3(kLanes), kDyn, s, a);
       else
