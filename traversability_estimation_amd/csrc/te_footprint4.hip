@@ -213,6 +213,32 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
     for (int q = lane; q < chunk_left; q += kLanes) a.blocked_list[chunk_at + (unsigned)q] = kF4NoCell;
   };
 
+  // TIES: what depends on the ROW alone -- isInside() for (0, +-R) (dx = 0 exactly) and dy * dy of the triple's cells -- is
+  // evaluated for 64 rows at once, lane l taking row ybase + l, and read back row by row (a ballot bit; v_readlane)
+  int ybase = js - kLanes;  // rows [ybase, ybase + 64) are at hand: none yet
+  unsigned long long yfail_p = 0ull, yfail_m = 0ull;  // bit l: (0, +R) / (0, -R) of row ybase + l is rejected (and lies in the map)
+  double dysq_l[4] = {0.0, 0.0, 0.0, 0.0};            // dy * dy for dj = -TB, -TA, +TA, +TB of row ybase + lane (-inf: outside the map)
+  auto rows_ahead = [&](int j0) __attribute__((always_inline)) {
+    ybase = j0;
+    const int jr = j0 + lane;
+    const double yr = a.ay + a.res * (double)(-jr);  // cell_y
+    const double dyp = (a.ay + a.res * (double)(-(jr + R))) - yr, dym = (a.ay + a.res * (double)(-(jr - R))) - yr;
+    yfail_p = __ballot(!(0.0 + dyp * dyp <= a.r2) && (unsigned)(jr + R) < (unsigned)a.cols);
+    yfail_m = __ballot(!(0.0 + dym * dym <= a.r2) && (unsigned)(jr - R) < (unsigned)a.cols);
+    if constexpr (TA != 0) {
+      constexpr int d4[4] = {-TB, -TA, TA, TB};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double dy = (a.ay + a.res * (double)(-(jr + d4[q]))) - yr;
+        dysq_l[q] = (unsigned)(jr + d4[q]) < (unsigned)a.cols ? dy * dy : -__builtin_inf();
+      }
+    }
+  };
+  auto row_value = [&](double v, int l) __attribute__((always_inline)) {  // v of lane l (uniform l)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+  };
+
   auto tail = [&](int j, int u) __attribute__((always_inline)) {
     int nt = nt_mid;
     float rn = rnt;
@@ -240,16 +266,11 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
       const unsigned* crow = ring + wrap(slot0 + R) * W + lane + R;
       take_out(((xfail_p >> lane) & 1ull) != 0ull, crow[R]);
       take_out(((xfail_m >> lane) & 1ull) != 0ull, crow[-R]);
-      // (0, +-R): dx = 0 exactly, the same answer for every lane of the row
-      const double yj = a.ay + a.res * (double)(-j);  // cell_y
-#pragma unroll
-      for (int sgn = -1; sgn <= 1; sgn += 2) {
-        const int jj = j + sgn * R;
-        if ((unsigned)jj < (unsigned)a.cols) {
-          const double dy = (a.ay + a.res * (double)(-jj)) - yj;
-          if (!(0.0 + dy * dy <= a.r2)) take_out(true, ring[wrap(slot0 + R + sgn * R) * W + lane + R]);
-        }
-      }
+      // (0, +-R): dx = 0 exactly, the same answer for every lane of the row -- from rows_ahead
+      if (__builtin_expect(j - ybase >= kLanes, 0)) rows_ahead(j);  // (uniform)
+      const int yl = __builtin_amdgcn_readfirstlane(j - ybase);
+      if ((yfail_m >> yl) & 1ull) take_out(true, ring[wrap(slot0 + R - R) * W + lane + R]);
+      if ((yfail_p >> yl) & 1ull) take_out(true, ring[wrap(slot0 + R + R) * W + lane + R]);
       // the others (3-4-5 radii: 5, 10, 13, 15 cells): the reference's test per cell
       if constexpr (TA != 0) {
         constexpr int d4[4] = {-TB, -TA, TA, TB};
@@ -257,9 +278,7 @@ __global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(kF4Waves
         const unsigned* rrow[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int jj = j + d4[q];
-          const double dy = (a.ay + a.res * (double)(-jj)) - yj;
-          dysq[q] = (unsigned)jj < (unsigned)a.cols ? dy * dy : -__builtin_inf();
+          dysq[q] = row_value(dysq_l[q], yl);
           rrow[q] = ring + wrap(slot0 + d4[q] + R) * W + lane + R;
         }
         // (di, dj) = (+-TA, +-TB) and (+-TB, +-TA): index q of d4 pairs with 3 - q' ... spelled out: |di| = TA <-> |dj| = TB

@@ -169,8 +169,20 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
         const int ii = i + a.di[k], jj = j + a.dj[k];
         bool in = (unsigned)ii < (unsigned)a.rows && (unsigned)jj < (unsigned)a.cols;
         if ((a.tie_mask >> k) & 1u) {  // CircleIterator::isInside with the reference's rounded positions
-          const double dx = (a.ax + a.res * (double)(-ii)) - xi, dy = (a.ay + a.res * (double)(-jj)) - yj;
-          in = in && (dx * dx + dy * dy <= a.r2);
+          // (a cell on an axis: its other coordinate is the centre's own, that difference and its square are 0 exactly and
+          // x + 0 = x -- the term is left out, the result is the same bit for bit; uniform branches)
+          double sq;
+          if (a.di[k] == 0) {
+            const double dy = (a.ay + a.res * (double)(-jj)) - yj;
+            sq = dy * dy;
+          } else if (a.dj[k] == 0) {
+            const double dx = (a.ax + a.res * (double)(-ii)) - xi;
+            sq = dx * dx;
+          } else {
+            const double dx = (a.ax + a.res * (double)(-ii)) - xi, dy = (a.ay + a.res * (double)(-jj)) - yj;
+            sq = dx * dx + dy * dy;
+          }
+          in = in && (sq <= a.r2);
         }
         if (in) zn[k] = a.elev[mo + (size_t)jj * a.rows + ii];
       }
@@ -265,9 +277,17 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_chain_window(SmallArgs a) 
       constexpr int k = decltype(kc)::value, di = k % 5 - 2, dj = k / 5 - 2;
       if (k != 12 && (((a.disc25 | a.tie25) >> k) & 1u)) {  // (uniform)
         bool in = true;
-        if ((a.tie25 >> k) & 1u) {  // CircleIterator::isInside with the reference's rounded positions
-          const double dx = (a.ax + a.res * (double)(-(i + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
-          in = dx * dx + dy * dy <= a.r2;
+        if ((a.tie25 >> k) & 1u) {  // CircleIterator::isInside with the reference's rounded positions (axis cells: see k_normals_small)
+          if constexpr (di == 0) {
+            const double dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
+            in = dy * dy <= a.r2;
+          } else if constexpr (dj == 0) {
+            const double dx = (a.ax + a.res * (double)(-(i + di))) - xi;
+            in = dx * dx <= a.r2;
+          } else {
+            const double dx = (a.ax + a.res * (double)(-(i + di))) - xi, dy = (a.ay + a.res * (double)(-(j + dj))) - yj;
+            in = dx * dx + dy * dy <= a.r2;
+          }
         }
         const bool v = in && __builtin_isfinite(z[k]);
         const double dz = v ? (double)z[k] - zc : 0.0;
