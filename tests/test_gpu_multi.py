@@ -146,27 +146,30 @@ def test_bcast_params_over_rccl_on_one_device(capi):
     """TE_OPT_BCAST_RCCL on the root: te_bcast_params takes its RCCL branch although every context shares one device --
     librccl is found at run time, a communicator of one rank is created, the 144-byte block goes host -> device -> grouped
     ncclBroadcast -> host, and the other contexts are given what came back.  (Between devices the same calls run with one
-    rank per device: test_bcast_params_across_devices_over_rccl, which needs two GPUs.)"""
-    ctxs = [capi.Context(0) for _ in range(3)]
-    try:
-        p = capi.default_params(slope_critical=0.65, step_ncrit=9, fp_radius=0.23, w_rough=0.25)
-        ctxs[1].set_params(p)
-        ctxs[1].set_option(capi.OPT_BCAST_RCCL, 1)
-        for _ in range(2):  # (a communicator per call: the second call builds another)
-            capi.bcast_params(ctxs, root=1)
-        want = bytes(memoryview(ctxs[1].get_params()))
-        assert want == bytes(memoryview(p))
-        for c in ctxs:
-            assert bytes(memoryview(c.get_params())) == want
+    rank per device: test_bcast_params_across_devices_over_rccl, which needs two GPUs.)  In a process of its own: librccl
+    prints its version banner to the C stdout of whoever initialises it, behind pytest's summary line."""
+    code = (
+        "from traversability_estimation_amd import capi\n"
+        "capi.load()\n"
+        "ctxs = [capi.Context(0) for _ in range(3)]\n"
+        "p = capi.default_params(slope_critical=0.65, step_ncrit=9, fp_radius=0.23, w_rough=0.25)\n"
+        "ctxs[1].set_params(p)\n"
+        "ctxs[1].set_option(capi.OPT_BCAST_RCCL, 1)\n"
+        "for _ in range(2):\n"  # (a communicator per call: the second call builds another)
+        "    capi.bcast_params(ctxs, root=1)\n"
+        "want = bytes(memoryview(ctxs[1].get_params()))\n"
+        "assert want == bytes(memoryview(p))\n"
+        "assert all(bytes(memoryview(c.get_params())) == want for c in ctxs)\n"
         # the default takes the host copy between contexts of one device: same result
-        ctxs[1].set_option(capi.OPT_BCAST_RCCL, 0)
-        ctxs[1].set_params(capi.default_params(rough_critical=0.07))
-        capi.bcast_params(ctxs, root=1)
-        for c in ctxs:
-            assert bytes(memoryview(c.get_params())) == bytes(memoryview(ctxs[1].get_params()))
-    finally:
-        for c in ctxs:
-            c.close()
+        "ctxs[1].set_option(capi.OPT_BCAST_RCCL, 0)\n"
+        "ctxs[1].set_params(capi.default_params(rough_critical=0.07))\n"
+        "capi.bcast_params(ctxs, root=1)\n"
+        "assert all(bytes(memoryview(c.get_params())) == bytes(memoryview(ctxs[1].get_params())) for c in ctxs)\n"
+        "[c.close() for c in ctxs]\n"
+        "print('rccl-one-device ok')\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-one-device ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_bench_gpus_2_without_a_launcher_runs_two_ranks(capi):
@@ -212,3 +215,6 @@ def test_bench_under_the_drivers_launcher_over_rccl_with_one_rank(capi):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["ranks"] == {"world": 1, "backend": "nccl", "devices": [0]}
     assert line["parity_check"]["ok"]
+    # the JSON line is the LAST thing on stdout: librccl's version banner (NCCL_DEBUG=VERSION on these boxes) went out when
+    # the communicator came up (dist.init_process_group flushes the C stdout), not at exit
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()][-1].startswith("{"), r.stdout[-2000:]

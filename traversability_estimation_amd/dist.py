@@ -24,6 +24,14 @@ def _active():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _world1_collectives())
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+
+
 def init_process_group(backend=None):
     """Returns (rank, world, local_rank).  No-op for world == 1 (but see _world1_collectives)."""
     rank, world, local_rank = env_world()
@@ -40,6 +48,11 @@ def init_process_group(backend=None):
             if backend == "nccl":
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+                # librccl prints its version banner (NCCL_DEBUG=VERSION, exported on the GPU boxes) to the C stdout of every
+                # rank when its communicator comes up; into a pipe that is block-buffered and would appear at exit, BEHIND
+                # the one JSON line rank 0 prints.  The first collective brings the communicator up; flush it out now.
+                dist.barrier()
+                _flush_c_stdio()
             else:
                 dist.init_process_group(backend)
     return rank, world, local_rank
