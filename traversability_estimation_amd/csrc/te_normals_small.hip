@@ -148,8 +148,12 @@ __device__ __forceinline__ void small_tail(const SmallArgs& a, int n, int si, in
   }
 }
 
-template <bool KEEP>
+// CROSS: the disc is the centre and its four edge neighbours, all four ON the circle (a one-cell tie radius: the default
+// 0.05 m on a 0.05 m map) -- the offsets are constants, the sums lose their zero terms and their int -> double conversions
+template <bool KEEP, bool CROSS>
 __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a) {
+  constexpr int NOFF = CROSS ? 4 : kSmallMaxOffsets;
+  constexpr int cdi[4] = {1, -1, 0, 0}, cdj[4] = {0, 0, 1, -1};
   const int lane = (int)threadIdx.x, ty = (int)threadIdx.y;
   const int mz = a.map >= 0 ? 0 : (int)blockIdx.z;
   const size_t mo = (size_t)(a.map >= 0 ? a.map : mz) * (size_t)a.map_cells;
@@ -161,21 +165,22 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
     // every neighbour's load is issued before the first is used (a loop over n_off waits for one load per turn: on a
     // 256^2 map the kernel then took 18 us against 11 for the sliding kernel it replaces)
     const double xi = a.ax + a.res * (double)(-i), yj = a.ay + a.res * (double)(-j);  // cell_x, cell_y (te_geom.h)
-    float zn[kSmallMaxOffsets];
+    float zn[NOFF];
 #pragma unroll
-    for (int k = 0; k < kSmallMaxOffsets; ++k) {
+    for (int k = 0; k < NOFF; ++k) {
       zn[k] = qnan();
-      if (k < a.n_off) {  // (uniform)
-        const int ii = i + a.di[k], jj = j + a.dj[k];
+      if (CROSS || k < a.n_off) {  // (uniform)
+        const int odi = CROSS ? cdi[k & 3] : (int)a.di[k], odj = CROSS ? cdj[k & 3] : (int)a.dj[k];
+        const int ii = i + odi, jj = j + odj;
         bool in = (unsigned)ii < (unsigned)a.rows && (unsigned)jj < (unsigned)a.cols;
-        if ((a.tie_mask >> k) & 1u) {  // CircleIterator::isInside with the reference's rounded positions
+        if (CROSS || ((a.tie_mask >> k) & 1u)) {  // CircleIterator::isInside with the reference's rounded positions
           // (a cell on an axis: its other coordinate is the centre's own, that difference and its square are 0 exactly and
           // x + 0 = x -- the term is left out, the result is the same bit for bit; uniform branches)
           double sq;
-          if (a.di[k] == 0) {
+          if (odi == 0) {
             const double dy = (a.ay + a.res * (double)(-jj)) - yj;
             sq = dy * dy;
-          } else if (a.dj[k] == 0) {
+          } else if (odj == 0) {
             const double dx = (a.ax + a.res * (double)(-ii)) - xi;
             sq = dx * dx;
           } else {
@@ -194,9 +199,9 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
       int n = 1, si = 0, sj = 0, sii = 0, sij = 0, sjj = 0;
       double Sz = 0.0, Siz = 0.0, Sjz = 0.0, Szz = 0.0;
 #pragma unroll
-      for (int k = 0; k < kSmallMaxOffsets; ++k) {
-        if (k < a.n_off) {
-          const int di = a.di[k], dj = a.dj[k];
+      for (int k = 0; k < NOFF; ++k) {
+        if (CROSS || k < a.n_off) {
+          const int di = CROSS ? cdi[k & 3] : (int)a.di[k], dj = CROSS ? cdj[k & 3] : (int)a.dj[k];
           const bool v = __builtin_isfinite(zn[k]);
           const double dz = v ? (double)zn[k] - zc : 0.0;
           const int w = v ? 1 : 0;
@@ -207,8 +212,15 @@ __global__ __launch_bounds__(kLanes* kSmallBY) void k_normals_small(SmallArgs a)
           sij += w * di * dj;
           sjj += w * dj * dj;
           Sz += dz;
-          Siz = fma((double)di, dz, Siz);
-          Sjz = fma((double)dj, dz, Sjz);
+          if constexpr (CROSS) {  // offsets of +-1 and 0: fma(+-1, dz, S) = S +- dz, fma(0, dz, S) = S (dz is finite)
+            if (di == 1) Siz += dz;
+            if (di == -1) Siz -= dz;
+            if (dj == 1) Sjz += dz;
+            if (dj == -1) Sjz -= dz;
+          } else {
+            Siz = fma((double)di, dz, Siz);
+            Sjz = fma((double)dj, dz, Sjz);
+          }
           Szz = fma(dz, dz, Szz);
         }
       }
@@ -450,10 +462,22 @@ bool normals_small(const Geo& g, const ChainParams& p, const Layers& L, bool kee
   fg->nbz = r.map >= 0 ? 1 : g.batch;
   fg->frame = -1;  // nothing is left to the fix-up pass: the caller does not launch it
   const dim3 grid((unsigned)fg->ntx, (unsigned)((r.j1 - r.j0 + kSmallBY - 1) / kSmallBY), (unsigned)fg->nbz);
+  // the one-cell tie radius: the four edge neighbours, every one of them on the circle (any order in the table)
+  bool cross = a.n_off == 4 && a.tie_mask == 0xfu;
+  for (int k = 0; k < 4 && cross; ++k) cross = (a.di[k] == 0) != (a.dj[k] == 0) && a.di[k] * a.di[k] + a.dj[k] * a.dj[k] == 1;
+  for (int k = 0; k < 4 && cross; ++k)
+    for (int q = 0; q < k; ++q) cross = cross && !(a.di[k] == a.di[q] && a.dj[k] == a.dj[q]);
+  if (cross) {
+    if (keep_normals)
+      hipLaunchKernelGGL((k_normals_small<true, true>), grid, dim3(kLanes, kSmallBY), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_normals_small<false, true>), grid, dim3(kLanes, kSmallBY), 0, s, a);
+    return true;
+  }
   if (keep_normals)
-    hipLaunchKernelGGL(k_normals_small<true>, grid, dim3(kLanes, kSmallBY), 0, s, a);
+    hipLaunchKernelGGL((k_normals_small<true, false>), grid, dim3(kLanes, kSmallBY), 0, s, a);
   else
-    hipLaunchKernelGGL(k_normals_small<false>, grid, dim3(kLanes, kSmallBY), 0, s, a);
+    hipLaunchKernelGGL((k_normals_small<false, false>), grid, dim3(kLanes, kSmallBY), 0, s, a);
   return true;
 }
 
