@@ -51,6 +51,8 @@ def lib():
         L.teo_geom_init.argtypes = [gp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.teo_params_default.argtypes = [pp]
         L.teo_set_threads.argtypes = [C.c_int]
+        L.teo_set_normals_rank_rule.argtypes = [C.c_int]
+        L.teo_set_normals_rank_rule.restype = None
         L.teo_get_max_threads.restype = C.c_int
         L.teo_normals.argtypes = [gp, fp, C.c_double, C.c_int, fp, fp, fp]
         L.teo_slope.argtypes = [gp, fp, C.c_double, fp]
@@ -104,6 +106,11 @@ def default_params(**over):
 
 def set_threads(n):
     lib().teo_set_threads(int(n))
+
+
+def set_normals_rank_rule(on):
+    """NormalVectorsFilter's degenerate-plane rule of the filter that wrote the reference's bag (te_oracle.c); off by default."""
+    lib().teo_set_normals_rank_rule(1 if on else 0)
 
 
 def max_threads():

@@ -74,6 +74,9 @@ void teo_params_default(teo_params* p); /* shipped YAML defaults */
 
 /* number of OpenMP threads used by the loops below (1 = the reference's single thread) */
 void teo_set_threads(int n);
+/* 1: NormalVectorsFilter's degenerate-plane rule of the filter that wrote the reference's bag (rank-deficient scatter matrix ->
+ * UnitZ; te_oracle.c).  0 (default): the current area method. */
+void teo_set_normals_rank_rule(int on);
 int teo_get_max_threads(void);
 
 /* a1: NormalVectorsFilter, area method. Outputs NaN where the centre elevation is invalid. */

@@ -30,6 +30,27 @@ def test_chain_reproduces_bag_golden(bag, oracle):
     assert _bitdiff(out["traversability"], bag["traversability"], rows) <= KNOWN_DEGENERATE
 
 
+def test_chain_reproduces_every_cell_of_the_bag_with_the_2018_plane_rule(bag, oracle):
+    """The two cells are not an error of the restatement but a rule of the filter that wrote the bag: up to grid_map 1.6
+    NormalVectorsFilter ran its eigen-solver only on a scatter matrix of full rank and returned UnitZ otherwise (te_oracle.c:
+    teo_set_normals_rank_rule).  With that rule the oracle reproduces all 13 300 cells of every golden layer bit for bit --
+    the discs of (99, 117) and (99, 118) are exactly planar AND tilted, the only two such discs of the map -- and the
+    classification does not hang on a threshold (third pivot exactly 0 on the planar discs, >= 1.4e-3 of the first elsewhere)."""
+    g = oracle.geom(int(bag["rows"]), int(bag["cols"]), float(bag["resolution"]), tuple(bag["position"]))
+    oracle.set_normals_rank_rule(True)
+    try:
+        out = oracle.chain(g, oracle.default_params(), bag["elevation"])
+    finally:
+        oracle.set_normals_rank_rule(False)
+    for k in ("traversability_step", "traversability_slope", "traversability_roughness", "traversability"):
+        assert _bitdiff(out[k], bag[k], g.rows) == set(), k
+    # and the rule changes nothing but those two cells
+    ref = oracle.chain(g, oracle.default_params(), bag["elevation"])
+    for k in ("traversability_slope", "traversability_roughness", "traversability"):
+        assert _bitdiff(out[k], ref[k], g.rows) <= KNOWN_DEGENERATE, k
+    assert _bitdiff(out["traversability_slope"], ref["traversability_slope"], g.rows) == KNOWN_DEGENERATE
+
+
 def test_combine_is_float32_left_to_right(bag, oracle):
     import ctypes as C
     n = bag["traversability"].size
