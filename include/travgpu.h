@@ -170,6 +170,7 @@ int te_get_params(te_ctx* ctx, te_params* p);
 #define TE_OPT_GRAPH_REPLAY 4             /* whole-map launches as a captured hipGraph: 0 by size (the default: from 2^22 cells), 1 always, 2 never */
 #define TE_OPT_POLYGON_PER_CELL 3         /* polygon footprint layers: 1 evaluates every cell of every bounding box instead of the offset table */
 #define TE_OPT_BCAST_RCCL 5               /* te_bcast_params, set on the ROOT context: 0 RCCL only between different devices (the default), 1 also when all contexts share one device (a communicator of one rank) */
+#define TE_OPT_NORMALS_RANK_RULE 6        /* 1: NormalVectorsFilter as grid_map <= 1.6 had it (the filter that wrote TE/maps/elevation_map.bag): a disc whose scatter matrix is rank-deficient -- exactly planar -- gets UnitZ; runs the shape-generic kernels.  0 (default): the current area method */
 int te_set_option(te_ctx* ctx, int option, int value);
 /* rows = size(0), cols = size(1) of every map of the batch; (pos_x,pos_y) = map centre. */
 int te_set_geometry(te_ctx* ctx, int rows, int cols, int batch, double resolution, double pos_x, double pos_y);

@@ -49,6 +49,56 @@ def test_bag_golden_vector(capi, bag):
     assert (got["traversability_step"].view(np.uint32) == bag["traversability_step"].view(np.uint32)).all()
 
 
+def test_bag_golden_vector_every_cell_with_the_2018_plane_rule(capi, oracle, bag):
+    """TE_OPT_NORMALS_RANK_RULE: NormalVectorsFilter as the filter that wrote the bag had it (a disc whose scatter matrix is
+    rank-deficient gets UnitZ: oracle/te_oracle.c, teo_set_normals_rank_rule).  With it the GPU reproduces the reference's
+    golden layers on ALL 13 300 cells -- the two exactly planar, tilted border discs included -- and, being the generic
+    kernels, bit for bit; without it those two cells are the only difference."""
+    rows, cols = int(bag["rows"]), int(bag["cols"])
+    with capi.Context(0) as ctx:
+        ctx.set_params(capi.default_params())
+        ctx.set_geometry(rows, cols, 1, float(bag["resolution"]), tuple(bag["position"]))
+        ctx.upload_elevation(bag["elevation"])
+        ctx.set_option(capi.OPT_NORMALS_RANK_RULE, 1)
+        ctx.run_chain(0)
+        ctx.sync()
+        got = {k: ctx.download(k) for k in OUT_LAYERS}
+        ctx.set_option(capi.OPT_NORMALS_RANK_RULE, 0)
+        ctx.run_chain(capi.RUN_GENERIC_KERNELS)
+        ctx.sync()
+        plain = {k: ctx.download(k) for k in OUT_LAYERS}
+    for k in OUT_LAYERS:
+        bad = np.flatnonzero(got[k].view(np.uint32) != bag[k].reshape(-1).view(np.uint32))
+        assert bad.size == 0, (k, [(int(c % rows), int(c // rows)) for c in bad[:5]])
+    diff = np.flatnonzero(plain["traversability_slope"].view(np.uint32) != got["traversability_slope"].view(np.uint32))
+    assert {(int(c % rows), int(c // rows)) for c in diff} == {(99, 117), (99, 118)}
+    # the oracle's rule and the library's agree on a map of exact planes, steps and noise
+    from traversability_estimation_amd import synth
+    r2, c2, res = 120, 90, 0.0625  # (a dyadic resolution: the oracle's centred sums of an exact plane cancel exactly, as on the bag)
+    e = synth.perlin_elevation(r2, c2, seed=31).reshape(c2, r2)
+    ii, jj = np.meshgrid(np.arange(r2, dtype=np.float32), np.arange(c2, dtype=np.float32))
+    e[:, :40] = (np.float32(0.25) * ii + np.float32(0.125) * jj)[:, :40] * np.float32(1.0 / 32)  # an exact plane (dyadic slopes)
+    e[20:40, 50:80] = np.float32(0.75)                                                            # a flat plateau with a step around it
+    op = oracle.default_params(normals_radius=synth.benchmark_radius(2, res), rough_radius=synth.benchmark_radius(2, res))
+    g = oracle.geom(r2, c2, res)
+    oracle.set_normals_rank_rule(True)
+    try:
+        want = oracle.chain(g, op, e)
+    finally:
+        oracle.set_normals_rank_rule(False)
+    ref = oracle.chain(g, op, e)
+    assert (want["traversability_slope"] != ref["traversability_slope"]).sum() > 1000  # the tilted plane's cells
+    with capi.Context(0) as ctx:
+        ctx.set_params(to_te_params(capi, op))
+        ctx.set_geometry(r2, c2, 1, res)
+        ctx.upload_elevation(e)
+        ctx.set_option(capi.OPT_NORMALS_RANK_RULE, 1)
+        ctx.run_chain(0)
+        ctx.sync()
+        got2 = {k: ctx.download(k) for k in OUT_LAYERS}
+    assert_layers_match(got2, want, ctx="exact planes with the 2018 plane rule")
+
+
 def test_bag_vs_oracle(capi, oracle, bag):
     got, want = both(capi, oracle, bag["elevation"], int(bag["rows"]), int(bag["cols"]), float(bag["resolution"]),
                      tuple(bag["position"]))

@@ -26,7 +26,7 @@ RUN_GENERIC_KERNELS = 0x4
 RUN_FOOTPRINT_MEMO = 0x8
 RUN_SEQUENTIAL = 0x10
 RUN_NORMALS_ONLY = 0x20
-OPT_FP_BLOCKED_WALK, OPT_FP_BLOCKED_BLOCKS_PER_CU, OPT_POLYGON_PER_CELL, OPT_GRAPH_REPLAY, OPT_BCAST_RCCL = 1, 2, 3, 4, 5
+OPT_FP_BLOCKED_WALK, OPT_FP_BLOCKED_BLOCKS_PER_CU, OPT_POLYGON_PER_CELL, OPT_GRAPH_REPLAY, OPT_BCAST_RCCL, OPT_NORMALS_RANK_RULE = 1, 2, 3, 4, 5, 6
 
 # every symbol include/travgpu.h declares (tests/test_cabi.py checks the library exports them all)
 SYMBOLS = ["te_params_default", "te_params_validate", "te_device_count", "te_create", "te_destroy",

@@ -142,6 +142,56 @@ __device__ __forceinline__ void normal_from_cov(const Mom& m, const double c[6],
   nf[2] = (float)(sgn * nv[2]);
 }
 
+// TE_OPT_NORMALS_RANK_RULE: is the scatter matrix of the disc rank-deficient (its points exactly on a plane or a line)?
+// NormalVectorsFilter up to grid_map 1.6 -- the filter that wrote the reference's bag; from memory, the library is not
+// vendored -- ran its eigen-solver only if covarianceMatrix.fullPivHouseholderQr().rank() >= 3 and returned UnitZ otherwise
+// (oracle/te_oracle.c: teo_set_normals_rank_rule restates it on the centred points).  Here: full pivoting on the covariance
+// from the centre-local moments (rank is scale-invariant); a pivot counts if it exceeds 1e-12 of the first.  On exactly
+// planar data the third pivot is rounding noise of the moment form, ~1e-16 of the first (the oracle's centred form: 0);
+// on the bag every other disc has >= 1.4e-3, and a disc of float32 terrain whose residual is below 1e-6 of its extent
+// does not occur -- the threshold decides nothing.
+__device__ __forceinline__ bool rank_deficient(const double c[6]) {
+  double S[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}};
+  double first = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int pr = k, pc = k;
+    double best = -1.0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+        if (u >= k && v >= k && fabs(S[u][v]) > best) {
+          best = fabs(S[u][v]);
+          pr = u;
+          pc = v;
+        }
+    if (k == 0) first = best;
+    if (!(best > 1e-12 * first) || best == 0.0) return true;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const double t = S[k][v];
+      S[k][v] = S[pr][v];
+      S[pr][v] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const double t = S[u][k];
+      S[u][k] = S[u][pc];
+      S[u][pc] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (u > k) {
+        const double f = S[u][k] / S[k][k];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+          if (v >= k) S[u][v] -= f * S[k][v];
+      }
+  }
+  return false;
+}
+
 __device__ __forceinline__ float slope_score(float nz, double crit) {
   const double slope = acos((double)nz);  // SlopeFilter.cpp:74
   return slope < crit ? (float)(1.0 - slope / crit) : 0.0f;

@@ -76,7 +76,7 @@ struct te_ctx {
   // still assume the bound; te_run_footprint and region runs take the double kernel.  Reset with the layers.
   bool trav_ptr_out = false;
   // te_set_option: choices between kernels that give identical results (tests reach both; never read from the environment)
-  int opt_fb_walk = 0, opt_fb_blocks_per_cu = 0, opt_polygon_per_cell = 0, opt_graph = 0, opt_bcast_rccl = 0;
+  int opt_fb_walk = 0, opt_fb_blocks_per_cu = 0, opt_polygon_per_cell = 0, opt_graph = 0, opt_bcast_rccl = 0, opt_rank_rule = 0;
   // invalid cells of the elevation layer as of the last whole upload (-1: unknown -- tiles, device pointer): see sparse_holes()
   long long invalid_cells = -1;
   long long invalid_runs = -1;  // runs of invalid cells in memory order (k_count_invalid); meaningful with invalid_cells >= 0

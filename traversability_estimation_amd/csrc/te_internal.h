@@ -76,6 +76,7 @@ struct ChainParams {
   Disc normals, rough, step1, step2;
   int same_rough_disc;  // roughness radius selects the same cells as the normals radius
   int axis;             // normal_vector_positive_axis
+  int rank_rule;        // TE_OPT_NORMALS_RANK_RULE: a rank-deficient scatter matrix gives UnitZ (generic normals kernel)
   double slope_crit, step_crit, rough_crit;
   int step_ncrit;
   float w_scale, w_slope, w_step, w_rough;

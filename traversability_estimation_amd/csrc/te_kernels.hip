@@ -218,6 +218,7 @@ struct NormalsArgs {
   float w_scale, w_slope, w_step, w_rough;
   int combine;  // also write the traversability layer (reads the step layer)
   int given_normals;  // RoughnessFilter alone: surface_normal_{x,y,z} are INPUT layers (RoughnessFilter.cpp:108-110)
+  int rank_rule;      // TE_OPT_NORMALS_RANK_RULE (te_cell.h: rank_deficient)
   float band_slope, band_rough;  // k_normals_fixup: a fast-tail score within this of its clip takes the generic arithmetic (te_internal.h)
 };
 
@@ -260,6 +261,10 @@ __device__ __forceinline__ void normals_cell(const Geo& g, const NormalsArgs& a,
     accumulate_disc(m, g, a.dn, ctr, tw, i, j, z0);
     covariance(m, g.res, cov);
     normal_from_cov(m, cov, a.axis, nf);
+    if (a.rank_rule && m.n >= 3 && rank_deficient(cov)) {  // (uniform flag) UnitZ, towards the positive axis
+      nf[0] = nf[1] = 0.0f;
+      nf[2] = 1.0f;  // (UnitZ . axis is 1 or 0: never negative, no flip)
+    }
     o_slope = slope_score(nf[2], a.slope_crit);
     if (!a.same_disc) {
       mom_zero(m);
@@ -531,6 +536,7 @@ hipError_t launch_filter(const Geo& g, const ChainParams& p, const Layers& L, in
     na.dr = p.rough;
     na.same_disc = 1;
     na.axis = p.axis;
+    na.rank_rule = p.rank_rule;
     na.slope_crit = p.slope_crit;
     na.rough_crit = p.rough_crit;
     na.w_scale = na.w_slope = na.w_step = na.w_rough = 0.0f;
@@ -622,6 +628,7 @@ hipError_t launch_chain(const Geo& g, const ChainParams& p, const Layers& L, con
   na.dr = p.rough;
   na.same_disc = p.same_rough_disc;
   na.axis = p.axis;
+  na.rank_rule = p.rank_rule;
   na.slope_crit = p.slope_crit;
   na.rough_crit = p.rough_crit;
   na.w_scale = p.w_scale;

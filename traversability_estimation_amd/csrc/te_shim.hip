@@ -526,6 +526,8 @@ int run_chain_locked(te_ctx* c, unsigned flags, const Region& r) {
   c->L.hole_queue = c->hole_queue;
   ensure_tie_scratch(c);  // (likewise)
   c->L.tie_scratch = c->tie_scratch;
+  c->cp.rank_rule = c->opt_rank_rule;
+  if (c->opt_rank_rule) flags |= TE_RUN_GENERIC_KERNELS;  // (the rule lives in the generic normals kernel only)
   HIP_TRY(launch_chain(c->geo, c->cp, c->L, r, flags, c->stream));
   c->chain_done = true;
   c->footprint_done = false;  // the layers the footprint pass reads have changed
@@ -561,6 +563,7 @@ int run_whole_locked(te_ctx* c, unsigned flags) {
   const bool large = c->opt_graph == 1 || (c->opt_graph == 0 && (size_t)c->geo.rows * c->geo.cols * c->geo.batch >= ((size_t)1 << 22));
   // (only the defined TE_RUN_* bits: the graph key below puts its own hints into the upper bits of the same word)
   flags &= TE_RUN_KEEP_NORMALS | TE_RUN_FOOTPRINT | TE_RUN_GENERIC_KERNELS | TE_RUN_FOOTPRINT_MEMO | TE_RUN_SEQUENTIAL | TE_RUN_NORMALS_ONLY;
+  if (c->opt_rank_rule) flags |= TE_RUN_GENERIC_KERNELS;
   if (flags & TE_RUN_NORMALS_ONLY) flags &= ~(TE_RUN_FOOTPRINT | TE_RUN_FOOTPRINT_MEMO);
   if (!no_graph && large && !(flags & TE_RUN_NORMALS_ONLY) && c->graph_ok && c->have_params && c->have_geo && c->have_elev) {
     if (!c->tables_ready) {
@@ -825,6 +828,11 @@ int te_set_option(te_ctx* c, int option, int value) {
     case TE_OPT_BCAST_RCCL:
       c->opt_bcast_rccl = value != 0;
       return TE_OK;  // (no launch depends on it)
+    case TE_OPT_NORMALS_RANK_RULE:
+      c->opt_rank_rule = value != 0;
+      c->chain_done = false;
+      c->footprint_done = false;
+      break;
     default:
       return fail(TE_ERR_INVALID_ARG, "te_set_option: unknown option %d", option);
   }
