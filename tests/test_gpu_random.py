@@ -60,6 +60,26 @@ def draw_case(seed):
     return rows, cols, res, pos, elev, over
 
 
+def _forgive_rounding_ties_of_the_normal_layer(oracle, got, want, op, rows, cols, res, pos, elev):
+    """NormalVectorsFilter stores the normal as float32 and SlopeFilter takes acos of the stored nz (SlopeFilter.cpp:74): on a
+    nearly flat cell ONE float32 ulp of nz moves the score by 6e-8 / (slope * slope_critical) -- 1.4e-5 at 0.01 rad and a
+    critical angle of 0.43.  Where the double nz of a disc lies halfway between two floats, the last bit of whichever solver
+    computes it decides (seeds 133562 and 262504 of 75 000 swept cases, profiles/r06_sweep.json: 0.500000 ulps).  A slope cell
+    beyond the tolerance is forgiven if its value IS the score of the oracle's nz moved by one float32 ulp (to 2e-7); the
+    layers that depend on it follow within their own tolerance."""
+    a, b = got["traversability_slope"].reshape(-1), want["traversability_slope"].reshape(-1)
+    both = np.isfinite(a) & np.isfinite(b)
+    bad = np.flatnonzero(both & (np.abs(a.astype(np.float64) - b.astype(np.float64)) > 1e-5))
+    if bad.size == 0 or bad.size > 3:
+        return
+    nz = oracle.chain(oracle.geom(rows, cols, res, pos), op, elev, want_normals=True)["surface_normal_z"].reshape(-1)
+    for c in bad:
+        v = np.float32(nz[c])
+        cands = [1.0 - np.arccos(np.float64(n)) / op.slope_critical for n in (np.nextafter(v, np.float32(2)), np.nextafter(v, np.float32(-2)))]
+        if min(abs(float(a[c]) - max(s, 0.0)) for s in cands) <= 2e-7:
+            a[c] = b[c]  # (the same array the comparison below reads)
+
+
 import os
 
 # TE_RANDOM_CASES="first:count" widens the sweep (default: 40 cases)
@@ -72,6 +92,7 @@ def test_random_case(capi, oracle, seed):
     if (over["fp_radius"] + over["fp_offset"]) / res > 19.5:  # footprint reach limit of the kernels (20 cells)
         over["fp_offset"] = 0.0
     got, want, op = both_fp(capi, oracle, elev, rows, cols, res, pos=pos, **over)
+    _forgive_rounding_ties_of_the_normal_layer(oracle, got, want, op, rows, cols, res, pos, elev)
     check_fp(got, want, op, f"random case seed {seed}: {rows}x{cols} res {res} {over}")
     for k in OUT_LAYERS:
         assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), (seed, k)
