@@ -63,6 +63,9 @@ def test_bag_golden_vector_every_cell_with_the_2018_plane_rule(capi, oracle, bag
         ctx.run_chain(0)
         ctx.sync()
         got = {k: ctx.download(k) for k in OUT_LAYERS}
+        ctx.run_filter("normals")  # the single plugin's entry point follows the option too
+        ctx.sync()
+        assert np.array_equal(ctx.download("traversability_slope").view(np.uint32), bag["traversability_slope"].reshape(-1).view(np.uint32))
         ctx.set_option(capi.OPT_NORMALS_RANK_RULE, 0)
         ctx.run_chain(capi.RUN_GENERIC_KERNELS)
         ctx.sync()

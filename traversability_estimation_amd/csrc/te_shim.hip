@@ -945,6 +945,8 @@ int te_run_filter(te_ctx* c, int filter, unsigned flags) {
   c->L.no_holes = c->invalid_cells == 0 ? 1 : 0;
   c->L.skip_clean = c->L.sparse_holes && skip_clean_march(c) ? 1 : 0;
   c->L.short_strips = short_strips(c) ? 1 : 0;
+  c->cp.rank_rule = c->opt_rank_rule;  // (TE_OPT_NORMALS_RANK_RULE: as in the chain)
+  if (c->opt_rank_rule) flags |= TE_RUN_GENERIC_KERNELS;
   HIP_TRY(launch_filter(c->geo, c->cp, c->L, filter, flags, c->stream));
   // A single plugin's filter overwrites score layers from whatever inputs are resident (TE_FILTER_NORMALS also slope
   // and roughness, with the normals radius): the layers no longer form one chain result, so region re-filters, the

@@ -27,6 +27,7 @@ class SurfaceNormalsFilter : public FilterBase<T> {
  private:
   double radius_;
   int axis_;
+  int rankRule_;  // unit_z_for_planar_discs (TE_OPT_NORMALS_RANK_RULE)
   std::string inputLayer_, prefix_;
 };
 

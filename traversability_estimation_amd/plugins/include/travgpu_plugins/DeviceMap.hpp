@@ -27,6 +27,7 @@ class DeviceMap {
   bool prepare(const grid_map::GridMap& map);                       // (re)sets the geometry if it changed, notes the start index
   bool params(te_params& p);                                        // current parameter set (to edit and pass back)
   bool setParams(const te_params& p);
+  bool setOption(int option, int value);                            // te_set_option (e.g. TE_OPT_NORMALS_RANK_RULE)
   // Uploads a layer unless the device already holds exactly this one: the reference's chain hands every plugin a deep
   // copy of the whole map (SlopeFilter.cpp:62, StepFilter.cpp:105, RoughnessFilter.cpp:76), so StepFilter and
   // RoughnessFilter both arrive with the same `elevation`, SlopeFilter and RoughnessFilter with the same

@@ -108,6 +108,11 @@ bool DeviceMap::setParams(const te_params& p) {
   return check(te_set_params(ctx_, &p));
 }
 
+bool DeviceMap::setOption(int option, int value) {
+  if (!ctx_ && !check(te_create(0, &ctx_))) return false;
+  return check(te_set_option(ctx_, option, value));
+}
+
 bool DeviceMap::upload(const grid_map::GridMap& map, const std::string& layer, int te_layer) {
   if (!map.exists(layer)) {
     error_ = "input layer '" + layer + "' is missing";

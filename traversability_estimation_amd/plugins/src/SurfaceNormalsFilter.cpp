@@ -13,7 +13,7 @@ using travgpu_plugins::DeviceMap;
 namespace filters {
 
 template <typename T>
-SurfaceNormalsFilter<T>::SurfaceNormalsFilter() : radius_(0.05), axis_(2), inputLayer_("elevation"), prefix_("surface_normal_") {}
+SurfaceNormalsFilter<T>::SurfaceNormalsFilter() : radius_(0.05), axis_(2), rankRule_(0), inputLayer_("elevation"), prefix_("surface_normal_") {}
 
 template <typename T>
 SurfaceNormalsFilter<T>::~SurfaceNormalsFilter() {}
@@ -42,6 +42,9 @@ bool SurfaceNormalsFilter<T>::configure() {
   }
   FilterBase<T>::getParam(std::string("input_layer"), inputLayer_);
   FilterBase<T>::getParam(std::string("output_layers_prefix"), prefix_);
+  // optional: NormalVectorsFilter's degenerate-plane rule of grid_map <= 1.6 (UnitZ for an exactly planar disc; the filter
+  // that wrote the reference's bag: travgpu.h TE_OPT_NORMALS_RANK_RULE); default: today's area method
+  FilterBase<T>::getParam(std::string("unit_z_for_planar_discs"), rankRule_);
   return true;
 }
 
@@ -57,7 +60,8 @@ bool SurfaceNormalsFilter<T>::update(const T& mapIn, T& mapOut) {
   if (ok) {
     p.normals_radius = radius_;
     p.normals_axis = axis_;
-    ok = dev.setParams(p) && dev.upload(mapOut, inputLayer_, TE_LAYER_ELEVATION) && dev.runFilter(TE_FILTER_NORMALS);
+    ok = dev.setParams(p) && dev.setOption(TE_OPT_NORMALS_RANK_RULE, rankRule_ ? 1 : 0) && dev.upload(mapOut, inputLayer_, TE_LAYER_ELEVATION) &&
+         dev.runFilter(TE_FILTER_NORMALS);
   }
   for (int k = 0; ok && k < 3; ++k) {
     const std::string name = prefix_ + kAxis[k];
