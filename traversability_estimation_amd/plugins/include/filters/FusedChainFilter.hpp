@@ -29,6 +29,7 @@ class FusedChainFilter : public FilterBase<T> {
  private:
   te_params params_;
   int keepNormals_;
+  int rankRule_;  // unit_z_for_planar_discs (TE_OPT_NORMALS_RANK_RULE)
 };
 
 }  // namespace filters

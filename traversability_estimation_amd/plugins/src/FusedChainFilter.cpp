@@ -13,7 +13,7 @@ using travgpu_plugins::DeviceMap;
 namespace filters {
 
 template <typename T>
-FusedChainFilter<T>::FusedChainFilter() : keepNormals_(0) {
+FusedChainFilter<T>::FusedChainFilter() : keepNormals_(0), rankRule_(0) {
   te_params_default(&params_);
 }
 
@@ -32,6 +32,7 @@ bool FusedChainFilter<T>::configure() {
   FilterBase<T>::getParam(std::string("roughness_critical_value"), params_.rough_critical);
   FilterBase<T>::getParam(std::string("estimation_radius"), params_.rough_radius);
   FilterBase<T>::getParam(std::string("keep_surface_normals"), keepNormals_);
+  FilterBase<T>::getParam(std::string("unit_z_for_planar_discs"), rankRule_);  // TE_OPT_NORMALS_RANK_RULE (see SurfaceNormalsFilter)
   if (te_params_validate(&params_) != TE_OK) {
     ROS_ERROR("%s", te_last_error());
     return false;
@@ -48,7 +49,8 @@ bool FusedChainFilter<T>::update(const T& mapIn, T& mapOut) {
   static const int kNL[3] = {TE_LAYER_NORMAL_X, TE_LAYER_NORMAL_Y, TE_LAYER_NORMAL_Z};
   DeviceMap& dev = DeviceMap::instance();
   std::lock_guard<std::mutex> lock(dev.mutex());
-  bool ok = dev.prepare(mapOut) && dev.setParams(params_) && dev.upload(mapOut, "elevation", TE_LAYER_ELEVATION) &&
+  bool ok = dev.prepare(mapOut) && dev.setParams(params_) && dev.setOption(TE_OPT_NORMALS_RANK_RULE, rankRule_ ? 1 : 0) &&
+            dev.upload(mapOut, "elevation", TE_LAYER_ELEVATION) &&
             dev.runChain(keepNormals_ ? TE_RUN_KEEP_NORMALS : 0u);
   for (int k = 0; ok && k < 4; ++k) {
     mapOut.add(kOut[k]);
