@@ -106,6 +106,31 @@ __device__ __forceinline__ void for_disc(const Geo& g, const Disc& d, int i, int
 
 // checkForSlope :867-893 / checkForRoughness :895-921: more than ncrit zeros of `layer` in circle(3*res)?
 __device__ __forceinline__ bool count_zero_ok(const Geo& g, const Disc& d, const TileView& layer, int i, int j, int ncrit) {
+  // circle(3 * res) away from the border -- what nearly every call sees: the 5 x 5 block (di^2 + dj^2 <= 8) and the four axis
+  // cells at distance 3, which lie ON the circle (isInside decides per centre; an axis cell's test without its exactly-zero
+  // term).  All 29 loads are issued together; the general loop below takes them one at a time, and where the slope score is 0
+  // in a fifth of the cells (the default 0.05 m normals radius on a 0.05 m map: discs whose cells are collinear have a
+  // horizontal normal) the slow cells' list is a tenth of the tile: k_fp_mask 132 -> 105 us on 4096^2.  (The 29 live values
+  // cost registers: k_fp_mask is held at 128 by amdgpu_waves_per_eu, see there.)
+  if (d.R == 2 && d.hw[0] == 2 && d.hw[1] == 2 && d.hw[2] == 2 && d.n_ties == 4 && d.reach == 3 && layer.lds == nullptr && i >= 3 && j >= 3 &&
+      i < g.rows - 3 && j < g.cols - 3) {
+    const float* const c = layer.glob + ((size_t)j * layer.rows + i);
+    const ptrdiff_t rs = (ptrdiff_t)layer.rows;
+    float v[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) v[k] = c[(ptrdiff_t)(k / 5 - 2) * rs + (k % 5 - 2)];
+    const float wxp = c[3], wxm = c[-3], wyp = c[3 * rs], wym = c[-3 * rs];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) n += (v[k] == 0.0f) ? 1 : 0;
+    const double xi = cell_x(g, i), yj = cell_y(g, j);
+    const double dxp = cell_x(g, i + 3) - xi, dxm = cell_x(g, i - 3) - xi, dyp = cell_y(g, j + 3) - yj, dym = cell_y(g, j - 3) - yj;
+    n += (dxp * dxp <= d.r2 && wxp == 0.0f) ? 1 : 0;
+    n += (dxm * dxm <= d.r2 && wxm == 0.0f) ? 1 : 0;
+    n += (dyp * dyp <= d.r2 && wyp == 0.0f) ? 1 : 0;
+    n += (dym * dym <= d.r2 && wym == 0.0f) ? 1 : 0;
+    return !(n > ncrit);
+  }
   int n = 0;
   for_disc(g, d, i, j, [&](int a, int b) { n += (layer.at(a, b) == 0.0f) ? 1 : 0; });
   return !(n > ncrit);
@@ -352,8 +377,11 @@ struct MaskArgs {
 // isTraversableForFilters :774-792 for every cell of a 64 x MY tile; every thread owns MY / 4 cells of a column.  MY = 8
 // (4 for very small maps) for maps too small to fill the GPU with 64 x 32 tiles: a thread's cells that need the full checkForStep are serial,
 // and on the reference's own 100 x 133 map (where half of the cells do) ten workgroups took 0.32 ms.
+// (amdgpu_waves_per_eu(4, 4): four waves per SIMD, 128 registers.  Left to itself the compiler takes 132-136 once
+// count_zero_ok holds its 29 values, and every tile -- with or without such cells -- runs at three waves: 67 -> 81 us on the
+// bench map.  Held at 128 it spills 144 bytes on the slow cells' path and the straight-line pass keeps its time.)
 template <int MY>
-__global__ __launch_bounds__(MX* MBY) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
+__global__ __launch_bounds__(MX* MBY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fp_mask(Geo g, MaskArgs a, const float* __restrict__ elev,
                                                      const float* __restrict__ slope, const float* __restrict__ step,
                                                      const float* __restrict__ rough, uint8_t* __restrict__ untrav,
                                                      float* __restrict__ slope_fp, float* __restrict__ step_fp,
